@@ -1,0 +1,320 @@
+"""Host-side mirror of the reference's Python solver module (reference cl.py:1-360),
+driving hand-written HIP kernels through the C ABI instead of pyopencl.
+
+Same names, argument meaning and return values as the reference for the CG path:
+
+    initialize_cl_environment()                 reference cl.py:16-19
+    initialize_cl_environment_with_device(dev)  reference cl.py:21-24
+    get_gpu_devices()                           reference cl.py:26-31
+    load_and_build_kernels(ctx, n_rhs)          reference cl.py:33-42
+    CG(ctx, queue, kernels, size, non_zeros, a_values, b_values, a_pointers,
+       a_cols, x, n_rhs, n_iterations, device=None)            reference cl.py:44-200
+    conjugate_gradient_multi_gpu(<same>, device)                reference cl.py:203-360
+
+Differences a caller can observe (all documented in INTEGRATION.md):
+  * nothing is JIT-compiled: the kernels are precompiled for gfx950, so
+    load_and_build_kernels is cheap and independent of n_rhs;
+  * the value type follows a_values.dtype (complex64 at the reference's call sites,
+    p_h-PY_C-CL.py:1926-1933; float32/float64/complex128 also work) instead of the
+    module-level IS_COMPLEX switch;
+  * errors raise CgAmdError instead of being printed and ignored.
+There is no CPU fallback: without the HIP library or a GPU these functions raise.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import CgAmdError, check, ptr  # noqa: F401
+
+# module constants of the reference (cl.py:5-7); values are those of the CDNA4 build
+IS_COMPLEX = True
+WAVE_SIZE = 64
+LOCAL_SIZE = 4 * WAVE_SIZE
+
+
+class Device:
+    """A HIP device (stands for a pyopencl.Device)."""
+
+    def __init__(self, index):
+        self.index = int(index)
+        buf = ctypes.create_string_buffer(256)
+        check(_lib.load().cgamd_device_name(self.index, buf, 256))
+        self.name = buf.value.decode()
+
+    def __repr__(self):
+        return f"<Device {self.index}: {self.name}>"
+
+
+class Context:
+    """Owns a cgamd_ctx (device + HIP stream + workspace). Stands for pyopencl.Context."""
+
+    def __init__(self, device=0):
+        self.device = device.index if isinstance(device, Device) else int(device)
+        h = ctypes.c_void_p()
+        check(_lib.load().cgamd_ctx_create(self.device, ctypes.byref(h)))
+        self.handle = h
+        self._lib = _lib.load()
+
+    def set_stream(self, stream):
+        """Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+        check(self._lib.cgamd_ctx_set_stream(self.handle, ctypes.c_void_p(int(stream))))
+
+    @property
+    def stream(self):
+        return self._lib.cgamd_ctx_stream(self.handle) or 0
+
+    def synchronize(self):
+        check(self._lib.cgamd_ctx_synchronize(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.cgamd_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CommandQueue:
+    """Stands for pyopencl.CommandQueue: the in-order HIP stream of a Context."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def flush(self):
+        pass
+
+    def finish(self):
+        self.ctx.synchronize()
+
+
+class DeviceBuffer:
+    """Device memory owned through the C ABI (stands for pyopencl.Buffer)."""
+
+    def __init__(self, ctx, nbytes=None, hostbuf=None, dtype=None):
+        self.ctx = ctx
+        self._lib = _lib.load()
+        if hostbuf is not None:
+            hostbuf = np.ascontiguousarray(hostbuf)
+            nbytes = hostbuf.nbytes
+            dtype = hostbuf.dtype
+        self.nbytes = int(nbytes)
+        self.dtype = np.dtype(dtype) if dtype is not None else np.dtype(np.uint8)
+        p = ctypes.c_void_p()
+        check(self._lib.cgamd_malloc(ctx.handle, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+        if hostbuf is not None and self.nbytes:
+            check(self._lib.cgamd_memcpy_h2d(ctx.handle, p, ptr(hostbuf), self.nbytes))
+
+    def get(self, out=None):
+        if out is None:
+            out = np.empty(self.nbytes // self.dtype.itemsize, dtype=self.dtype)
+        check(self._lib.cgamd_memcpy_d2h(self.ctx.handle, ptr(out), ctypes.c_void_p(self.ptr), self.nbytes))
+        return out
+
+    def release(self):
+        if getattr(self, "ptr", None) and getattr(self.ctx, "handle", None):
+            self._lib.cgamd_free(self.ctx.handle, ctypes.c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def get_gpu_devices():
+    """reference cl.py:26-31 -- list of GPU devices."""
+    n = _lib.load().cgamd_device_count()
+    if n < 0:
+        raise CgAmdError(-n, _lib.load().cgamd_last_error().decode())
+    return [Device(i) for i in range(n)]
+
+
+def initialize_cl_environment():
+    """reference cl.py:16-19 -- (ctx, queue) on the default device."""
+    ctx = Context(0)
+    return ctx, CommandQueue(ctx)
+
+
+def initialize_cl_environment_with_device(device):
+    """reference cl.py:21-24."""
+    ctx = Context(device)
+    return ctx, CommandQueue(ctx)
+
+
+# ---- the five kernels, as callables on DeviceBuffers -------------------------------------------
+def _code(buf):
+    return _lib.DTYPE_CODE[np.dtype(buf.dtype)]
+
+
+class _Kernels(dict):
+    """{'axpy','aypx','spmv','sub','vdot'} -> callables (reference cl.py:36-42).
+
+    spmv(queue, size, a_values, a_pointers, a_cols, x, y, n_rhs=None)
+    vdot(queue, a, b, result, size, n_rhs=None)        result: DeviceBuffer of n_rhs values
+    axpy(queue, x, y, a, a_sign, size, n_rhs=None)     a: DeviceBuffer of n_rhs values
+    aypx(queue, x, y, a, size, n_rhs=None)
+    sub(queue, a, b, result, size, n_rhs=None)
+    """
+
+    def __init__(self, ctx, n_rhs):
+        lib = _lib.load()
+        self.ctx, self.n_rhs = ctx, int(n_rhs)
+        h = ctx.handle
+
+        def spmv(queue, size, a_values, a_pointers, a_cols, x, y, n_rhs=None):
+            nnz = a_cols.nbytes // 4
+            check(lib.cgamd_spmv(h, _code(a_values), int(size), nnz, ptr(a_values), ptr(a_pointers), ptr(a_cols),
+                                 ptr(x), ptr(y), n_rhs or self.n_rhs))
+
+        def vdot(queue, a, b, result, size, n_rhs=None):
+            check(lib.cgamd_vdot(h, _code(a), int(size), ptr(a), ptr(b), ptr(result), n_rhs or self.n_rhs))
+
+        def axpy(queue, x, y, a, a_sign, size, n_rhs=None):
+            check(lib.cgamd_axpy(h, _code(y), int(size), ptr(x), ptr(y), ptr(a), int(a_sign), n_rhs or self.n_rhs))
+
+        def aypx(queue, x, y, a, size, n_rhs=None):
+            check(lib.cgamd_aypx(h, _code(y), int(size), ptr(x), ptr(y), ptr(a), n_rhs or self.n_rhs))
+
+        def sub(queue, a, b, result, size, n_rhs=None):
+            check(lib.cgamd_sub(h, _code(a), int(size), ptr(a), ptr(b), ptr(result), n_rhs or self.n_rhs))
+
+        super().__init__(axpy=axpy, aypx=aypx, spmv=spmv, sub=sub, vdot=vdot)
+
+
+def load_and_build_kernels(ctx, n_rhs):
+    """reference cl.py:33-42.  Nothing is compiled here: the gfx950 code objects ship in libcgamd.so."""
+    return _Kernels(ctx, n_rhs)
+
+
+# ---- persistent solver ------------------------------------------------------------------------
+class Solver:
+    """Matrix-resident CG handle: the reference re-uploads the matrix and re-JITs
+    its kernels on every call (clcg.c:142-214, cl.py:45-46,73-84); here only b goes up and x comes down."""
+
+    def __init__(self, ctx, size, non_zeros, a_values, a_pointers, a_cols, n_rhs=1, flags=0, dtype=None):
+        self.ctx = ctx
+        self._lib = _lib.load()
+        on_device = bool(flags & _lib.MATRIX_ON_DEVICE)
+        if not on_device:
+            self.dtype = np.dtype(dtype) if dtype is not None else np.dtype(a_values.dtype)
+            a_values = np.ascontiguousarray(a_values, dtype=self.dtype)
+            a_pointers = np.ascontiguousarray(a_pointers, dtype=np.intc)
+            a_cols = np.ascontiguousarray(a_cols, dtype=np.intc)
+        else:
+            if dtype is None:
+                raise ValueError("dtype is required for device-resident matrices")
+            self.dtype = np.dtype(dtype)
+        self._keep = (a_values, a_pointers, a_cols)      # borrowed device arrays must outlive the handle
+        self.size, self.n_rhs = int(size), int(n_rhs)
+        h = ctypes.c_void_p()
+        check(self._lib.cgamd_solver_create(ctx.handle, _lib.DTYPE_CODE[self.dtype], self.size, int(non_zeros),
+                                            ptr(a_values), ptr(a_pointers), ptr(a_cols), self.n_rhs, int(flags),
+                                            ctypes.byref(h)))
+        self.handle = h
+
+    def set_rhs(self, b, x0=None, on_device=False):
+        if not on_device:
+            b = np.ascontiguousarray(np.asarray(b).reshape(-1), dtype=self.dtype)
+            if x0 is not None:
+                x0 = np.ascontiguousarray(np.asarray(x0).reshape(-1), dtype=self.dtype)
+        check(self._lib.cgamd_solver_set_rhs(self.handle, ptr(b), ptr(x0), int(on_device)))
+
+    def iterate(self, n_iterations):
+        check(self._lib.cgamd_solver_iterate(self.handle, int(n_iterations)))
+
+    def x(self, out=None):
+        if out is None:
+            out = np.empty(self.size * self.n_rhs, dtype=self.dtype)
+        on_device = not isinstance(out, np.ndarray)
+        check(self._lib.cgamd_solver_get_x(self.handle, ptr(out), int(on_device)))
+        return out
+
+    def history(self):
+        """delta_k = r_k . r_k (unconjugated) for k = 0..iterations; shape (iterations+1, n_rhs)."""
+        n = self._lib.cgamd_solver_iterations_done(self.handle) + 1
+        out = np.empty((n, self.n_rhs), dtype=self.dtype)
+        got = self._lib.cgamd_solver_history(self.handle, ptr(out), n)
+        if got < 0:
+            check(-got)
+        return out[:got]
+
+    def solve(self, b, x0=None, n_iterations=10):
+        self.set_rhs(b, x0)
+        self.iterate(n_iterations)
+        return self.x(), self.history()
+
+    def spmv(self, x, y, fused_dot=False):
+        check(self._lib.cgamd_solver_spmv(self.handle, ptr(x), ptr(y), int(fused_dot)))
+
+    def vector(self, which):
+        return self._lib.cgamd_solver_vector(self.handle, {"x": 0, "r": 1, "d": 2, "q": 3}[which])
+
+    @property
+    def spmv_bytes(self):
+        return self._lib.cgamd_solver_spmv_bytes(self.handle)
+
+    def iter_bytes(self, fused=False):
+        return self._lib.cgamd_solver_iter_bytes(self.handle, int(fused))
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self._lib.cgamd_solver_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- reference entry points --------------------------------------------------------------------
+def CG(ctx, queue, kernels, size, non_zeros, a_values, b_values, a_pointers, a_cols, x, n_rhs, n_iterations,
+       device=None, return_history=False):
+    """reference cl.py:44-200: exactly n_iterations iterations of (CO)CG on n_rhs right-hand sides.
+
+    a_values/b_values/x: 1-D arrays of the value type (np.csingle at the reference's call sites),
+    a_pointers/a_cols: np.intc.  b_values and x are RHS-major (element i of RHS r at i + r*size).
+    x is the initial guess on input and receives the solution (cl.py:188); it is also returned.
+    """
+    dt = np.dtype(a_values.dtype)
+    if dt not in _lib.DTYPE_CODE:
+        raise TypeError(f"unsupported value type {dt}")
+    if not (isinstance(x, np.ndarray) and x.dtype == dt and x.flags.c_contiguous):
+        raise TypeError("x must be a C-contiguous numpy array of the matrix value type (it is filled in place)")
+    s = Solver(ctx, size, non_zeros, a_values, a_pointers, a_cols, n_rhs)
+    try:
+        s.set_rhs(b_values, x)
+        s.iterate(n_iterations)
+        s.x(out=x.reshape(-1))
+        hist = s.history() if return_history else None
+    finally:
+        s.close()
+    return (x, hist) if return_history else x
+
+
+def conjugate_gradient_multi_gpu(ctx, queue, kernels, size, non_zeros, a_values, b_values, a_pointers, a_cols, x,
+                                 n_rhs, n_iterations, device):
+    """reference cl.py:203-360: the per-device worker of the RHS-sharded multi-GPU mode
+    (p_h-PY_C-CL-multi-GPU.py:2123-2181).  Each device gets the whole matrix and a slice of the
+    right-hand sides; there is no inter-GPU communication.  Thread-safe per (ctx, queue): ctypes
+    releases the GIL during the call, so one Python thread per device runs concurrently, as in the
+    reference.  (The row-partitioned RCCL solver lives in .dist.)"""
+    return CG(ctx, queue, kernels, size, non_zeros, a_values, b_values, a_pointers, a_cols, x, n_rhs, n_iterations,
+              device=device)
+
+
+def cg(size, non_zeros, a_values, b_values, a_pointers, a_cols, x, n_rhs, n_iterations, is_complex):
+    """The C entry cg() (reference clcg.h:3-5) through libcgamd.so, same argument order.
+    a_values/b_values/x must be float32 (or complex64 viewed as such when is_complex)."""
+    lib = _lib.load()
+    lib.cg(int(size), int(non_zeros), ptr(a_values), ptr(b_values), ptr(a_pointers), ptr(a_cols), ptr(x), int(n_rhs),
+           int(n_iterations), int(is_complex))
+    return x

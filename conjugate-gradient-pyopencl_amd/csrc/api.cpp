@@ -1,0 +1,244 @@
+// C ABI: context, memory helpers, the five stand-alone kernels, generators, legacy cg()/connect().
+// The ABI mirrors the reference's Python operator surface (cl.py:16-42) and C entry (clcg.h:3-5).
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/clcg.h"
+#include "cgamd_internal.h"
+
+namespace cgamd {
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(int status, const std::string &msg) {
+    g_err = msg;
+    return status;
+}
+}  // namespace cgamd
+using namespace cgamd;
+
+extern "C" {
+
+const char *cgamd_last_error(void) { return g_err.c_str(); }
+int cgamd_version(void) { return 100; }
+size_t cgamd_dtype_size(int dtype) { return dtype_size(dtype); }
+
+int cgamd_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        fail(CGAMD_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+        return -CGAMD_ERR_NO_DEVICE;
+    }
+    return n;
+}
+
+int cgamd_device_name(int device, char *buf, size_t buflen) {
+    if (!buf || !buflen) return fail(CGAMD_ERR_INVALID, "device_name: null buffer");
+    hipDeviceProp_t p;
+    CG_HIP(hipGetDeviceProperties(&p, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return CGAMD_OK;
+}
+
+int cgamd_ctx_create(int device, cgamd_ctx **out) {
+    if (!out) return fail(CGAMD_ERR_INVALID, "ctx_create: out is NULL");
+    *out = nullptr;
+    int n = cgamd_device_count();
+    if (n <= 0) return fail(CGAMD_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(CGAMD_ERR_INVALID, "ctx_create: device index out of range");
+    CG_HIP(hipSetDevice(device));
+    cgamd_ctx *c = new cgamd_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(CGAMD_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    c->own_stream = true;
+    *out = c;
+    return CGAMD_OK;
+}
+
+int cgamd_ctx_destroy(cgamd_ctx *c) {
+    if (!c) return CGAMD_OK;
+    (void)hipSetDevice(c->device);
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return CGAMD_OK;
+}
+
+int cgamd_ctx_set_stream(cgamd_ctx *c, void *stream) {
+    if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    if (c->own_stream && c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    c->own_stream = false;
+    c->stream = static_cast<hipStream_t>(stream);
+    return CGAMD_OK;
+}
+void *cgamd_ctx_stream(cgamd_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int cgamd_ctx_device(cgamd_ctx *c) { return c ? c->device : -1; }
+int cgamd_ctx_synchronize(cgamd_ctx *c) {
+    if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    CG_HIP(hipSetDevice(c->device));
+    CG_HIP(hipStreamSynchronize(c->stream));
+    return CGAMD_OK;
+}
+
+int cgamd_malloc(cgamd_ctx *c, size_t bytes, void **dptr) {
+    if (!c || !dptr) return fail(CGAMD_ERR_INVALID, "malloc: null argument");
+    CG_HIP(hipSetDevice(c->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(CGAMD_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return CGAMD_OK;
+}
+int cgamd_free(cgamd_ctx *c, void *dptr) {
+    if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    CG_HIP(hipSetDevice(c->device));
+    if (dptr) CG_HIP(hipFree(dptr));
+    return CGAMD_OK;
+}
+int cgamd_memcpy_h2d(cgamd_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    CG_HIP(hipSetDevice(c->device));
+    CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    CG_HIP(hipStreamSynchronize(c->stream));
+    return CGAMD_OK;
+}
+int cgamd_memcpy_d2h(cgamd_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    CG_HIP(hipSetDevice(c->device));
+    CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    CG_HIP(hipStreamSynchronize(c->stream));
+    return CGAMD_OK;
+}
+int cgamd_memcpy_d2d(cgamd_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    CG_HIP(hipSetDevice(c->device));
+    CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return CGAMD_OK;
+}
+int cgamd_memset(cgamd_ctx *c, void *dst, int value, size_t bytes) {
+    if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    CG_HIP(hipSetDevice(c->device));
+    CG_HIP(hipMemsetAsync(dst, value, bytes, c->stream));
+    return CGAMD_OK;
+}
+
+// ---- stand-alone ops ---------------------------------------------------------------------------
+static int check_op(cgamd_ctx *c, int dtype, int size, int nRHS, const char *what) {
+    if (!c) return fail(CGAMD_ERR_INVALID, std::string(what) + ": ctx is NULL");
+    if (dtype < 0 || dtype > 3) return fail(CGAMD_ERR_INVALID, std::string(what) + ": bad dtype");
+    if (size < 0 || nRHS < 1) return fail(CGAMD_ERR_INVALID, std::string(what) + ": bad size/nRHS");
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(CGAMD_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    return CGAMD_OK;
+}
+
+int cgamd_spmv(cgamd_ctx *c, int dtype, int size, long long nnz, const void *aValues, const int *aPointers,
+               const int *aCols, const void *x, void *y, int nRHS) {
+    if (int rc = check_op(c, dtype, size, nRHS, "spmv")) return rc;
+    if (size == 0) return CGAMD_OK;
+    if (!aPointers || !x || !y || (nnz > 0 && (!aValues || !aCols))) return fail(CGAMD_ERR_INVALID, "spmv: null pointer");
+    const SpmvPlan plan = make_spmv_plan(size);
+    return launch_spmv(dtype, plan, size, nnz, aValues, aPointers, aCols, x, size, y, size, nRHS, nullptr, nullptr, c->stream);
+}
+
+static int ensure_partials(cgamd_ctx *c, size_t bytes) {
+    if (c->partials_bytes >= bytes) return CGAMD_OK;
+    if (c->partials) {
+        CG_HIP(hipStreamSynchronize(c->stream));
+        CG_HIP(hipFree(c->partials));
+        c->partials = nullptr;
+        c->partials_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&c->partials, bytes);
+    if (e != hipSuccess) return fail(CGAMD_ERR_ALLOC, std::string("hipMalloc(partials): ") + hipGetErrorString(e));
+    c->partials_bytes = bytes;
+    return CGAMD_OK;
+}
+
+int cgamd_vdot(cgamd_ctx *c, int dtype, int size, const void *a, const void *b, void *result, int nRHS) {
+    if (int rc = check_op(c, dtype, size, nRHS, "vdot")) return rc;
+    if (!result || (size > 0 && (!a || !b))) return fail(CGAMD_ERR_INVALID, "vdot: null pointer");
+    const int grid = vec_grid(size, dtype);
+    if (int rc = ensure_partials(c, acc_size(dtype) * (size_t)grid * nRHS)) return rc;
+    if (int rc = launch_dot_partials(dtype, size, a, b, size, nRHS, c->partials, grid, c->stream)) return rc;
+    return launch_reduce_to_value(dtype, c->partials, grid, nRHS, result, c->stream);
+}
+
+int cgamd_axpy(cgamd_ctx *c, int dtype, int size, const void *x, void *y, const void *a, int aSign, int nRHS) {
+    if (int rc = check_op(c, dtype, size, nRHS, "axpy")) return rc;
+    if (size > 0 && (!x || !y || !a)) return fail(CGAMD_ERR_INVALID, "axpy: null pointer");
+    return launch_axpy(dtype, size, x, y, size, a, aSign, nRHS, c->stream);
+}
+int cgamd_aypx(cgamd_ctx *c, int dtype, int size, const void *x, void *y, const void *a, int nRHS) {
+    if (int rc = check_op(c, dtype, size, nRHS, "aypx")) return rc;
+    if (size > 0 && (!x || !y || !a)) return fail(CGAMD_ERR_INVALID, "aypx: null pointer");
+    return launch_aypx(dtype, size, x, y, size, a, nRHS, c->stream);
+}
+int cgamd_sub(cgamd_ctx *c, int dtype, int size, const void *a, const void *b, void *result, int nRHS) {
+    if (int rc = check_op(c, dtype, size, nRHS, "sub")) return rc;
+    if (size > 0 && (!a || !b || !result)) return fail(CGAMD_ERR_INVALID, "sub: null pointer");
+    return launch_sub(dtype, size, a, b, result, size, nRHS, c->stream);
+}
+
+// ---- generators --------------------------------------------------------------------------------
+int cgamd_gen_laplace3d(cgamd_ctx *c, int dtype, int nx, int ny, int nz, long long row_begin, long long row_end,
+                        void *aValues, int *aPointers, int *aCols, long long *nnz_out) {
+    const long long n = (long long)nx * ny * nz;
+    if (nx < 1 || ny < 1 || nz < 1 || row_begin < 0 || row_end > n || row_begin > row_end)
+        return fail(CGAMD_ERR_INVALID, "gen_laplace3d: bad grid or row range");
+    if (n > 2147483647LL) return fail(CGAMD_ERR_INVALID, "gen_laplace3d: more than 2^31-1 columns (int32 column indices)");
+    const long long nnz = laplace3d_ptr(row_end, nx, ny, nz) - laplace3d_ptr(row_begin, nx, ny, nz);
+    if (nnz_out) *nnz_out = nnz;
+    if (!aPointers) return CGAMD_OK;  // size query
+    if (nnz > 2147483647LL - 8192) return fail(CGAMD_ERR_INVALID, "gen_laplace3d: slab has more than 2^31 entries");
+    if (int rc = check_op(c, dtype, 0, 1, "gen_laplace3d")) return rc;
+    if (!aValues || !aCols) return fail(CGAMD_ERR_INVALID, "gen_laplace3d: null pointer");
+    return launch_gen_laplace3d(dtype, nx, ny, nz, row_begin, row_end, aValues, aPointers, aCols, c->stream);
+}
+
+int cgamd_gen_poisson2d(cgamd_ctx *c, int dtype, int N, void *aValues, int *aPointers, int *aCols, long long *nnz_out) {
+    if (N < 1 || (long long)N * N > 400000000LL) return fail(CGAMD_ERR_INVALID, "gen_poisson2d: bad N");
+    const long long nnz = poisson2d_ptr((long long)N * N, N);
+    if (nnz_out) *nnz_out = nnz;
+    if (!aPointers) return CGAMD_OK;
+    if (int rc = check_op(c, dtype, 0, 1, "gen_poisson2d")) return rc;
+    if (!aValues || !aCols) return fail(CGAMD_ERR_INVALID, "gen_poisson2d: null pointer");
+    return launch_gen_poisson2d(dtype, N, aValues, aPointers, aCols, c->stream);
+}
+
+// ---- one-call typed solve on host arrays ----------------------------------------------------------
+int cgamd_cg(int dtype, int size, long long nnz, const void *aValues, const void *b, const int *aPointers,
+             const int *aCols, void *x, int nRHS, int nIterations, void *history, int device) {
+    if (size < 0 || nnz < 0 || nRHS < 1 || nIterations < 0) return fail(CGAMD_ERR_INVALID, "cg: bad size argument");
+    if (size == 0) return CGAMD_OK;
+    if (!aPointers || !b || !x || (nnz > 0 && (!aValues || !aCols))) return fail(CGAMD_ERR_INVALID, "cg: null pointer");
+    cgamd_ctx *ctx = nullptr;
+    if (int rc = cgamd_ctx_create(device, &ctx)) return rc;
+    cgamd_solver *s = nullptr;
+    int rc = cgamd_solver_create(ctx, dtype, size, nnz, aValues, aPointers, aCols, nRHS, 0, &s);
+    if (rc == CGAMD_OK) rc = cgamd_solver_solve(s, b, x, nIterations, history);
+    std::string keep = g_err;
+    if (s) cgamd_solver_destroy(s);
+    cgamd_ctx_destroy(ctx);
+    if (rc != CGAMD_OK) g_err = keep;
+    return rc;
+}
+
+// ---- legacy ABI (reference clcg.h:3-5) ------------------------------------------------------------
+float *cg(int size, int nonZeros, const float *aValues, const float *b, const int *aPointers, const int *aCols,
+          float *x, int nRHS, int nIterations, int isComplex) {
+    const int rc = cgamd_cg(isComplex ? CGAMD_C64 : CGAMD_F32, size, nonZeros, aValues, b, aPointers, aCols, x, nRHS,
+                            nIterations, nullptr, 0);
+    if (rc != CGAMD_OK)  // the reference prints and carries on (clcg.c:52-56); x is left as passed in
+        fprintf(stderr, "error -- cg (MI355X/HIP) failed with status %d: %s\n", rc, cgamd_last_error());
+    return x;
+}
+
+}  // extern "C"

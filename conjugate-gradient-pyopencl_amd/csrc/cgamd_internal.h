@@ -1,0 +1,96 @@
+// Host-side internal interfaces between the kernel launchers (kernels.hip), the solver
+// (solver.cpp), the C ABI (api.cpp) and the multi-GPU loop (dist.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../include/cgamd.h"
+
+namespace cgamd {
+
+// ---- error plumbing ---------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(int status, const std::string &msg);
+#define CG_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return ::cgamd::fail(e__ == hipErrorNoDevice || e__ == hipErrorInvalidDevice     \
+                                     ? CGAMD_ERR_NO_DEVICE : CGAMD_ERR_HIP,                  \
+                                 std::string(#expr) + ": " + hipGetErrorString(e__));        \
+    } while (0)
+
+inline size_t dtype_size(int dt) { return dt == 0 ? 4 : dt == 1 ? 8 : dt == 2 ? 8 : dt == 3 ? 16 : 0; }
+inline size_t acc_size(int dt) { return (dt == 0 || dt == 1) ? 8 : 16; }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Launch geometry of the persistent streaming kernels.
+constexpr int kBlock = 256;          // threads per work-group (4 waves)
+constexpr int kMaxGrid = 2048;       // 256 CUs x 8 resident work-groups
+constexpr int kQuadsPerThread = 2;   // SpMV: 2 x 4 non-zeros per thread per chunk -> 2048 nnz / chunk
+
+struct SpmvPlan {
+    int grid = 0;        // work-groups launched (multiple of 8 when >= 8)
+    int row_blocks = 0;  // ceil(n / kBlock)
+};
+SpmvPlan make_spmv_plan(int n);
+int vec_grid(long long n_elems_per_rhs, int dtype);
+
+// ---- kernel launchers (all asynchronous on `st`) ------------------------------
+// y = A x for nrhs vectors; x has leading dimension ldx (>= number of columns), y has ldy.
+// If partials != nullptr also writes per-work-group partial sums of dvec.y (unconjugated),
+// laid out partials[r * plan.grid + wg] in accumulator precision.
+int launch_spmv(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr,
+                const int *cols, const void *x, long long ldx, void *y, long long ldy, int nrhs,
+                const void *dvec, void *partials, hipStream_t st);
+// partial sums of a.b -> partials[r*grid + wg]
+int launch_dot_partials(int dtype, int n, const void *a, const void *b, long long ld, int nrhs, void *partials,
+                        int grid, hipStream_t st);
+// result[r] = sum partials (value type)
+int launch_reduce_to_value(int dtype, const void *partials, int grid, int nrhs, void *result, hipStream_t st);
+int launch_axpy(int dtype, int n, const void *x, void *y, long long ld, const void *a, int sign, int nrhs, hipStream_t st);
+int launch_aypx(int dtype, int n, const void *x, void *y, long long ld, const void *a, int nrhs, hipStream_t st);
+int launch_sub(int dtype, int n, const void *a, const void *b, void *res, long long ld, int nrhs, hipStream_t st);
+// fused x += alpha d ; r -= alpha q ; partials(r.r)
+int launch_axpy2_dot(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld,
+                     const void *alpha, int nrhs, void *partials, int grid, hipStream_t st);
+
+// device-resident scalar state of one CG run
+struct CgScalars {
+    void *alpha = nullptr;     // T[nrhs]
+    void *beta = nullptr;      // T[nrhs]
+    void *delta = nullptr;     // T[nrhs]   current delta_new
+    void *history = nullptr;   // T[cap][nrhs]
+    int *iter = nullptr;       // iterations completed
+    int history_cap = 0;
+};
+// delta[r] = sum partials ; history[0][r] = delta[r] ; *iter = 0
+int launch_cg_delta0(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st);
+// alpha[r] = delta[r] / sum partials_dq
+int launch_cg_alpha(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st);
+// dn = sum partials_rr ; beta = dn/delta ; delta = dn ; history[++iter] = dn
+int launch_cg_beta(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st);
+
+// partials -> accumulator-precision scalar per RHS (all-reduce input); halo pack out[k] = v[index[k]]
+int launch_reduce_to_acc(int dtype, const void *partials, int grid, int nrhs, void *out, hipStream_t st);
+int launch_pack(int dtype, int count, const int *index, const void *v, void *out, hipStream_t st);
+
+// synthetic generators (device)
+int launch_gen_laplace3d(int dtype, int nx, int ny, int nz, long long row_begin, long long row_end, void *vals,
+                         int *ptr, int *cols, hipStream_t st);
+long long laplace3d_ptr(long long i, int nx, int ny, int nz);
+int launch_gen_poisson2d(int dtype, int N, void *vals, int *ptr, int *cols, hipStream_t st);
+long long poisson2d_ptr(long long i, int N);
+
+}  // namespace cgamd
+
+// ---- context (shared by api.cpp / solver.cpp / dist.cpp) ---------------------------
+struct cgamd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void *partials = nullptr;   // workspace for the stand-alone vdot op
+    size_t partials_bytes = 0;
+};

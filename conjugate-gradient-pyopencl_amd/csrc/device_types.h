@@ -1,0 +1,115 @@
+// Value-type traits and arithmetic helpers shared by all gfx950 kernels.
+//
+// Four value types: float, double, float2 (complex64, interleaved re/im),
+// double2 (complex128).  Complex arithmetic is componentwise exactly as the
+// reference defines it (kernel/complex/cmplx.h:6-25); the dot product is
+// UNCONJUGATED (kernel/complex/vdot.cl:15).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cgamd {
+
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+template <typename T> struct VT;
+template <> struct VT<float> {
+    using acc = double; using real = float;
+    static constexpr int dtype = 0; static constexpr bool cplx = false;
+};
+template <> struct VT<double> {
+    using acc = double; using real = double;
+    static constexpr int dtype = 1; static constexpr bool cplx = false;
+};
+template <> struct VT<float2> {
+    using acc = double2; using real = float;
+    static constexpr int dtype = 2; static constexpr bool cplx = true;
+};
+template <> struct VT<double2> {
+    using acc = double2; using real = double;
+    static constexpr int dtype = 3; static constexpr bool cplx = true;
+};
+
+#define CG_DEV __device__ __forceinline__
+
+template <typename T> CG_DEV T vzero();
+template <> CG_DEV float vzero<float>() { return 0.f; }
+template <> CG_DEV double vzero<double>() { return 0.; }
+template <> CG_DEV float2 vzero<float2>() { return make_float2(0.f, 0.f); }
+template <> CG_DEV double2 vzero<double2>() { return make_double2(0., 0.); }
+
+CG_DEV float vadd(float a, float b) { return a + b; }
+CG_DEV double vadd(double a, double b) { return a + b; }
+CG_DEV float2 vadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+CG_DEV double2 vadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+
+CG_DEV float vsub(float a, float b) { return a - b; }
+CG_DEV double vsub(double a, double b) { return a - b; }
+CG_DEV float2 vsub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+CG_DEV double2 vsub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+
+CG_DEV float vmul(float a, float b) { return a * b; }
+CG_DEV double vmul(double a, double b) { return a * b; }
+CG_DEV float2 vmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+CG_DEV double2 vmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// c + a*b
+template <typename T> CG_DEV T vfma(T a, T b, T c) { return vadd(c, vmul(a, b)); }
+
+// widening to the accumulator type used by reductions and scalar math
+CG_DEV double to_acc(float a) { return (double)a; }
+CG_DEV double to_acc(double a) { return a; }
+CG_DEV double2 to_acc(float2 a) { return make_double2((double)a.x, (double)a.y); }
+CG_DEV double2 to_acc(double2 a) { return a; }
+
+template <typename T> CG_DEV T from_acc(typename VT<T>::acc a);
+template <> CG_DEV float from_acc<float>(double a) { return (float)a; }
+template <> CG_DEV double from_acc<double>(double a) { return a; }
+template <> CG_DEV float2 from_acc<float2>(double2 a) { return make_float2((float)a.x, (float)a.y); }
+template <> CG_DEV double2 from_acc<double2>(double2 a) { return a; }
+
+// scalar division used for alpha = delta/dq and beta = delta_new/delta_old
+// (reference clcg.c:326-327,389-391).  Complex: Smith's algorithm, as C99 / numpy do.
+CG_DEV double acc_div(double a, double b) { return a / b; }
+CG_DEV double2 acc_div(double2 a, double2 b) {
+    if (fabs(b.x) >= fabs(b.y)) {
+        const double ratio = b.y / b.x, den = b.x + b.y * ratio;
+        return make_double2((a.x + a.y * ratio) / den, (a.y - a.x * ratio) / den);
+    }
+    const double ratio = b.x / b.y, den = b.x * ratio + b.y;
+    return make_double2((a.x * ratio + a.y) / den, (a.y * ratio - a.x) / den);
+}
+
+// ---- cross-lane reductions (wave64) -----------------------------------------
+CG_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+CG_DEV double2 wave_sum(double2 v) {
+    v.x = wave_sum(v.x);
+    v.y = wave_sum(v.y);
+    return v;
+}
+
+// Sum over a thread block; result valid in thread 0.  `smem` holds BLOCK/64 entries.
+template <int BLOCK, typename A> CG_DEV A block_sum(A v, A *smem) {
+    constexpr int NW = BLOCK / kWave;
+    v = wave_sum(v);
+    if constexpr (NW == 1) return v;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    __syncthreads();  // smem may be reused by the caller
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < NW; ++i) v = vadd(v, smem[i]);
+    }
+    return v;
+}
+
+// blockIdx -> logical work-group id such that each XCD (blocks are dealt round-robin over the
+// 8 XCDs) owns one contiguous range of logical ids, i.e. a contiguous row range whose gathered
+// x window stays in that XCD's private 4 MiB L2.  Bijective because G % 8 == 0 is required.
+CG_DEV int xcd_remap(int b, int G) { return ((G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b; }
+
+}  // namespace cgamd

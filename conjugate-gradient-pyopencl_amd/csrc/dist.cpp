@@ -1,0 +1,355 @@
+// Row-partitioned multi-GPU CG: one process per GPU, RCCL over xGMI.
+//
+// The reference has no row partitioning (its multi-GPU mode replicates the matrix and splits the RHS
+// columns over devices with zero communication: p_h-PY_C-CL-multi-GPU.py:2123-2181, cl.py:203-360);
+// BASELINE.json's north star asks for the matrix to be row-partitioned, so this file is new design:
+//
+//   rank g owns a contiguous row block; its CSR slice has columns renumbered to
+//   [0,n_local) = own entries of d, [n_local, n_local+n_halo) = entries owned by other ranks.
+//   d lives in one extended buffer d_ext[n_local + n_halo]; the SpMV gathers from it directly.
+//   Per iteration:  pack boundary entries -> grouped ncclSend/ncclRecv with the neighbours (the
+//   "boundary all-gather" restricted to the entries actually referenced) -> SpMV fused with the local
+//   d.q partials -> ncclAllReduce(1 scalar) -> x/r update fused with local r.r partials ->
+//   ncclAllReduce(1 scalar) -> d update.  alpha/beta are computed redundantly on every rank from the
+//   reduced scalars; there is no host synchronisation anywhere in the loop.
+//
+// RCCL is bound at run time with dlopen so that the single-GPU library has no link-time dependency
+// on it (torch ships its own librccl.so.1; whichever copy is already in the process is reused).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "cgamd_internal.h"
+
+using namespace cgamd;
+
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+std::string g_rccl_err;
+
+void load_rccl() {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.handle) break;
+    }
+    if (!g_rccl.handle) { g_rccl_err = std::string("dlopen(librccl.so.1): ") + dlerror(); return; }
+#define BIND(field, sym)                                                             \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.handle, sym)); \
+    if (!g_rccl.field) { g_rccl_err = std::string("dlsym(") + sym + ") failed"; return; }
+    BIND(GetUniqueId, "ncclGetUniqueId")
+    BIND(CommInitRank, "ncclCommInitRank")
+    BIND(CommDestroy, "ncclCommDestroy")
+    BIND(AllReduce, "ncclAllReduce")
+    BIND(Send, "ncclSend")
+    BIND(Recv, "ncclRecv")
+    BIND(GroupStart, "ncclGroupStart")
+    BIND(GroupEnd, "ncclGroupEnd")
+    BIND(GetErrorString, "ncclGetErrorString")
+#undef BIND
+}
+int need_rccl() {
+    std::call_once(g_rccl_once, load_rccl);
+    if (!g_rccl_err.empty()) return fail(CGAMD_ERR_COMM, g_rccl_err);
+    return CGAMD_OK;
+}
+#define CG_NCCL(expr)                                                                                     \
+    do {                                                                                                  \
+        ncclResult_t r__ = (expr);                                                                        \
+        if (r__ != ncclSuccess)                                                                           \
+            return fail(CGAMD_ERR_COMM, std::string(#expr) + ": " + g_rccl.GetErrorString(r__));          \
+    } while (0)
+}  // namespace
+
+struct cgamd_dist {
+    cgamd_ctx *ctx = nullptr;
+    int dtype = 0, rank = 0, nranks = 1, n_local = 0, n_halo = 0, flags = 0;
+    long long nnz = 0;
+    const void *vals = nullptr;
+    const int *ptr = nullptr, *cols = nullptr;
+    SpmvPlan plan;
+    int vgrid = 1;
+    void *x = nullptr, *r = nullptr, *q = nullptr, *d_ext = nullptr, *b = nullptr;
+    std::vector<int> peer, send_count, recv_count, send_off, recv_off;
+    int total_send = 0;
+    const int *send_index = nullptr;
+    void *sendbuf = nullptr;
+    void *part_dq = nullptr, *part_rr = nullptr;
+    void *red = nullptr;  // 2 accumulator scalars: [0] = d.q, [1] = r.r
+    CgScalars sc;
+    ncclComm_t comm = nullptr;
+    bool rhs_set = false;
+    int iters = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    bool graph_failed = false;
+};
+
+static int dalloc(void **p, size_t bytes, const char *what) {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(CGAMD_ERR_ALLOC, std::string("hipMalloc(") + what + "): " + hipGetErrorString(e));
+    return CGAMD_OK;
+}
+
+static ncclDataType_t elem_type(int dtype) { return (dtype == CGAMD_F32 || dtype == CGAMD_C64) ? ncclFloat : ncclDouble; }
+static size_t elem_mult(int dtype) { return (dtype == CGAMD_C64 || dtype == CGAMD_C128) ? 2 : 1; }
+
+// boundary exchange of `v_ext[0:n_local]` into `v_ext[n_local:]` of the neighbours
+static int exchange(cgamd_dist *d, void *v_ext, hipStream_t st) {
+    if (d->peer.empty()) return CGAMD_OK;
+    const size_t vs = dtype_size(d->dtype), em = elem_mult(d->dtype);
+    if (int rc = launch_pack(d->dtype, d->total_send, d->send_index, v_ext, d->sendbuf, st)) return rc;
+    CG_NCCL(g_rccl.GroupStart());
+    for (size_t p = 0; p < d->peer.size(); ++p) {
+        if (d->send_count[p])
+            CG_NCCL(g_rccl.Send((const char *)d->sendbuf + (size_t)d->send_off[p] * vs, (size_t)d->send_count[p] * em,
+                                elem_type(d->dtype), d->peer[p], d->comm, st));
+        if (d->recv_count[p])
+            CG_NCCL(g_rccl.Recv((char *)v_ext + ((size_t)d->n_local + d->recv_off[p]) * vs, (size_t)d->recv_count[p] * em,
+                                elem_type(d->dtype), d->peer[p], d->comm, st));
+    }
+    CG_NCCL(g_rccl.GroupEnd());
+    return CGAMD_OK;
+}
+
+static int allreduce_scalar(cgamd_dist *d, void *acc, hipStream_t st) {
+    if (!d->comm) return CGAMD_OK;
+    CG_NCCL(g_rccl.AllReduce(acc, acc, acc_size(d->dtype) / 8, ncclDouble, ncclSum, d->comm, st));
+    return CGAMD_OK;
+}
+
+static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
+    const int dt = d->dtype, n = d->n_local;
+    const long long ldx = (long long)d->n_local + d->n_halo;
+    char *red = (char *)d->red;
+    int rc;
+    if ((rc = exchange(d, d->d_ext, st))) return rc;
+    if ((rc = launch_spmv(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, ldx, d->q, n, 1, d->d_ext, d->part_dq, st))) return rc;
+    if ((rc = launch_reduce_to_acc(dt, d->part_dq, d->plan.grid, 1, red, st))) return rc;
+    if ((rc = allreduce_scalar(d, red, st))) return rc;
+    if ((rc = launch_cg_alpha(dt, red, 1, 1, d->sc, st))) return rc;
+    if ((rc = launch_axpy2_dot(dt, n, d->d_ext, d->x, d->q, d->r, n, d->sc.alpha, 1, d->part_rr, d->vgrid, st))) return rc;
+    if ((rc = launch_reduce_to_acc(dt, d->part_rr, d->vgrid, 1, red + 16, st))) return rc;
+    if ((rc = allreduce_scalar(d, red + 16, st))) return rc;
+    if ((rc = launch_cg_beta(dt, red + 16, 1, 1, d->sc, st))) return rc;
+    return launch_aypx(dt, n, d->r, d->d_ext, n, d->sc.beta, 1, st);
+}
+
+static int ensure_history(cgamd_dist *d, int entries) {
+    if (entries <= d->sc.history_cap) return CGAMD_OK;
+    const int cap = std::max(entries, std::max(1024, d->sc.history_cap * 2));
+    const size_t vs = dtype_size(d->dtype);
+    void *nh = nullptr;
+    if (int rc = dalloc(&nh, (size_t)cap * vs, "history")) return rc;
+    if (d->sc.history) {
+        CG_HIP(hipStreamSynchronize(d->ctx->stream));
+        CG_HIP(hipMemcpy(nh, d->sc.history, (size_t)d->sc.history_cap * vs, hipMemcpyDeviceToDevice));
+        CG_HIP(hipFree(d->sc.history));
+    }
+    d->sc.history = nh;
+    d->sc.history_cap = cap;
+    if (d->gexec) { (void)hipGraphExecDestroy(d->gexec); d->gexec = nullptr; }
+    if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
+    return CGAMD_OK;
+}
+
+extern "C" {
+
+int cgamd_comm_unique_id(void *id128) {
+    if (!id128) return fail(CGAMD_ERR_INVALID, "comm_unique_id: null buffer");
+    if (int rc = need_rccl()) return rc;
+    ncclUniqueId id;
+    CG_NCCL(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, 128);
+    return CGAMD_OK;
+}
+
+int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, int dtype, int n_local, int n_halo,
+                      long long nnz_local, const void *aValues, const int *aPointers, const int *aCols, int n_peers,
+                      const int *peer_rank, const int *send_count, const int *recv_count, const int *send_index,
+                      int flags, cgamd_dist **out) {
+    if (!out) return fail(CGAMD_ERR_INVALID, "dist_create: out is NULL");
+    *out = nullptr;
+    if (!ctx) return fail(CGAMD_ERR_INVALID, "dist_create: ctx is NULL");
+    if (dtype < 0 || dtype > 3) return fail(CGAMD_ERR_INVALID, "dist_create: bad dtype");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(CGAMD_ERR_INVALID, "dist_create: bad rank/nranks");
+    if (n_local < 1 || n_halo < 0 || nnz_local < 0 || n_peers < 0) return fail(CGAMD_ERR_INVALID, "dist_create: bad sizes");
+    if ((long long)n_local + n_halo > 2147483647LL || nnz_local > 2147483647LL - 8192)
+        return fail(CGAMD_ERR_INVALID, "dist_create: local problem exceeds int32 indexing");
+    if (!aValues || !aPointers || !aCols) return fail(CGAMD_ERR_INVALID, "dist_create: null matrix pointer");
+    if (n_peers > 0 && (!peer_rank || !send_count || !recv_count)) return fail(CGAMD_ERR_INVALID, "dist_create: null plan arrays");
+    if (nranks > 1 && !id128) return fail(CGAMD_ERR_INVALID, "dist_create: a communicator id is required for nranks > 1");
+    CG_HIP(hipSetDevice(ctx->device));
+
+    cgamd_dist *d = new cgamd_dist();
+    d->ctx = ctx; d->dtype = dtype; d->rank = rank; d->nranks = nranks; d->n_local = n_local; d->n_halo = n_halo;
+    d->nnz = nnz_local; d->vals = aValues; d->ptr = aPointers; d->cols = aCols; d->flags = flags;
+    d->plan = make_spmv_plan(n_local);
+    d->vgrid = vec_grid(n_local, dtype);
+    long long so = 0, ro = 0;
+    for (int p = 0; p < n_peers; ++p) {
+        if (peer_rank[p] < 0 || peer_rank[p] >= nranks || peer_rank[p] == rank || send_count[p] < 0 || recv_count[p] < 0) {
+            delete d;
+            return fail(CGAMD_ERR_INVALID, "dist_create: bad peer entry");
+        }
+        d->peer.push_back(peer_rank[p]);
+        d->send_count.push_back(send_count[p]);
+        d->recv_count.push_back(recv_count[p]);
+        d->send_off.push_back((int)so);
+        d->recv_off.push_back((int)ro);
+        so += send_count[p];
+        ro += recv_count[p];
+    }
+    if (ro != n_halo) { delete d; return fail(CGAMD_ERR_INVALID, "dist_create: sum(recv_count) != n_halo"); }
+    if (so > 0 && !send_index) { delete d; return fail(CGAMD_ERR_INVALID, "dist_create: send_index is NULL"); }
+    d->total_send = (int)so;
+    d->send_index = send_index;
+
+    const size_t vs = dtype_size(dtype);
+    int rc = CGAMD_OK;
+    if (!rc) rc = dalloc(&d->x, (size_t)n_local * vs, "x");
+    if (!rc) rc = dalloc(&d->r, (size_t)n_local * vs, "r");
+    if (!rc) rc = dalloc(&d->q, (size_t)n_local * vs, "q");
+    if (!rc) rc = dalloc(&d->b, (size_t)n_local * vs, "b");
+    if (!rc) rc = dalloc(&d->d_ext, ((size_t)n_local + n_halo) * vs, "d_ext");
+    if (!rc) rc = dalloc(&d->sendbuf, (size_t)so * vs, "sendbuf");
+    if (!rc) rc = dalloc(&d->part_dq, acc_size(dtype) * (size_t)d->plan.grid, "partials_dq");
+    if (!rc) rc = dalloc(&d->part_rr, acc_size(dtype) * (size_t)d->vgrid, "partials_rr");
+    if (!rc) rc = dalloc(&d->red, 64, "red");
+    if (!rc) rc = dalloc(&d->sc.alpha, vs, "alpha");
+    if (!rc) rc = dalloc(&d->sc.beta, vs, "beta");
+    if (!rc) rc = dalloc(&d->sc.delta, vs, "delta");
+    if (!rc) rc = dalloc((void **)&d->sc.iter, 16, "iter");
+    if (!rc) rc = ensure_history(d, 1024);
+    if (!rc && id128) {
+        rc = need_rccl();
+        if (!rc) {
+            ncclUniqueId id;
+            memcpy(&id, id128, 128);
+            ncclResult_t r = g_rccl.CommInitRank(&d->comm, nranks, id, rank);
+            if (r != ncclSuccess) rc = fail(CGAMD_ERR_COMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+        }
+    }
+    if (rc) {
+        std::string keep = cgamd_last_error();
+        cgamd_dist_destroy(d);
+        set_error(keep);
+        return rc;
+    }
+    *out = d;
+    return CGAMD_OK;
+}
+
+int cgamd_dist_destroy(cgamd_dist *d) {
+    if (!d) return CGAMD_OK;
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipStreamSynchronize(d->ctx->stream);
+    if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
+    if (d->graph) (void)hipGraphDestroy(d->graph);
+    if (d->comm) (void)g_rccl.CommDestroy(d->comm);
+    void *bufs[] = {d->x, d->r, d->q, d->b, d->d_ext, d->sendbuf, d->part_dq, d->part_rr, d->red, d->sc.alpha,
+                    d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    delete d;
+    return CGAMD_OK;
+}
+
+int cgamd_dist_set_rhs(cgamd_dist *d, const void *b_local, const void *x0_local) {
+    if (!d || !b_local) return fail(CGAMD_ERR_INVALID, "dist_set_rhs: null argument");
+    CG_HIP(hipSetDevice(d->ctx->device));
+    hipStream_t st = d->ctx->stream;
+    const size_t vs = dtype_size(d->dtype), vb = (size_t)d->n_local * vs;
+    const long long ldx = (long long)d->n_local + d->n_halo;
+    CG_HIP(hipMemcpyAsync(d->b, b_local, vb, hipMemcpyDeviceToDevice, st));
+    if (x0_local) CG_HIP(hipMemcpyAsync(d->x, x0_local, vb, hipMemcpyDeviceToDevice, st));
+    else CG_HIP(hipMemsetAsync(d->x, 0, vb, st));
+    // r = b - A x0 (x0 exchanged through the extended buffer), d = r, delta0 = allreduce(r.r)
+    CG_HIP(hipMemcpyAsync(d->d_ext, d->x, vb, hipMemcpyDeviceToDevice, st));
+    int rc;
+    if ((rc = exchange(d, d->d_ext, st))) return rc;
+    if ((rc = launch_spmv(d->dtype, d->plan, d->n_local, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, ldx, d->q, d->n_local, 1,
+                          nullptr, nullptr, st))) return rc;
+    if ((rc = launch_sub(d->dtype, d->n_local, d->b, d->q, d->r, d->n_local, 1, st))) return rc;
+    CG_HIP(hipMemcpyAsync(d->d_ext, d->r, vb, hipMemcpyDeviceToDevice, st));
+    if ((rc = launch_dot_partials(d->dtype, d->n_local, d->r, d->r, d->n_local, 1, d->part_rr, d->vgrid, st))) return rc;
+    if ((rc = launch_reduce_to_acc(d->dtype, d->part_rr, d->vgrid, 1, (char *)d->red + 16, st))) return rc;
+    if ((rc = allreduce_scalar(d, (char *)d->red + 16, st))) return rc;
+    if ((rc = launch_cg_delta0(d->dtype, (char *)d->red + 16, 1, 1, d->sc, st))) return rc;
+    d->rhs_set = true;
+    d->iters = 0;
+    return CGAMD_OK;
+}
+
+int cgamd_dist_iterate(cgamd_dist *d, int nIterations) {
+    if (!d) return fail(CGAMD_ERR_INVALID, "dist_iterate: null handle");
+    if (!d->rhs_set) return fail(CGAMD_ERR_STATE, "dist_iterate: call dist_set_rhs first");
+    if (nIterations < 0) return fail(CGAMD_ERR_INVALID, "dist_iterate: negative iteration count");
+    CG_HIP(hipSetDevice(d->ctx->device));
+    if (int rc = ensure_history(d, d->iters + nIterations + 1)) return rc;
+    hipStream_t st = d->ctx->stream;
+    int left = nIterations;
+    // Optional hipGraph replay of one iteration including the RCCL operations (RCCL >= 2.9 captures).
+    if ((d->flags & CGAMD_DIST_GRAPH) && !d->graph_failed && !d->gexec) {
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+        int rc = e == hipSuccess ? enqueue_iteration(d, st) : CGAMD_ERR_HIP;
+        hipError_t e2 = hipStreamEndCapture(st, &d->graph);
+        if (e != hipSuccess || rc != CGAMD_OK || e2 != hipSuccess ||
+            hipGraphInstantiate(&d->gexec, d->graph, nullptr, nullptr, 0) != hipSuccess) {
+            d->graph_failed = true;
+            d->gexec = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    for (; left > 0; --left) {
+        if (d->gexec) CG_HIP(hipGraphLaunch(d->gexec, st));
+        else if (int rc = enqueue_iteration(d, st)) return rc;
+    }
+    d->iters += nIterations;
+    return CGAMD_OK;
+}
+
+int cgamd_dist_get_x(cgamd_dist *d, void *x_local) {
+    if (!d || !x_local) return fail(CGAMD_ERR_INVALID, "dist_get_x: null argument");
+    CG_HIP(hipSetDevice(d->ctx->device));
+    CG_HIP(hipMemcpyAsync(x_local, d->x, (size_t)d->n_local * dtype_size(d->dtype), hipMemcpyDeviceToDevice, d->ctx->stream));
+    return CGAMD_OK;
+}
+
+int cgamd_dist_history(cgamd_dist *d, void *history, int max_entries) {
+    if (!d || !history) { fail(CGAMD_ERR_INVALID, "dist_history: null argument"); return -CGAMD_ERR_INVALID; }
+    if (!d->rhs_set) { fail(CGAMD_ERR_STATE, "dist_history: no right-hand side set"); return -CGAMD_ERR_STATE; }
+    if (hipSetDevice(d->ctx->device) != hipSuccess) return -CGAMD_ERR_NO_DEVICE;
+    const int entries = std::min(std::min(d->iters + 1, d->sc.history_cap), max_entries);
+    hipError_t e = hipMemcpyAsync(history, d->sc.history, (size_t)entries * dtype_size(d->dtype), hipMemcpyDeviceToHost, d->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->ctx->stream);
+    if (e != hipSuccess) { fail(CGAMD_ERR_HIP, std::string("dist_history: ") + hipGetErrorString(e)); return -CGAMD_ERR_HIP; }
+    return entries;
+}
+
+int cgamd_dist_synchronize(cgamd_dist *d) {
+    if (!d) return fail(CGAMD_ERR_INVALID, "dist_synchronize: null handle");
+    CG_HIP(hipSetDevice(d->ctx->device));
+    CG_HIP(hipStreamSynchronize(d->ctx->stream));
+    return CGAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,636 @@
+// Hand-written gfx950 kernels of the CG hot path.
+//
+//   spmv_stream_kernel   CSR SpMV/SpMM (replaces reference kernel/{real,complex}/spmv.cl), optionally fused
+//                        with the d.q partial reduction (reference vdot.cl + host sum clcg.c:317-324)
+//   dot_partials_kernel  reference kernel/{real,complex}/vdot.cl (partials stay on the device)
+//   axpy / aypx / sub    reference kernel/{real,complex}/{axpy,aypx,sub}.cl
+//   axpy2_dot_kernel     x += alpha d ; r -= alpha q ; partial r.r in one pass (reference clcg.c:338-374)
+//   cg_alpha/beta/delta0 the scalar work the reference does on the host (clcg.c:274-292,317-334,376-411)
+//
+// Design (MI355X): every kernel is HBM-bound.  Work-groups are 256 threads (4 wave64); streaming
+// kernels launch <= 2048 persistent work-groups (256 CUs x 8) that own contiguous ranges, mapped so
+// that each XCD owns one contiguous range (xcd_remap).  Loads are 16 B per lane; matrix streams are
+// non-temporal so they do not evict the gathered vector from L2.  Reductions are wave64 shuffles,
+// then LDS across the 4 waves, then a fixed-order pass over the per-work-group partials: bitwise
+// reproducible run to run, no atomics.
+#include "cgamd_internal.h"
+#include "device_types.h"
+
+namespace cgamd {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// ---- 16-byte packs -----------------------------------------------------------------------------
+template <typename T> struct Pack {
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+} __attribute__((aligned(16)));
+
+template <typename T> CG_DEV Pack<T> ld_pack(const T *p) { return *reinterpret_cast<const Pack<T> *>(p); }
+template <typename T> CG_DEV void st_pack(T *p, const Pack<T> &v) { *reinterpret_cast<Pack<T> *>(p) = v; }
+
+template <typename T> CG_DEV void ld4_nt(const T *p, T (&out)[4]) {
+    // 4 consecutive values = sizeof(T)/4 sixteen-byte non-temporal loads
+    constexpr int NV = sizeof(T) * 4 / 16;
+    union { u32x4 raw[NV]; T v[4]; } u;
+    const u32x4 *q = reinterpret_cast<const u32x4 *>(p);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) u.raw[i] = __builtin_nontemporal_load(q + i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = u.v[i];
+}
+
+// =================================================================================================
+// SpMV / SpMM, CSR-stream: a work-group owns BLOCK consecutive rows at a time.  Their non-zeros are one
+// contiguous slice of aValues/aCols, streamed with 16 B coalesced non-temporal loads (4 nnz per lane
+// per load group, slice start rounded down to a multiple of 4 so every load is aligned); each lane
+// multiplies its non-zeros with the gathered x entries and parks the products in LDS; after one
+// barrier, lane t sums the products of row t (left to right, CSR order) and writes y[t] coalesced.
+// For nRHS > 1 the matrix quads stay in registers while the gather/LDS/sum phase repeats per RHS,
+// so the matrix is read from HBM once per SpMM.
+// =================================================================================================
+template <typename T> struct SpmvArgs {
+    int n;
+    int nrhs;
+    long long nnz;
+    const T *vals;
+    const int *ptr;
+    const int *cols;
+    const T *x;
+    long long ldx;
+    T *y;
+    long long ldy;
+    const T *dvec;                  // fused dot: sum dvec[row] * y[row]
+    typename VT<T>::acc *partials;  // [nrhs][grid]
+    int row_blocks;
+};
+
+template <typename T, int BLOCK, int QPT, bool VEC, bool FUSE_DOT>
+__global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs<T> a) {
+    using A = typename VT<T>::acc;
+    constexpr int CHUNK = 4 * QPT * BLOCK;
+    __shared__ T prod[CHUNK];
+    __shared__ A red[BLOCK / kWave];
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];  // FUSE_DOT && nrhs > 1: A[nrhs][BLOCK/64]
+    A *wavedot = reinterpret_cast<A *>(dyn_smem);
+
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    const int L = xcd_remap(blockIdx.x, G);
+    const int rb_begin = (int)((long long)L * a.row_blocks / G);
+    const int rb_end = (int)((long long)(L + 1) * a.row_blocks / G);
+
+    A dot1 = vzero<A>();
+    if (FUSE_DOT && a.nrhs > 1) {
+        for (int i = t; i < a.nrhs * (BLOCK / kWave); i += BLOCK) wavedot[i] = vzero<A>();
+        __syncthreads();
+    }
+
+    for (int rb = rb_begin; rb < rb_end; ++rb) {
+        const int r0 = rb * BLOCK;
+        const int r1 = min(r0 + BLOCK, a.n);
+        const int row = r0 + t;
+        const int p0 = a.ptr[r0];   // wave-uniform
+        const int p1 = a.ptr[r1];
+        int s = 0, e = 0;
+        if (row < a.n) { s = a.ptr[row]; e = a.ptr[row + 1]; }
+        const int cfirst = p0 & ~3;
+
+        for (int c0 = cfirst; c0 < p1 || c0 == cfirst; c0 += CHUNK) {
+            // ---- stream this chunk's matrix entries into registers
+            T v[QPT][4];
+            int c[QPT][4];
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                const long long q = (long long)c0 + 4 * (t + u * BLOCK);
+                if (q < p1) {
+                    if (VEC && q + 4 <= a.nnz) {
+                        ld4_nt<T>(a.vals + q, v[u]);
+                        const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(a.cols + q));
+                        c[u][0] = cc.x; c[u][1] = cc.y; c[u][2] = cc.z; c[u][3] = cc.w;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool ok = q + k < a.nnz;
+                            v[u][k] = ok ? a.vals[q + k] : vzero<T>();
+                            c[u][k] = ok ? a.cols[q + k] : 0;
+                        }
+                    }
+                }
+            }
+            const int lo = max(s, c0) - c0, hi = min(e, c0 + CHUNK) - c0;
+            for (int r = 0; r < a.nrhs; ++r) {
+                const T *xr = a.x + (long long)r * a.ldx;
+#pragma unroll
+                for (int u = 0; u < QPT; ++u) {
+                    const long long q = (long long)c0 + 4 * (t + u * BLOCK);
+                    if (q < p1) {
+                        T pr[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pr[k] = vmul(v[u][k], xr[c[u][k]]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) prod[4 * (t + u * BLOCK) + k] = pr[k];
+                    }
+                }
+                __syncthreads();
+                T sum = vzero<T>();
+                for (int k = lo; k < hi; ++k) sum = vadd(sum, prod[k]);
+                if (row < a.n) {
+                    T *yr = a.y + (long long)r * a.ldy;
+                    if (c0 == cfirst) yr[row] = sum;
+                    else if (hi > lo) yr[row] = vadd(yr[row], sum);
+                }
+                if (FUSE_DOT) {
+                    const A contrib = (row < a.n) ? to_acc(vmul(a.dvec[(long long)r * a.ldx + row], sum)) : vzero<A>();
+                    if (a.nrhs == 1) dot1 = vadd(dot1, contrib);
+                    else {
+                        // per-wave running sums in LDS; only this wave touches its slot
+                        const A w = wave_sum(contrib);
+                        if ((t & (kWave - 1)) == 0) {
+                            A *slot = &wavedot[r * (BLOCK / kWave) + t / kWave];
+                            *slot = vadd(*slot, w);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (FUSE_DOT) {
+        if (a.nrhs == 1) {
+            const A tot = block_sum<BLOCK>(dot1, red);
+            if (t == 0) a.partials[L] = tot;
+        } else {
+            __syncthreads();
+            for (int r = t; r < a.nrhs; r += BLOCK) {
+                A tot = wavedot[r * (BLOCK / kWave)];
+                for (int w = 1; w < BLOCK / kWave; ++w) tot = vadd(tot, wavedot[r * (BLOCK / kWave) + w]);
+                a.partials[(long long)r * G + L] = tot;
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// Streaming vector kernels.  grid = (G, nRHS); RHS r lives at base + r*ld.
+// =================================================================================================
+// x += alpha d ; r -= alpha q ; partial(r.r)
+template <typename T, int BLOCK, bool VEC>
+__global__ __launch_bounds__(BLOCK) void axpy2_dot_kernel(int n, const T *__restrict__ d, T *__restrict__ x,
+                                                          const T *__restrict__ q, T *__restrict__ rv, long long ld,
+                                                          const T *__restrict__ alpha,
+                                                          typename VT<T>::acc *__restrict__ partials) {
+    using A = typename VT<T>::acc;
+    __shared__ A red[BLOCK / kWave];
+    const int r = blockIdx.y;
+    const long long off = (long long)r * ld;
+    d += off; x += off; q += off; rv += off;
+    const T al = alpha[r];
+    A acc = vzero<A>();
+    constexpr int E = Pack<T>::N;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (VEC) {
+        const long long npack = n / E;
+        for (long long i = i0; i < npack; i += stride) {
+            const Pack<T> pd = ld_pack(d + i * E), pq = ld_pack(q + i * E);
+            Pack<T> px = ld_pack(x + i * E), pr = ld_pack(rv + i * E);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                px.v[k] = vadd(px.v[k], vmul(al, pd.v[k]));
+                pr.v[k] = vsub(pr.v[k], vmul(al, pq.v[k]));
+                acc = vadd(acc, to_acc(vmul(pr.v[k], pr.v[k])));
+            }
+            st_pack(x + i * E, px);
+            st_pack(rv + i * E, pr);
+        }
+        i0 += npack * E;  // scalar tail
+    }
+    for (long long i = i0; i < n; i += stride) {
+        x[i] = vadd(x[i], vmul(al, d[i]));
+        const T rn = vsub(rv[i], vmul(al, q[i]));
+        rv[i] = rn;
+        acc = vadd(acc, to_acc(vmul(rn, rn)));
+    }
+    const A tot = block_sum<BLOCK>(acc, red);
+    if (threadIdx.x == 0) partials[(long long)r * gridDim.x + blockIdx.x] = tot;
+}
+
+template <typename T, int BLOCK, bool VEC>
+__global__ __launch_bounds__(BLOCK) void dot_partials_kernel(int n, const T *__restrict__ a, const T *__restrict__ b,
+                                                             long long ld, typename VT<T>::acc *__restrict__ partials) {
+    using A = typename VT<T>::acc;
+    __shared__ A red[BLOCK / kWave];
+    const int r = blockIdx.y;
+    a += (long long)r * ld; b += (long long)r * ld;
+    A acc = vzero<A>();
+    constexpr int E = Pack<T>::N;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (VEC) {
+        const long long npack = n / E;
+        for (long long i = i0; i < npack; i += stride) {
+            const Pack<T> pa = ld_pack(a + i * E), pb = ld_pack(b + i * E);
+#pragma unroll
+            for (int k = 0; k < E; ++k) acc = vadd(acc, to_acc(vmul(pa.v[k], pb.v[k])));
+        }
+        i0 += npack * E;
+    }
+    for (long long i = i0; i < n; i += stride) acc = vadd(acc, to_acc(vmul(a[i], b[i])));
+    const A tot = block_sum<BLOCK>(acc, red);
+    if (threadIdx.x == 0) partials[(long long)r * gridDim.x + blockIdx.x] = tot;
+}
+
+// OP 0: y += a x   1: y -= a x   2: y = a y + x   3: res(y) = x - b
+template <typename T, int BLOCK, bool VEC, int OP>
+__global__ __launch_bounds__(BLOCK) void ewise_kernel(int n, const T *__restrict__ x, T *__restrict__ y,
+                                                      const T *__restrict__ b2, long long ld,
+                                                      const T *__restrict__ alpha) {
+    const int r = blockIdx.y;
+    x += (long long)r * ld; y += (long long)r * ld;
+    if (OP == 3) b2 += (long long)r * ld;
+    const T al = (OP == 3) ? vzero<T>() : alpha[r];
+    constexpr int E = Pack<T>::N;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    auto f = [&](T xv, T yv, T bv) -> T {
+        if (OP == 0) return vadd(yv, vmul(al, xv));
+        if (OP == 1) return vsub(yv, vmul(al, xv));
+        if (OP == 2) return vadd(vmul(al, yv), xv);
+        return vsub(xv, bv);
+    };
+    if (VEC) {
+        const long long npack = n / E;
+        for (long long i = i0; i < npack; i += stride) {
+            const Pack<T> px = ld_pack(x + i * E);
+            Pack<T> py, pb;
+            if (OP != 3) py = ld_pack(y + i * E);
+            if (OP == 3) pb = ld_pack(b2 + i * E);
+#pragma unroll
+            for (int k = 0; k < E; ++k) py.v[k] = f(px.v[k], OP != 3 ? py.v[k] : vzero<T>(), OP == 3 ? pb.v[k] : vzero<T>());
+            st_pack(y + i * E, py);
+        }
+        i0 += npack * E;
+    }
+    for (long long i = i0; i < n; i += stride)
+        y[i] = f(x[i], OP != 3 ? y[i] : vzero<T>(), OP == 3 ? b2[i] : vzero<T>());
+}
+
+// =================================================================================================
+// Scalar kernels: one work-group; wave w owns RHS r = w, w+4, ...; fixed summation order.
+// =================================================================================================
+template <typename A> CG_DEV A sum_partials_wave(const A *p, int grid) {
+    A acc = vzero<A>();
+    for (int i = threadIdx.x & (kWave - 1); i < grid; i += kWave) acc = vadd(acc, p[i]);
+    return wave_sum(acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_to_value_kernel(const typename VT<T>::acc *partials, int grid, int nrhs,
+                                                              T *result) {
+    for (int r = threadIdx.x / kWave; r < nrhs; r += 256 / kWave) {
+        const auto s = sum_partials_wave(partials + (long long)r * grid, grid);
+        if ((threadIdx.x & (kWave - 1)) == 0) result[r] = from_acc<T>(s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cg_delta0_kernel(const typename VT<T>::acc *partials, int grid, int nrhs, T *delta,
+                                                        T *history, int *iter) {
+    for (int r = threadIdx.x / kWave; r < nrhs; r += 256 / kWave) {
+        const auto s = sum_partials_wave(partials + (long long)r * grid, grid);
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            delta[r] = from_acc<T>(s);
+            history[r] = from_acc<T>(s);
+        }
+    }
+    if (threadIdx.x == 0) *iter = 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cg_alpha_kernel(const typename VT<T>::acc *partials, int grid, int nrhs,
+                                                       const T *delta, T *alpha) {
+    for (int r = threadIdx.x / kWave; r < nrhs; r += 256 / kWave) {
+        const auto dq = sum_partials_wave(partials + (long long)r * grid, grid);
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            // the reference rounds dq to the value type before dividing (clcg.c:318-327)
+            const T dqT = from_acc<T>(dq);
+            alpha[r] = from_acc<T>(acc_div(to_acc(delta[r]), to_acc(dqT)));
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cg_beta_kernel(const typename VT<T>::acc *partials, int grid, int nrhs, T *delta,
+                                                      T *beta, T *history, int history_cap, int *iter) {
+    const int it = *iter + 1;
+    for (int r = threadIdx.x / kWave; r < nrhs; r += 256 / kWave) {
+        const auto dn = sum_partials_wave(partials + (long long)r * grid, grid);
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            const T dnT = from_acc<T>(dn);
+            beta[r] = from_acc<T>(acc_div(to_acc(dnT), to_acc(delta[r])));   // clcg.c:389-391
+            delta[r] = dnT;
+            if (it < history_cap) history[(long long)it * nrhs + r] = dnT;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *iter = it;
+}
+
+// partials -> one accumulator value per RHS (input of the RCCL all-reduce in the multi-GPU loop)
+template <typename A>
+__global__ __launch_bounds__(256) void reduce_to_acc_kernel(const A *partials, int grid, int nrhs, A *out) {
+    for (int r = threadIdx.x / kWave; r < nrhs; r += 256 / kWave) {
+        const A s = sum_partials_wave(partials + (long long)r * grid, grid);
+        if ((threadIdx.x & (kWave - 1)) == 0) out[r] = s;
+    }
+}
+
+// halo pack: out[k] = v[index[k]]  (boundary entries of d that neighbouring ranks gather in their SpMV)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(int count, const int *__restrict__ index, const T *__restrict__ v,
+                                                   T *__restrict__ out) {
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < count; k += gridDim.x * 256) out[k] = v[index[k]];
+}
+
+// =================================================================================================
+// Synthetic generators (device side, so multi-GB systems never cross PCIe)
+// =================================================================================================
+__host__ __device__ inline long long lap3d_ptr(long long i, long long nx, long long ny, long long nz) {
+    // entries stored before row i = 7 i - (missing neighbours of rows < i), closed form
+    const long long pl = nx * ny, n = pl * nz;
+    const long long x0 = (i + nx - 1) / nx;                       // rows j<i with ix == 0
+    const long long x1 = i / nx;                                  // ix == nx-1
+    const long long full = i / pl, rem = i % pl;
+    const long long y0 = full * nx + (rem < nx ? rem : nx);       // iy == 0
+    const long long y1 = full * nx + (rem > pl - nx ? rem - (pl - nx) : 0);  // iy == ny-1
+    const long long z0 = i < pl ? i : pl;                         // iz == 0
+    const long long z1 = i > n - pl ? i - (n - pl) : 0;           // iz == nz-1
+    return 7 * i - (x0 + x1 + y0 + y1 + z0 + z1);
+}
+long long laplace3d_ptr(long long i, int nx, int ny, int nz) { return lap3d_ptr(i, nx, ny, nz); }
+
+template <typename T> CG_DEV T real_val(double v);
+template <> CG_DEV float real_val<float>(double v) { return (float)v; }
+template <> CG_DEV double real_val<double>(double v) { return v; }
+template <> CG_DEV float2 real_val<float2>(double v) { return make_float2((float)v, 0.f); }
+template <> CG_DEV double2 real_val<double2>(double v) { return make_double2(v, 0.); }
+
+template <typename T>
+__global__ void gen_laplace3d_kernel(int nx, int ny, int nz, long long row_begin, long long row_end, T *vals, int *ptr,
+                                     int *cols) {
+    const long long nloc = row_end - row_begin;
+    const long long base = lap3d_ptr(row_begin, nx, ny, nz);
+    for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li <= nloc;
+         li += (long long)gridDim.x * blockDim.x) {
+        const long long i = row_begin + li;
+        long long p = lap3d_ptr(i, nx, ny, nz) - base;
+        ptr[li] = (int)p;
+        if (li == nloc) break;
+        const long long pl = (long long)nx * ny;
+        const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / pl);
+        if (iz > 0) { cols[p] = (int)(i - pl); vals[p++] = real_val<T>(-1.0); }
+        if (iy > 0) { cols[p] = (int)(i - nx); vals[p++] = real_val<T>(-1.0); }
+        if (ix > 0) { cols[p] = (int)(i - 1); vals[p++] = real_val<T>(-1.0); }
+        cols[p] = (int)i; vals[p++] = real_val<T>(6.0);
+        if (ix < nx - 1) { cols[p] = (int)(i + 1); vals[p++] = real_val<T>(-1.0); }
+        if (iy < ny - 1) { cols[p] = (int)(i + nx); vals[p++] = real_val<T>(-1.0); }
+        if (iz < nz - 1) { cols[p] = (int)(i + pl); vals[p++] = real_val<T>(-1.0); }
+    }
+}
+
+__host__ __device__ inline long long poi2d_ptr(long long i, long long N) {
+    const long long n = N * N;
+    const long long x0 = (i + N - 1) / N, x1 = i / N;
+    const long long y0 = i < N ? i : N, y1 = i > n - N ? i - (n - N) : 0;
+    return 5 * i - (x0 + x1 + y0 + y1);
+}
+long long poisson2d_ptr(long long i, int N) { return poi2d_ptr(i, N); }
+
+template <typename T> __global__ void gen_poisson2d_kernel(int N, T *vals, int *ptr, int *cols) {
+    const long long n = (long long)N * N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (long long)gridDim.x * blockDim.x) {
+        long long p = poi2d_ptr(i, N);
+        ptr[i] = (int)p;
+        if (i == n) break;
+        const int jx = (int)(i % N), iy = (int)(i / N);
+        if (iy > 0) { cols[p] = (int)(i - N); vals[p++] = real_val<T>(-1.0); }
+        if (jx > 0) { cols[p] = (int)(i - 1); vals[p++] = real_val<T>(-1.0); }
+        cols[p] = (int)i; vals[p++] = real_val<T>(4.0);
+        if (jx < N - 1) { cols[p] = (int)(i + 1); vals[p++] = real_val<T>(-1.0); }
+        if (iy < N - 1) { cols[p] = (int)(i + N); vals[p++] = real_val<T>(-1.0); }
+    }
+}
+
+// =================================================================================================
+// Host-side launchers
+// =================================================================================================
+#define CG_DISPATCH(dtype, FN, ...)                                         \
+    switch (dtype) {                                                        \
+    case CGAMD_F32: return FN<float>(__VA_ARGS__);                          \
+    case CGAMD_F64: return FN<double>(__VA_ARGS__);                         \
+    case CGAMD_C64: return FN<float2>(__VA_ARGS__);                         \
+    case CGAMD_C128: return FN<double2>(__VA_ARGS__);                       \
+    default: return fail(CGAMD_ERR_INVALID, "bad dtype");                   \
+    }
+
+static int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return CGAMD_OK;
+}
+
+SpmvPlan make_spmv_plan(int n) {
+    SpmvPlan p;
+    p.row_blocks = (n + kBlock - 1) / kBlock;
+    int g = p.row_blocks < kMaxGrid ? p.row_blocks : kMaxGrid;
+    if (g >= 8) g &= ~7;  // xcd_remap needs a multiple of 8
+    if (g < 1) g = 1;
+    p.grid = g;
+    return p;
+}
+
+int vec_grid(long long n, int dtype) {
+    const long long per_block = (long long)kBlock * (16 / (long long)dtype_size(dtype)) * 4;  // 4 packs per thread
+    long long g = (n + per_block - 1) / per_block;
+    if (g > kMaxGrid) g = kMaxGrid;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <typename T>
+static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
+                     const void *x, long long ldx, void *y, long long ldy, int nrhs, const void *dvec, void *partials,
+                     hipStream_t st) {
+    SpmvArgs<T> a;
+    a.n = n; a.nrhs = nrhs; a.nnz = nnz;
+    a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
+    a.x = static_cast<const T *>(x); a.ldx = ldx;
+    a.y = static_cast<T *>(y); a.ldy = ldy;
+    a.dvec = static_cast<const T *>(dvec);
+    a.partials = static_cast<typename VT<T>::acc *>(partials);
+    a.row_blocks = plan.row_blocks;
+    const bool vec = aligned16(vals) && aligned16(cols);
+    const bool fuse = partials != nullptr;
+    const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
+    dim3 grid(plan.grid), block(kBlock);
+    if (vec) {
+        if (fuse) hipLaunchKernelGGL((spmv_stream_kernel<T, kBlock, kQuadsPerThread, true, true>), grid, block, dyn, st, a);
+        else hipLaunchKernelGGL((spmv_stream_kernel<T, kBlock, kQuadsPerThread, true, false>), grid, block, dyn, st, a);
+    } else {
+        if (fuse) hipLaunchKernelGGL((spmv_stream_kernel<T, kBlock, kQuadsPerThread, false, true>), grid, block, dyn, st, a);
+        else hipLaunchKernelGGL((spmv_stream_kernel<T, kBlock, kQuadsPerThread, false, false>), grid, block, dyn, st, a);
+    }
+    return check_launch("spmv");
+}
+
+int launch_spmv(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr,
+                const int *cols, const void *x, long long ldx, void *y, long long ldy, int nrhs, const void *dvec,
+                void *partials, hipStream_t st) {
+    if (n <= 0) return CGAMD_OK;
+    CG_DISPATCH(dtype, spmv_impl, plan, n, nnz, vals, ptr, cols, x, ldx, y, ldy, nrhs, dvec, partials, st);
+}
+
+static bool vec_ok(int dtype, long long ld, int nrhs, std::initializer_list<const void *> ptrs) {
+    for (const void *p : ptrs)
+        if (p && !aligned16(p)) return false;
+    if (nrhs > 1 && ((ld * (long long)dtype_size(dtype)) & 15)) return false;
+    return true;
+}
+
+template <typename T>
+static int dot_impl(int n, const void *a, const void *b, long long ld, int nrhs, void *partials, int grid, bool vec,
+                    hipStream_t st) {
+    dim3 g(grid, nrhs), blk(kBlock);
+    auto *pp = static_cast<typename VT<T>::acc *>(partials);
+    if (vec) hipLaunchKernelGGL((dot_partials_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)a, (const T *)b, ld, pp);
+    else hipLaunchKernelGGL((dot_partials_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)a, (const T *)b, ld, pp);
+    return check_launch("vdot");
+}
+int launch_dot_partials(int dtype, int n, const void *a, const void *b, long long ld, int nrhs, void *partials, int grid,
+                        hipStream_t st) {
+    const bool vec = vec_ok(dtype, ld, nrhs, {a, b});
+    CG_DISPATCH(dtype, dot_impl, n, a, b, ld, nrhs, partials, grid, vec, st);
+}
+
+template <typename T> static int reduce_impl(const void *partials, int grid, int nrhs, void *result, hipStream_t st) {
+    hipLaunchKernelGGL((reduce_to_value_kernel<T>), dim3(1), dim3(256), 0, st,
+                       static_cast<const typename VT<T>::acc *>(partials), grid, nrhs, static_cast<T *>(result));
+    return check_launch("reduce");
+}
+int launch_reduce_to_value(int dtype, const void *partials, int grid, int nrhs, void *result, hipStream_t st) {
+    CG_DISPATCH(dtype, reduce_impl, partials, grid, nrhs, result, st);
+}
+
+template <typename T, int OP>
+static int ewise_impl(int n, const void *x, void *y, const void *b2, long long ld, const void *alpha, int nrhs, bool vec,
+                      hipStream_t st) {
+    dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
+    if (vec) hipLaunchKernelGGL((ewise_kernel<T, kBlock, true, OP>), g, blk, 0, st, n, (const T *)x, (T *)y, (const T *)b2, ld, (const T *)alpha);
+    else hipLaunchKernelGGL((ewise_kernel<T, kBlock, false, OP>), g, blk, 0, st, n, (const T *)x, (T *)y, (const T *)b2, ld, (const T *)alpha);
+    return check_launch("ewise");
+}
+template <typename T> static int axpy_p(int n, const void *x, void *y, long long ld, const void *a, int nrhs, bool v, hipStream_t st) { return ewise_impl<T, 0>(n, x, y, nullptr, ld, a, nrhs, v, st); }
+template <typename T> static int axpy_m(int n, const void *x, void *y, long long ld, const void *a, int nrhs, bool v, hipStream_t st) { return ewise_impl<T, 1>(n, x, y, nullptr, ld, a, nrhs, v, st); }
+template <typename T> static int aypx_i(int n, const void *x, void *y, long long ld, const void *a, int nrhs, bool v, hipStream_t st) { return ewise_impl<T, 2>(n, x, y, nullptr, ld, a, nrhs, v, st); }
+template <typename T> static int sub_i(int n, const void *a, const void *b, void *res, long long ld, int nrhs, bool v, hipStream_t st) { return ewise_impl<T, 3>(n, a, res, b, ld, nullptr, nrhs, v, st); }
+
+int launch_axpy(int dtype, int n, const void *x, void *y, long long ld, const void *a, int sign, int nrhs, hipStream_t st) {
+    if (n <= 0) return CGAMD_OK;
+    const bool v = vec_ok(dtype, ld, nrhs, {x, y});
+    if (sign) { CG_DISPATCH(dtype, axpy_p, n, x, y, ld, a, nrhs, v, st); }
+    CG_DISPATCH(dtype, axpy_m, n, x, y, ld, a, nrhs, v, st);
+}
+int launch_aypx(int dtype, int n, const void *x, void *y, long long ld, const void *a, int nrhs, hipStream_t st) {
+    if (n <= 0) return CGAMD_OK;
+    const bool v = vec_ok(dtype, ld, nrhs, {x, y});
+    CG_DISPATCH(dtype, aypx_i, n, x, y, ld, a, nrhs, v, st);
+}
+int launch_sub(int dtype, int n, const void *a, const void *b, void *res, long long ld, int nrhs, hipStream_t st) {
+    if (n <= 0) return CGAMD_OK;
+    const bool v = vec_ok(dtype, ld, nrhs, {a, b, res});
+    CG_DISPATCH(dtype, sub_i, n, a, b, res, ld, nrhs, v, st);
+}
+
+template <typename T>
+static int axpy2_impl(int n, const void *d, void *x, const void *q, void *r, long long ld, const void *alpha, int nrhs,
+                      void *partials, int grid, bool vec, hipStream_t st) {
+    dim3 g(grid, nrhs), blk(kBlock);
+    auto *pp = static_cast<typename VT<T>::acc *>(partials);
+    if (vec) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    else hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    return check_launch("axpy2_dot");
+}
+int launch_axpy2_dot(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *alpha,
+                     int nrhs, void *partials, int grid, hipStream_t st) {
+    const bool vec = vec_ok(dtype, ld, nrhs, {d, x, q, r});
+    CG_DISPATCH(dtype, axpy2_impl, n, d, x, q, r, ld, alpha, nrhs, partials, grid, vec, st);
+}
+
+template <typename T> static int delta0_impl(const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
+    hipLaunchKernelGGL((cg_delta0_kernel<T>), dim3(1), dim3(256), 0, st, static_cast<const typename VT<T>::acc *>(partials),
+                       grid, nrhs, (T *)s.delta, (T *)s.history, s.iter);
+    return check_launch("cg_delta0");
+}
+int launch_cg_delta0(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
+    CG_DISPATCH(dtype, delta0_impl, partials, grid, nrhs, s, st);
+}
+template <typename T> static int alpha_impl(const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
+    hipLaunchKernelGGL((cg_alpha_kernel<T>), dim3(1), dim3(256), 0, st, static_cast<const typename VT<T>::acc *>(partials),
+                       grid, nrhs, (const T *)s.delta, (T *)s.alpha);
+    return check_launch("cg_alpha");
+}
+int launch_cg_alpha(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
+    CG_DISPATCH(dtype, alpha_impl, partials, grid, nrhs, s, st);
+}
+template <typename T> static int beta_impl(const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
+    hipLaunchKernelGGL((cg_beta_kernel<T>), dim3(1), dim3(256), 0, st, static_cast<const typename VT<T>::acc *>(partials),
+                       grid, nrhs, (T *)s.delta, (T *)s.beta, (T *)s.history, s.history_cap, s.iter);
+    return check_launch("cg_beta");
+}
+int launch_cg_beta(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
+    CG_DISPATCH(dtype, beta_impl, partials, grid, nrhs, s, st);
+}
+
+template <typename T>
+static int gen3d_impl(int nx, int ny, int nz, long long rb, long long re, void *vals, int *ptr, int *cols, hipStream_t st) {
+    const long long nloc = re - rb + 1;
+    int g = (int)((nloc + 255) / 256 < 8192 ? (nloc + 255) / 256 : 8192);
+    hipLaunchKernelGGL((gen_laplace3d_kernel<T>), dim3(g), dim3(256), 0, st, nx, ny, nz, rb, re, (T *)vals, ptr, cols);
+    return check_launch("gen_laplace3d");
+}
+int launch_gen_laplace3d(int dtype, int nx, int ny, int nz, long long row_begin, long long row_end, void *vals, int *ptr,
+                         int *cols, hipStream_t st) {
+    CG_DISPATCH(dtype, gen3d_impl, nx, ny, nz, row_begin, row_end, vals, ptr, cols, st);
+}
+template <typename T> static int gen2d_impl(int N, void *vals, int *ptr, int *cols, hipStream_t st) {
+    const long long n = (long long)N * N + 1;
+    int g = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL((gen_poisson2d_kernel<T>), dim3(g), dim3(256), 0, st, N, (T *)vals, ptr, cols);
+    return check_launch("gen_poisson2d");
+}
+int launch_gen_poisson2d(int dtype, int N, void *vals, int *ptr, int *cols, hipStream_t st) {
+    CG_DISPATCH(dtype, gen2d_impl, N, vals, ptr, cols, st);
+}
+
+int launch_reduce_to_acc(int dtype, const void *partials, int grid, int nrhs, void *out, hipStream_t st) {
+    if (dtype == CGAMD_F32 || dtype == CGAMD_F64)
+        hipLaunchKernelGGL((reduce_to_acc_kernel<double>), dim3(1), dim3(256), 0, st, (const double *)partials, grid, nrhs, (double *)out);
+    else
+        hipLaunchKernelGGL((reduce_to_acc_kernel<double2>), dim3(1), dim3(256), 0, st, (const double2 *)partials, grid, nrhs, (double2 *)out);
+    return check_launch("reduce_to_acc");
+}
+
+template <typename T> static int pack_impl(int count, const int *index, const void *v, void *out, hipStream_t st) {
+    int g = (count + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL((pack_kernel<T>), dim3(g), dim3(256), 0, st, count, index, (const T *)v, (T *)out);
+    return check_launch("pack");
+}
+int launch_pack(int dtype, int count, const int *index, const void *v, void *out, hipStream_t st) {
+    if (count <= 0) return CGAMD_OK;
+    CG_DISPATCH(dtype, pack_impl, count, index, v, out, st);
+}
+
+}  // namespace cgamd

@@ -1,0 +1,309 @@
+// Persistent single-GPU CG solver: the recurrence of reference clcg.c:250-430 (== cl.py:96-200 ==
+// helmFE_var.py:507-544) with every scalar kept on the device, no host synchronisation inside the
+// loop, and the per-iteration kernel sequence replayed from a hipGraph.
+//
+// Per iteration (fused, default) -- 5 launches instead of the reference's 6 kernels + 4 blocking copies:
+//   spmv+dot   q = A d, partials of d.q                     (clcg.c:299-315)
+//   cg_alpha   alpha = delta / (d.q)                          (clcg.c:317-334, done on the host there)
+//   axpy2_dot  x += alpha d ; r -= alpha q ; partials of r.r (clcg.c:338-374)
+//   cg_beta    beta = delta_new/delta_old ; history           (clcg.c:376-411)
+//   aypx       d = beta d + r                                 (clcg.c:415)
+// CGAMD_UNFUSED replays the reference's own op structure (spmv, vdot, axpy, axpy, vdot, aypx).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "cgamd_internal.h"
+
+using namespace cgamd;
+
+struct cgamd_solver {
+    cgamd_ctx *ctx = nullptr;
+    int dtype = 0, n = 0, nrhs = 1, flags = 0;
+    long long nnz = 0;
+    void *vals = nullptr;
+    int *ptr = nullptr, *cols = nullptr;
+    bool own_matrix = false;
+    SpmvPlan plan;
+    int vgrid = 1;
+    void *x = nullptr, *r = nullptr, *d = nullptr, *q = nullptr, *b = nullptr;
+    void *part_dq = nullptr, *part_rr = nullptr;
+    CgScalars sc;
+    bool rhs_set = false;
+    int iters = 0;  // iterations enqueued since set_rhs
+    hipGraphExec_t g1 = nullptr, gU = nullptr;
+    hipGraph_t g1g = nullptr, gUg = nullptr;
+    int U = 8;
+    bool graph_failed = false;
+};
+
+static void destroy_graphs(cgamd_solver *s) {
+    if (s->g1) (void)hipGraphExecDestroy(s->g1);
+    if (s->gU) (void)hipGraphExecDestroy(s->gU);
+    if (s->g1g) (void)hipGraphDestroy(s->g1g);
+    if (s->gUg) (void)hipGraphDestroy(s->gUg);
+    s->g1 = s->gU = nullptr;
+    s->g1g = s->gUg = nullptr;
+}
+
+static int dmalloc(void **p, size_t bytes, const char *what) {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess)
+        return fail(CGAMD_ERR_ALLOC, std::string("hipMalloc(") + what + ", " + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+    return CGAMD_OK;
+}
+
+static int validate_csr_host(int n, long long nnz, const int *ptr, const int *cols) {
+    if (ptr[0] != 0) return fail(CGAMD_ERR_INVALID, "CSR: aPointers[0] != 0");
+    for (int i = 0; i < n; ++i)
+        if (ptr[i + 1] < ptr[i]) return fail(CGAMD_ERR_INVALID, "CSR: aPointers not monotone at row " + std::to_string(i));
+    if (ptr[n] != nnz) return fail(CGAMD_ERR_INVALID, "CSR: aPointers[size] != nonZeros");
+    for (long long j = 0; j < nnz; ++j)
+        if (cols[j] < 0 || cols[j] >= n) return fail(CGAMD_ERR_INVALID, "CSR: column index out of range at entry " + std::to_string(j));
+    return CGAMD_OK;
+}
+
+static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
+    const int dt = s->dtype, n = s->n, nr = s->nrhs;
+    int rc;
+    if (!(s->flags & CGAMD_UNFUSED)) {
+        if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
+        if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.grid, nr, s->sc, st))) return rc;
+        if ((rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st))) return rc;
+        if ((rc = launch_cg_beta(dt, s->part_rr, s->vgrid, nr, s->sc, st))) return rc;
+        return launch_aypx(dt, n, s->r, s->d, n, s->sc.beta, nr, st);
+    }
+    if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, nullptr, nullptr, st))) return rc;
+    if ((rc = launch_dot_partials(dt, n, s->d, s->q, n, nr, s->part_rr, s->vgrid, st))) return rc;
+    if ((rc = launch_cg_alpha(dt, s->part_rr, s->vgrid, nr, s->sc, st))) return rc;
+    if ((rc = launch_axpy(dt, n, s->d, s->x, n, s->sc.alpha, 1, nr, st))) return rc;
+    if ((rc = launch_axpy(dt, n, s->q, s->r, n, s->sc.alpha, 0, nr, st))) return rc;
+    if ((rc = launch_dot_partials(dt, n, s->r, s->r, n, nr, s->part_rr, s->vgrid, st))) return rc;
+    if ((rc = launch_cg_beta(dt, s->part_rr, s->vgrid, nr, s->sc, st))) return rc;
+    return launch_aypx(dt, n, s->r, s->d, n, s->sc.beta, nr, st);
+}
+
+static int capture(cgamd_solver *s, int iters, hipGraph_t *g, hipGraphExec_t *ge) {
+    hipStream_t st = s->ctx->stream;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
+    int rc = CGAMD_OK;
+    for (int i = 0; i < iters && rc == CGAMD_OK; ++i) rc = enqueue_iteration(s, st);
+    e = hipStreamEndCapture(st, g);
+    if (rc != CGAMD_OK) return rc;
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(ge, *g, nullptr, nullptr, 0);
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    return CGAMD_OK;
+}
+
+static int ensure_history(cgamd_solver *s, int entries) {
+    if (entries <= s->sc.history_cap) return CGAMD_OK;
+    int cap = std::max(entries, std::max(1024, s->sc.history_cap * 2));
+    const size_t vs = dtype_size(s->dtype);
+    void *nh = nullptr;
+    if (int rc = dmalloc(&nh, (size_t)cap * s->nrhs * vs, "history")) return rc;
+    if (s->sc.history) {
+        CG_HIP(hipStreamSynchronize(s->ctx->stream));
+        CG_HIP(hipMemcpy(nh, s->sc.history, (size_t)s->sc.history_cap * s->nrhs * vs, hipMemcpyDeviceToDevice));
+        CG_HIP(hipFree(s->sc.history));
+    }
+    s->sc.history = nh;
+    s->sc.history_cap = cap;
+    destroy_graphs(s);  // history pointer / capacity are baked into captured kernel arguments
+    return CGAMD_OK;
+}
+
+extern "C" {
+
+int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, const void *aValues, const int *aPointers,
+                        const int *aCols, int nRHS, int flags, cgamd_solver **out) {
+    if (!out) return fail(CGAMD_ERR_INVALID, "solver_create: out is NULL");
+    *out = nullptr;
+    if (!ctx) return fail(CGAMD_ERR_INVALID, "solver_create: ctx is NULL");
+    if (dtype < 0 || dtype > 3) return fail(CGAMD_ERR_INVALID, "solver_create: bad dtype");
+    if (size < 1 || nnz < 0 || nRHS < 1) return fail(CGAMD_ERR_INVALID, "solver_create: bad size/nnz/nRHS");
+    if (nnz > 2147483647LL - 8192) return fail(CGAMD_ERR_INVALID, "solver_create: nnz exceeds int32 row pointers");
+    if (!aPointers || (nnz > 0 && (!aValues || !aCols))) return fail(CGAMD_ERR_INVALID, "solver_create: null matrix pointer");
+    CG_HIP(hipSetDevice(ctx->device));
+    const size_t vs = dtype_size(dtype);
+    cgamd_solver *s = new cgamd_solver();
+    s->ctx = ctx; s->dtype = dtype; s->n = size; s->nnz = nnz; s->nrhs = nRHS; s->flags = flags;
+    s->plan = make_spmv_plan(size);
+    s->vgrid = vec_grid(size, dtype);
+    int rc = CGAMD_OK;
+    if (flags & CGAMD_MATRIX_ON_DEVICE) {
+        s->vals = const_cast<void *>(aValues);
+        s->ptr = const_cast<int *>(aPointers);
+        s->cols = const_cast<int *>(aCols);
+    } else {
+        rc = validate_csr_host(size, nnz, aPointers, aCols);
+        s->own_matrix = true;
+        if (!rc) rc = dmalloc(&s->vals, (size_t)nnz * vs + 64, "aValues");
+        if (!rc) rc = dmalloc((void **)&s->ptr, (size_t)(size + 1) * 4, "aPointers");
+        if (!rc) rc = dmalloc((void **)&s->cols, (size_t)nnz * 4 + 64, "aCols");
+        if (!rc && nnz) {
+            hipError_t e = hipMemcpyAsync(s->vals, aValues, (size_t)nnz * vs, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(s->cols, aCols, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("upload matrix: ") + hipGetErrorString(e));
+        }
+        if (!rc) {
+            hipError_t e = hipMemcpyAsync(s->ptr, aPointers, (size_t)(size + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("upload aPointers: ") + hipGetErrorString(e));
+        }
+    }
+    const size_t vbytes = (size_t)size * nRHS * vs;
+    if (!rc) rc = dmalloc(&s->x, vbytes, "x");
+    if (!rc) rc = dmalloc(&s->r, vbytes, "r");
+    if (!rc) rc = dmalloc(&s->d, vbytes, "d");
+    if (!rc) rc = dmalloc(&s->q, vbytes, "q");
+    if (!rc) rc = dmalloc(&s->b, vbytes, "b");
+    if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * (size_t)s->plan.grid * nRHS, "partials_dq");
+    if (!rc) rc = dmalloc(&s->part_rr, acc_size(dtype) * (size_t)s->vgrid * nRHS, "partials_rr");
+    if (!rc) rc = dmalloc(&s->sc.alpha, vs * nRHS, "alpha");
+    if (!rc) rc = dmalloc(&s->sc.beta, vs * nRHS, "beta");
+    if (!rc) rc = dmalloc(&s->sc.delta, vs * nRHS, "delta");
+    if (!rc) rc = dmalloc((void **)&s->sc.iter, 16, "iter");
+    if (!rc) rc = ensure_history(s, 1024);
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);  // host matrix arrays may go away after return
+        if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("solver_create sync: ") + hipGetErrorString(e));
+    }
+    if (rc) {
+        std::string keep = cgamd_last_error();
+        cgamd_solver_destroy(s);
+        set_error(keep);
+        return rc;
+    }
+    *out = s;
+    return CGAMD_OK;
+}
+
+int cgamd_solver_destroy(cgamd_solver *s) {
+    if (!s) return CGAMD_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    destroy_graphs(s);
+    if (s->own_matrix) {
+        if (s->vals) (void)hipFree(s->vals);
+        if (s->ptr) (void)hipFree(s->ptr);
+        if (s->cols) (void)hipFree(s->cols);
+    }
+    void *bufs[] = {s->x, s->r, s->d, s->q, s->b, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
+                    s->sc.history, s->sc.iter};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    delete s;
+    return CGAMD_OK;
+}
+
+int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_device) {
+    if (!s || !b) return fail(CGAMD_ERR_INVALID, "set_rhs: null argument");
+    CG_HIP(hipSetDevice(s->ctx->device));
+    hipStream_t st = s->ctx->stream;
+    const size_t vbytes = (size_t)s->n * s->nrhs * dtype_size(s->dtype);
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    CG_HIP(hipMemcpyAsync(s->b, b, vbytes, kind, st));
+    if (x0) CG_HIP(hipMemcpyAsync(s->x, x0, vbytes, kind, st));
+    else CG_HIP(hipMemsetAsync(s->x, 0, vbytes, st));
+    int rc;
+    // r = b - A x0 ; d = r ; delta0 = r.r   (clcg.c:255-292)
+    if ((rc = launch_spmv(s->dtype, s->plan, s->n, s->nnz, s->vals, s->ptr, s->cols, s->x, s->n, s->q, s->n, s->nrhs,
+                          nullptr, nullptr, st))) return rc;
+    if ((rc = launch_sub(s->dtype, s->n, s->b, s->q, s->r, s->n, s->nrhs, st))) return rc;
+    CG_HIP(hipMemcpyAsync(s->d, s->r, vbytes, hipMemcpyDeviceToDevice, st));
+    if ((rc = launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, s->nrhs, s->part_rr, s->vgrid, st))) return rc;
+    if ((rc = launch_cg_delta0(s->dtype, s->part_rr, s->vgrid, s->nrhs, s->sc, st))) return rc;
+    if (!on_device) CG_HIP(hipStreamSynchronize(st));  // host buffers may be released by the caller
+    s->rhs_set = true;
+    s->iters = 0;
+    return CGAMD_OK;
+}
+
+int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
+    if (!s) return fail(CGAMD_ERR_INVALID, "iterate: solver is NULL");
+    if (!s->rhs_set) return fail(CGAMD_ERR_STATE, "iterate: call set_rhs first");
+    if (nIterations < 0) return fail(CGAMD_ERR_INVALID, "iterate: negative iteration count");
+    CG_HIP(hipSetDevice(s->ctx->device));
+    if (int rc = ensure_history(s, s->iters + nIterations + 1)) return rc;
+    hipStream_t st = s->ctx->stream;
+    int left = nIterations;
+    const bool use_graph = !(s->flags & CGAMD_NO_GRAPH) && !s->graph_failed;
+    if (use_graph) {
+        if (!s->g1 && capture(s, 1, &s->g1g, &s->g1) != CGAMD_OK) { s->graph_failed = true; destroy_graphs(s); }
+        if (!s->graph_failed && left >= s->U && !s->gU && capture(s, s->U, &s->gUg, &s->gU) != CGAMD_OK) {
+            s->graph_failed = true;
+            destroy_graphs(s);
+        }
+    }
+    if (use_graph && !s->graph_failed) {
+        while (left >= s->U && s->gU) { CG_HIP(hipGraphLaunch(s->gU, st)); left -= s->U; }
+        while (left > 0) { CG_HIP(hipGraphLaunch(s->g1, st)); --left; }
+    } else {
+        for (; left > 0; --left)
+            if (int rc = enqueue_iteration(s, st)) return rc;
+    }
+    s->iters += nIterations;
+    return CGAMD_OK;
+}
+
+int cgamd_solver_get_x(cgamd_solver *s, void *x, int on_device) {
+    if (!s || !x) return fail(CGAMD_ERR_INVALID, "get_x: null argument");
+    CG_HIP(hipSetDevice(s->ctx->device));
+    const size_t vbytes = (size_t)s->n * s->nrhs * dtype_size(s->dtype);
+    CG_HIP(hipMemcpyAsync(x, s->x, vbytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->ctx->stream));
+    if (!on_device) CG_HIP(hipStreamSynchronize(s->ctx->stream));
+    return CGAMD_OK;
+}
+
+int cgamd_solver_iterations_done(cgamd_solver *s) { return s ? s->iters : -CGAMD_ERR_INVALID; }
+
+int cgamd_solver_history(cgamd_solver *s, void *history, int max_entries) {
+    if (!s || !history) { fail(CGAMD_ERR_INVALID, "history: null argument"); return -CGAMD_ERR_INVALID; }
+    if (!s->rhs_set) { fail(CGAMD_ERR_STATE, "history: no right-hand side set"); return -CGAMD_ERR_STATE; }
+    if (hipSetDevice(s->ctx->device) != hipSuccess) return -CGAMD_ERR_NO_DEVICE;
+    const int entries = std::min(std::min(s->iters + 1, s->sc.history_cap), max_entries);
+    hipError_t e = hipMemcpyAsync(history, s->sc.history, (size_t)entries * s->nrhs * dtype_size(s->dtype),
+                                  hipMemcpyDeviceToHost, s->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->ctx->stream);
+    if (e != hipSuccess) { fail(CGAMD_ERR_HIP, std::string("history: ") + hipGetErrorString(e)); return -CGAMD_ERR_HIP; }
+    return entries;
+}
+
+void *cgamd_solver_vector(cgamd_solver *s, int which) {
+    if (!s) return nullptr;
+    switch (which) { case 0: return s->x; case 1: return s->r; case 2: return s->d; case 3: return s->q; default: return nullptr; }
+}
+
+int cgamd_solver_solve(cgamd_solver *s, const void *b, void *x, int nIterations, void *history) {
+    if (!s || !b || !x) return fail(CGAMD_ERR_INVALID, "solve: null argument");
+    int rc;
+    if ((rc = cgamd_solver_set_rhs(s, b, x, 0))) return rc;   // x is in/out: initial guess (clcg.c:210)
+    if ((rc = cgamd_solver_iterate(s, nIterations))) return rc;
+    if ((rc = cgamd_solver_get_x(s, x, 0))) return rc;
+    if (history) {
+        const int got = cgamd_solver_history(s, history, nIterations + 1);
+        if (got < 0) return -got;
+    }
+    return CGAMD_OK;
+}
+
+int cgamd_solver_spmv(cgamd_solver *s, const void *x, void *y, int fused_dot) {
+    if (!s || !x || !y) return fail(CGAMD_ERR_INVALID, "solver_spmv: null argument");
+    CG_HIP(hipSetDevice(s->ctx->device));
+    return launch_spmv(s->dtype, s->plan, s->n, s->nnz, s->vals, s->ptr, s->cols, x, s->n, y, s->n, s->nrhs,
+                       fused_dot ? x : nullptr, fused_dot ? s->part_dq : nullptr, s->ctx->stream);
+}
+
+long long cgamd_solver_spmv_bytes(cgamd_solver *s) {
+    if (!s) return 0;
+    const long long V = (long long)dtype_size(s->dtype);
+    return s->nnz * (V + 4) + ((long long)s->n + 1) * 4 + 2LL * s->n * V * s->nrhs;
+}
+long long cgamd_solver_iter_bytes(cgamd_solver *s, int fused) {
+    if (!s) return 0;
+    const long long V = (long long)dtype_size(s->dtype);
+    return s->nnz * (V + 4) + ((long long)s->n + 1) * 4 + (fused ? 11LL : 14LL) * s->n * V * s->nrhs;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+/* cgamd.h -- extended C ABI of the MI355X-native CG solver (gfx950, HIP).
+ *
+ * Everything here is plain C: pointers, sizes, opaque handles.  No torch types.
+ * Device pointers are ordinary `void*` values in the HIP address space (e.g.
+ * torch.Tensor.data_ptr()); `stream` arguments are hipStream_t passed as void*
+ * (0/NULL = the context's own stream).
+ *
+ * The API mirrors the reference's operator surface for the CG hot path:
+ *   reference cl.py:16-31   initialize_cl_environment*, get_gpu_devices -> cgamd_ctx_*
+ *   reference cl.py:33-42   kernels {'axpy','aypx','spmv','sub','vdot'}  -> cgamd_{axpy,aypx,spmv,sub,vdot}
+ *   reference cl.py:44-200 / clcg.c:111-466   CG()/cg()                  -> cgamd_solver_* and cg()
+ * plus what SURVEY §8(f) asks for: a persistent handle (matrix stays resident
+ * across solves), the residual history the reference computes but drops
+ * (clcg.c:274-292,384-387), status codes, and row-partitioned multi-GPU CG.
+ *
+ * Value types: the reference is fp32/complex64 only (clcg.h:3-5); f64/c128 are
+ * added for the headline metric.  Complex values are interleaved (re,im).
+ * Multiple right-hand sides are RHS-major: element i of RHS r at [i + r*size].
+ *
+ * All functions return CGAMD_OK (0) or a negative/positive cgamd_status; the
+ * message of the last failure on the calling thread is cgamd_last_error().
+ * There is no CPU fallback anywhere: without a HIP device every compute entry
+ * fails with CGAMD_ERR_NO_DEVICE.
+ */
+#ifndef CGAMD_H
+#define CGAMD_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { CGAMD_F32 = 0, CGAMD_F64 = 1, CGAMD_C64 = 2, CGAMD_C128 = 3 } cgamd_dtype;
+
+typedef enum {
+    CGAMD_OK = 0,
+    CGAMD_ERR_INVALID = 1,    /* bad argument (NULL, negative size, misaligned pointer, bad dtype) */
+    CGAMD_ERR_NO_DEVICE = 2,  /* no HIP device / runtime unavailable */
+    CGAMD_ERR_HIP = 3,        /* a HIP runtime call failed */
+    CGAMD_ERR_ALLOC = 4,
+    CGAMD_ERR_IO = 5,         /* Matrix-Market file problems */
+    CGAMD_ERR_COMM = 6,       /* RCCL failure / not initialised */
+    CGAMD_ERR_STATE = 7       /* call order (e.g. iterate before set_rhs) */
+} cgamd_status;
+
+typedef struct cgamd_ctx cgamd_ctx;
+typedef struct cgamd_solver cgamd_solver;
+
+const char *cgamd_last_error(void);
+int cgamd_version(void);
+size_t cgamd_dtype_size(int dtype);
+
+/* ---- devices / context (reference cl.py:16-31) -------------------------- */
+int cgamd_device_count(void);                                /* <0 on error */
+int cgamd_device_name(int device, char *buf, size_t buflen);
+int cgamd_ctx_create(int device, cgamd_ctx **out);           /* owns one HIP stream + workspace */
+int cgamd_ctx_destroy(cgamd_ctx *ctx);
+int cgamd_ctx_set_stream(cgamd_ctx *ctx, void *stream);      /* borrow caller's stream (torch) */
+void *cgamd_ctx_stream(cgamd_ctx *ctx);
+int cgamd_ctx_device(cgamd_ctx *ctx);
+int cgamd_ctx_synchronize(cgamd_ctx *ctx);
+
+/* device memory helpers for hosts without torch (ctypes + numpy only) */
+int cgamd_malloc(cgamd_ctx *ctx, size_t bytes, void **dptr);
+int cgamd_free(cgamd_ctx *ctx, void *dptr);
+int cgamd_memcpy_h2d(cgamd_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronous */
+int cgamd_memcpy_d2h(cgamd_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronous */
+int cgamd_memcpy_d2d(cgamd_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async on ctx stream */
+int cgamd_memset(cgamd_ctx *ctx, void *dst, int value, size_t bytes);             /* async on ctx stream */
+
+/* ---- the five kernels of the hot path, device pointers, async on ctx stream
+ * spmv : y[row + r*size] = sum_j aValues[j] * x[aCols[j] + r*size]
+ *        (reference kernel/real/spmv.cl:5-50, kernel/complex/spmv.cl:7-53)
+ * vdot : result[r] = sum_i a[i + r*size] * b[i + r*size]   (UNCONJUGATED,
+ *        reference kernel/complex/vdot.cl:15; includes the final reduction the
+ *        reference leaves to the host, clcg.c:274-279); result is a DEVICE array
+ * axpy : y += a[r]*x (aSign != 0)  /  y -= a[r]*x (aSign == 0); a is a DEVICE array
+ *        (reference kernel/real/axpy.cl:2-17)
+ * aypx : y = a[r]*y + x            (reference kernel/real/aypx.cl:2-10)
+ * sub  : result = a - b            (reference kernel/real/sub.cl:2-12)
+ */
+int cgamd_spmv(cgamd_ctx *ctx, int dtype, int size, long long nnz, const void *aValues,
+               const int *aPointers, const int *aCols, const void *x, void *y, int nRHS);
+int cgamd_vdot(cgamd_ctx *ctx, int dtype, int size, const void *a, const void *b, void *result, int nRHS);
+int cgamd_axpy(cgamd_ctx *ctx, int dtype, int size, const void *x, void *y, const void *a, int aSign, int nRHS);
+int cgamd_aypx(cgamd_ctx *ctx, int dtype, int size, const void *x, void *y, const void *a, int nRHS);
+int cgamd_sub(cgamd_ctx *ctx, int dtype, int size, const void *a, const void *b, void *result, int nRHS);
+
+/* ---- persistent solver handle ------------------------
+ * flags for cgamd_solver_create */
+#define CGAMD_MATRIX_ON_DEVICE 1   /* aValues/aPointers/aCols are device pointers, borrowed (not copied) */
+#define CGAMD_NO_GRAPH 2           /* plain stream launches instead of hipGraph replay */
+#define CGAMD_UNFUSED 4            /* reference op structure: spmv, vdot, axpy, axpy, vdot, aypx (6 kernels) */
+#define CGAMD_DIST_GRAPH 8         /* cgamd_dist_create: replay each iteration (incl. RCCL ops) from a hipGraph */
+
+int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, const void *aValues,
+                        const int *aPointers, const int *aCols, int nRHS, int flags, cgamd_solver **out);
+int cgamd_solver_destroy(cgamd_solver *s);
+/* b, x0: nRHS*size values, host (on_device=0) or device (on_device=1) memory; x0 may be NULL (zeros).
+ * Computes r = b - A x0, d = r, delta0 = r.r  (reference clcg.c:255-292) and resets the iteration count. */
+int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_device);
+/* enqueue exactly nIterations iterations (reference clcg.c:297-419); asynchronous, no host sync */
+int cgamd_solver_iterate(cgamd_solver *s, int nIterations);
+/* copy the current iterate; synchronises the stream when on_device == 0 */
+int cgamd_solver_get_x(cgamd_solver *s, void *x, int on_device);
+/* residual history: entry k (k = 0..iterations done) holds delta_k[r] for r < nRHS, value type = dtype.
+ * Synchronises.  Returns the number of entries written (<= max_entries) or a negative status. */
+int cgamd_solver_history(cgamd_solver *s, void *history, int max_entries);
+int cgamd_solver_iterations_done(cgamd_solver *s);
+/* device pointers of the solver's resident state (for zero-copy inspection): which = 0:x 1:r 2:d 3:q */
+void *cgamd_solver_vector(cgamd_solver *s, int which);
+/* convenience: set_rhs + iterate + get_x (+ history if non-NULL, (nIterations+1)*nRHS values), host arrays */
+int cgamd_solver_solve(cgamd_solver *s, const void *b, void *x, int nIterations, void *history);
+/* the solver's SpMV (optionally fused with the d.q partial reduction) on caller vectors -- bench/profiling */
+int cgamd_solver_spmv(cgamd_solver *s, const void *x, void *y, int fused_dot);
+/* algorithmic HBM bytes of one SpMV / one CG iteration of this solver (SURVEY §8d formulae) */
+long long cgamd_solver_spmv_bytes(cgamd_solver *s);
+long long cgamd_solver_iter_bytes(cgamd_solver *s, int fused);
+
+/* one-call typed solve on host arrays: cg() generalised to all four dtypes, with history and status */
+int cgamd_cg(int dtype, int size, long long nnz, const void *aValues, const void *b, const int *aPointers,
+             const int *aCols, void *x, int nRHS, int nIterations, void *history, int device);
+
+/* ---- synthetic matrix generators, written straight into device memory -----
+ * 7-point 3-D Laplacian (x fastest), Dirichlet, diag 6 / off-diag -1 (SURVEY §8d "M", "C5").
+ * Generates global rows [row_begin,row_end) with GLOBAL column indices; canonical CSR.
+ * Pass aPointers==NULL to query nnz of the slab via *nnz_out. */
+int cgamd_gen_laplace3d(cgamd_ctx *ctx, int dtype, int nx, int ny, int nz, long long row_begin,
+                        long long row_end, void *aValues, int *aPointers, int *aCols, long long *nnz_out);
+/* 5-point 2-D Laplacian N x N, diag 4 / off-diag -1 (reference Poisson(), p_h-PY_C-CL.py:1642-1682) */
+int cgamd_gen_poisson2d(cgamd_ctx *ctx, int dtype, int N, void *aValues, int *aPointers, int *aCols,
+                        long long *nnz_out);
+
+/* ---- Matrix-Market ingest (reference main.c:20-33 via BeBOP) ---------------
+ * Reads a coordinate file (real/complex/integer/pattern x general/symmetric/hermitian/skew-symmetric),
+ * expands symmetric storage, sums duplicates, converts 1-based -> 0-based CSR with sorted columns.
+ * Values are returned as double (is_complex=0) or interleaved double pairs (is_complex=1).
+ * Free the three arrays with cgamd_mm_free. */
+int cgamd_mm_read(const char *path, int *size, long long *nnz, int *is_complex, double **values,
+                  int **pointers, int **cols);
+void cgamd_mm_free(void *p);
+
+/* ---- row-partitioned multi-GPU CG (one process per GPU, RCCL over xGMI) ----
+ * The host (torch.distributed) builds the partition plan; this library runs the loop.
+ * See DESIGN.md "Multi-GPU" for the plan layout. */
+typedef struct cgamd_dist cgamd_dist;
+int cgamd_comm_unique_id(void *id128);      /* rank 0: 128 bytes to broadcast */
+int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, int dtype,
+                      int n_local, int n_halo, long long nnz_local, const void *aValues,
+                      const int *aPointers, const int *aCols, /* device, cols in [0,n_local+n_halo) */
+                      int n_peers, const int *peer_rank, const int *send_count, const int *recv_count,
+                      const int *send_index /* device: concatenated local row ids to send */,
+                      int flags, cgamd_dist **out);
+int cgamd_dist_destroy(cgamd_dist *d);
+int cgamd_dist_set_rhs(cgamd_dist *d, const void *b_local, const void *x0_local);   /* device pointers */
+int cgamd_dist_iterate(cgamd_dist *d, int nIterations);
+int cgamd_dist_get_x(cgamd_dist *d, void *x_local);                                  /* device pointer */
+int cgamd_dist_history(cgamd_dist *d, void *history, int max_entries);
+int cgamd_dist_synchronize(cgamd_dist *d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGAMD_H */

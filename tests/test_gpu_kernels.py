@@ -1,0 +1,105 @@
+"""GPU parity of the five hot-path kernels against the CPU oracle, through the C ABI.
+
+Tolerances (stated per SURVEY §8c): the HIP kernels sum in a different order than the reference
+(sequential per row / wave-shuffle trees) and contract a*b+c into FMAs, so results agree to
+rounding: rtol 1e-5 for f32/c64 element-wise ops and row sums, 1e-13 for f64/c128; dots
+accumulate in fp64, so f32 dots are compared at 1e-6 relative to sum|a||b|.
+"""
+import numpy as np
+import pytest
+
+import cg_oracle
+from conftest import ALL_DTYPES, rand_csr, rand_vec
+
+pytestmark = pytest.mark.gpu
+
+RTOL = {np.dtype(np.float32): 2e-5, np.dtype(np.complex64): 2e-5,
+        np.dtype(np.float64): 1e-13, np.dtype(np.complex128): 1e-13}
+
+
+def _buf(pkg, ctx, a):
+    return pkg.DeviceBuffer(ctx, hostbuf=a)
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("n,avg,nrhs", [(1, 1, 1), (7, 3, 1), (255, 5, 1), (256, 7, 1), (257, 7, 2), (1000, 7, 3),
+                                         (5000, 9, 1), (4099, 40, 2), (70000, 7, 1)])
+def test_spmv_matches_oracle(pkg, gpu, dtype, n, avg, nrhs):
+    ctx, queue, kernels = gpu
+    rng = np.random.default_rng(n * 31 + nrhs)
+    indptr, indices, data = rand_csr(rng, n, avg, dtype, empty_rows=n > 100)
+    x = rand_vec(rng, n * nrhs, dtype)
+    want = cg_oracle.spmv(indptr, indices, data, x, nrhs=nrhs, mode=cg_oracle.MODE_SEQUENTIAL)
+    y = _buf(pkg, ctx, np.full(n * nrhs, 7, dtype=dtype))
+    kernels["spmv"](queue, n, _buf(pkg, ctx, data), _buf(pkg, ctx, indptr), _buf(pkg, ctx, indices),
+                    _buf(pkg, ctx, x), y, n_rhs=nrhs)
+    got = y.get()
+    import scipy.sparse as sp
+    scale = np.abs(sp.csr_matrix((np.abs(data), indices, indptr), shape=(n, n))) @ np.abs(x.reshape(nrhs, n).T)
+    scale = scale.T.reshape(-1) + 1e-30
+    assert np.max(np.abs(got - want) / scale) < RTOL[np.dtype(dtype)]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex64])
+def test_spmv_long_rows_span_chunks(pkg, gpu, dtype):
+    """rows longer than one 2048-entry LDS chunk, next to empty rows (multi-chunk accumulate path)"""
+    ctx, queue, kernels = gpu
+    rng = np.random.default_rng(5)
+    n = 6000
+    indptr, indices, data = rand_csr(rng, n, 3, dtype, empty_rows=True, long_row=(300, 5000))
+    x = rand_vec(rng, n, dtype)
+    want = cg_oracle.spmv(indptr, indices, data, x, mode=cg_oracle.MODE_SEQUENTIAL)
+    y = _buf(pkg, ctx, np.zeros(n, dtype=dtype))
+    kernels["spmv"](queue, n, _buf(pkg, ctx, data), _buf(pkg, ctx, indptr), _buf(pkg, ctx, indices), _buf(pkg, ctx, x), y)
+    got = y.get()
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < (1e-4 if np.dtype(dtype).itemsize <= 8 and np.dtype(dtype).kind == 'c' else 1e-12)
+
+
+def test_spmv_reference_order_oracle_agrees(pkg, gpu):
+    """the reference's lane-strided + tree order (spmv.cl:22-43) and the sequential order agree to rounding"""
+    rng = np.random.default_rng(9)
+    indptr, indices, data = rand_csr(rng, 500, 40, np.float64)
+    x = rand_vec(rng, 500, np.float64)
+    a = cg_oracle.spmv(indptr, indices, data, x, mode=cg_oracle.MODE_REFERENCE_ORDER)
+    b = cg_oracle.spmv(indptr, indices, data, x, mode=cg_oracle.MODE_SEQUENTIAL)
+    assert np.allclose(a, b, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("n,nrhs", [(1, 1), (3, 2), (255, 1), (256, 3), (1001, 2), (100003, 1), (262144, 2)])
+def test_vdot_unconjugated(pkg, gpu, dtype, n, nrhs):
+    ctx, queue, kernels = gpu
+    rng = np.random.default_rng(n + nrhs)
+    a, b = rand_vec(rng, n * nrhs, dtype), rand_vec(rng, n * nrhs, dtype)
+    res = _buf(pkg, ctx, np.zeros(nrhs, dtype=dtype))
+    kernels["vdot"](queue, _buf(pkg, ctx, a), _buf(pkg, ctx, b), res, n, n_rhs=nrhs)
+    got = res.get()
+    wide = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    want = np.array([np.dot(a[r * n:(r + 1) * n].astype(wide), b[r * n:(r + 1) * n].astype(wide)) for r in range(nrhs)])
+    scale = np.array([np.dot(np.abs(a[r * n:(r + 1) * n]).astype(np.float64), np.abs(b[r * n:(r + 1) * n]).astype(np.float64)) for r in range(nrhs)])
+    tol = 2e-7 if np.dtype(dtype).itemsize <= 8 and np.dtype(dtype) != np.float64 else 1e-14
+    assert np.max(np.abs(got - want) / scale) < tol
+    # and against the C oracle in the reference's own summation order, at the reference's precision
+    ref = cg_oracle.vdot(a, b, nrhs=nrhs, mode=cg_oracle.MODE_REFERENCE_ORDER)
+    assert np.max(np.abs(got - ref) / scale) < (5e-6 if np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-13)
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("n,nrhs", [(1, 1), (5, 3), (257, 2), (4096, 1), (100001, 2)])
+def test_axpy_aypx_sub(pkg, gpu, dtype, n, nrhs):
+    ctx, queue, kernels = gpu
+    rng = np.random.default_rng(n * 7 + nrhs)
+    x, y = rand_vec(rng, n * nrhs, dtype), rand_vec(rng, n * nrhs, dtype)
+    a = rand_vec(rng, nrhs, dtype)
+    tol = RTOL[np.dtype(dtype)]
+    for sign in (1, 0):
+        yb = _buf(pkg, ctx, y)
+        kernels["axpy"](queue, _buf(pkg, ctx, x), yb, _buf(pkg, ctx, a), sign, n, n_rhs=nrhs)
+        want = cg_oracle.axpy(x, y, a, sign, nrhs=nrhs)
+        assert np.allclose(yb.get(), want, rtol=tol, atol=tol * 4)
+    yb = _buf(pkg, ctx, y)
+    kernels["aypx"](queue, _buf(pkg, ctx, x), yb, _buf(pkg, ctx, a), n, n_rhs=nrhs)
+    assert np.allclose(yb.get(), cg_oracle.aypx(x, y, a, nrhs=nrhs), rtol=tol, atol=tol * 4)
+    rb = _buf(pkg, ctx, np.zeros_like(x))
+    kernels["sub"](queue, _buf(pkg, ctx, x), _buf(pkg, ctx, y), rb, n, n_rhs=nrhs)
+    assert np.array_equal(rb.get(), cg_oracle.sub(x, y, nrhs=nrhs))    # a single rounding: bit-exact
