@@ -48,33 +48,24 @@ def rand_vec(rng, n, dtype):
     return v.astype(dtype)
 
 
-def rand_csr(rng, n, avg_nnz, dtype, spd=False, empty_rows=False, long_row=None):
-    """Random CSR with unsorted columns inside rows (the kernels must not rely on sortedness)."""
-    import scipy.sparse as sp
-    density = min(1.0, avg_nnz / max(n, 1))
-    A = sp.random(n, n, density=density, random_state=np.random.RandomState(rng.integers(1 << 31)), format="lil")
+def rand_csr(rng, n, avg_nnz, dtype, empty_rows=False, long_row=None):
+    """Random CSR, columns unsorted inside rows (the kernels must not rely on sortedness), no duplicates."""
+    counts = np.minimum(rng.poisson(avg_nnz, size=n), n)
+    if empty_rows:
+        counts[rng.choice(n, size=max(1, n // 7), replace=False)] = 0
+    if long_row is not None:
+        counts[long_row[0]] = 0
+    rows = np.repeat(np.arange(n, dtype=np.int64), counts)
+    cols = rng.integers(0, n, size=rows.size, dtype=np.int64)
     if long_row is not None:
         r, ln = long_row
-        cols = rng.choice(n, size=min(ln, n), replace=False)
-        A[r, cols] = 1.0
-    A = A.tocsr()
-    if empty_rows:
-        A = A.tolil()
-        for r in rng.choice(n, size=max(1, n // 7), replace=False):
-            A[r, :] = 0
-        A = A.tocsr()
-        A.eliminate_zeros()
-    data = rand_vec(rng, A.nnz, dtype)
-    A = sp.csr_matrix((data, A.indices, A.indptr), shape=(n, n))
-    if spd:
-        A = (A + A.T.conj() if False else A + A.T) * 0.5
-        A = A + sp.identity(n, dtype=dtype) * (abs(A).sum(axis=1).max() + 1.0)
-        A = sp.csr_matrix(A)
-    # shuffle columns inside each row
-    indptr, indices, data = A.indptr.astype(np.int32), A.indices.astype(np.int32).copy(), A.data.astype(dtype).copy()
-    for r in range(n):
-        s, e = indptr[r], indptr[r + 1]
-        p = rng.permutation(e - s)
-        indices[s:e] = indices[s:e][p]
-        data[s:e] = data[s:e][p]
-    return indptr, indices, data
+        extra = rng.choice(n, size=min(ln, n), replace=False)
+        at = int(np.searchsorted(rows, r))
+        rows = np.insert(rows, at, np.full(extra.size, r))
+        cols = np.insert(cols, at, extra)
+    _, first = np.unique(rows * n + cols, return_index=True)
+    first.sort()                                   # keep generation order => unsorted columns
+    rows, cols = rows[first], cols[first]
+    indptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=n), out=indptr[1:])
+    return indptr, cols.astype(np.int32), rand_vec(rng, cols.size, dtype)
