@@ -45,6 +45,7 @@ def load():
         "cgamd_last_error": (ctypes.c_char_p, []),
         "cgamd_version": (ci, []),
         "cgamd_dtype_size": (sz, [ci]),
+        "cgamd_tune": (ci, [ctypes.c_char_p, ci]),
         "cgamd_device_count": (ci, []),
         "cgamd_device_name": (ci, [ci, ctypes.c_char_p, sz]),
         "cgamd_ctx_create": (ci, [ci, pvp]),

@@ -149,8 +149,15 @@ def initialize_cl_environment_with_device(device):
 
 
 # ---- the five kernels, as callables on DeviceBuffers -------------------------------------------
+_TORCH_NAMES = {"torch.float32": np.float32, "torch.float64": np.float64,
+                "torch.complex64": np.complex64, "torch.complex128": np.complex128}
+
+
 def _code(buf):
-    return _lib.DTYPE_CODE[np.dtype(buf.dtype)]
+    dt = buf.dtype
+    if str(dt) in _TORCH_NAMES:          # torch tensors are accepted wherever a DeviceBuffer is
+        dt = _TORCH_NAMES[str(dt)]
+    return _lib.DTYPE_CODE[np.dtype(dt)]
 
 
 class _Kernels(dict):
@@ -169,7 +176,7 @@ class _Kernels(dict):
         h = ctx.handle
 
         def spmv(queue, size, a_values, a_pointers, a_cols, x, y, n_rhs=None):
-            nnz = a_cols.nbytes // 4
+            nnz = (a_cols.numel() if hasattr(a_cols, "numel") else a_cols.nbytes // 4)
             check(lib.cgamd_spmv(h, _code(a_values), int(size), nnz, ptr(a_values), ptr(a_pointers), ptr(a_cols),
                                  ptr(x), ptr(y), n_rhs or self.n_rhs))
 

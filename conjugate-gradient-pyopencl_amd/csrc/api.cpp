@@ -24,6 +24,20 @@ const char *cgamd_last_error(void) { return g_err.c_str(); }
 int cgamd_version(void) { return 100; }
 size_t cgamd_dtype_size(int dtype) { return dtype_size(dtype); }
 
+int cgamd_tune(const char *key, int value) {
+    if (!key) return fail(CGAMD_ERR_INVALID, "tune: null key");
+    const std::string k(key);
+    if (k == "spmv_variant") g_tune.spmv_variant = value;
+    else if (k == "spmv_nt") g_tune.spmv_nt = value;
+    else if (k == "spmv_grid") g_tune.spmv_grid = value;
+    else if (k == "vec_grid") g_tune.vec_grid = value;
+    else if (k == "spmv_dbg") g_tune.spmv_dbg = value;
+    else if (k == "spmv_map") g_tune.spmv_map = value;
+    else if (k == "spmv_far") g_tune.spmv_far = value;
+    else return fail(CGAMD_ERR_INVALID, "tune: unknown key " + k);
+    return CGAMD_OK;
+}
+
 int cgamd_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

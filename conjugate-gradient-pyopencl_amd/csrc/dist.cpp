@@ -142,7 +142,7 @@ static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
     int rc;
     if ((rc = exchange(d, d->d_ext, st))) return rc;
     if ((rc = launch_spmv(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, ldx, d->q, n, 1, d->d_ext, d->part_dq, st))) return rc;
-    if ((rc = launch_reduce_to_acc(dt, d->part_dq, d->plan.grid, 1, red, st))) return rc;
+    if ((rc = launch_reduce_to_acc(dt, d->part_dq, d->plan.n_partials, 1, red, st))) return rc;
     if ((rc = allreduce_scalar(d, red, st))) return rc;
     if ((rc = launch_cg_alpha(dt, red, 1, 1, d->sc, st))) return rc;
     if ((rc = launch_axpy2_dot(dt, n, d->d_ext, d->x, d->q, d->r, n, d->sc.alpha, 1, d->part_rr, d->vgrid, st))) return rc;
@@ -231,7 +231,7 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     if (!rc) rc = dalloc(&d->b, (size_t)n_local * vs, "b");
     if (!rc) rc = dalloc(&d->d_ext, ((size_t)n_local + n_halo) * vs, "d_ext");
     if (!rc) rc = dalloc(&d->sendbuf, (size_t)so * vs, "sendbuf");
-    if (!rc) rc = dalloc(&d->part_dq, acc_size(dtype) * (size_t)d->plan.grid, "partials_dq");
+    if (!rc) rc = dalloc(&d->part_dq, acc_size(dtype) * (size_t)std::max(d->plan.grid, d->plan.row_blocks), "partials_dq");
     if (!rc) rc = dalloc(&d->part_rr, acc_size(dtype) * (size_t)d->vgrid, "partials_rr");
     if (!rc) rc = dalloc(&d->red, 64, "red");
     if (!rc) rc = dalloc(&d->sc.alpha, vs, "alpha");
@@ -239,6 +239,8 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     if (!rc) rc = dalloc(&d->sc.delta, vs, "delta");
     if (!rc) rc = dalloc((void **)&d->sc.iter, 16, "iter");
     if (!rc) rc = ensure_history(d, 1024);
+    if (!rc) rc = compute_spmv_plan(d->ptr, d->cols, n_local, d->sc.iter, ctx->stream, &d->plan);
+    if (!rc) finalize_spmv_plan(&d->plan, dtype, 1, d->vals, d->cols);
     if (!rc && id128) {
         rc = need_rccl();
         if (!rc) {

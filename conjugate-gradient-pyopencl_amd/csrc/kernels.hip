@@ -16,6 +16,8 @@
 #include "cgamd_internal.h"
 #include "device_types.h"
 
+#include <algorithm>
+
 namespace cgamd {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -29,6 +31,13 @@ template <typename T> struct Pack {
 
 template <typename T> CG_DEV Pack<T> ld_pack(const T *p) { return *reinterpret_cast<const Pack<T> *>(p); }
 template <typename T> CG_DEV void st_pack(T *p, const Pack<T> &v) { *reinterpret_cast<Pack<T> *>(p) = v; }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+CG_DEV void st_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
+CG_DEV void st_nt(double *p, double v) { __builtin_nontemporal_store(v, p); }
+CG_DEV void st_nt(float2 *p, float2 v) { f32x2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<f32x2 *>(p)); }
+CG_DEV void st_nt(double2 *p, double2 v) { f64x2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<f64x2 *>(p)); }
 
 template <typename T> CG_DEV void ld4_nt(const T *p, T (&out)[4]) {
     // 4 consecutive values = sizeof(T)/4 sixteen-byte non-temporal loads
@@ -64,6 +73,10 @@ template <typename T> struct SpmvArgs {
     const T *dvec;                  // fused dot: sum dvec[row] * y[row]
     typename VT<T>::acc *partials;  // [nrhs][grid]
     int row_blocks;
+    int cap;   // variant 5: LDS slice capacity in entries (multiple of 4)
+    int far;   // variant 5: interleave stride in row blocks (far off-diagonal distance)
+    int map;   // row-block schedule of the fast kernels (0 contiguous per work-group, 1 XCD block-cyclic)
+    int dbg;   // experiments only (cgamd_tune spmv_dbg): 1 = skip the x gather, 2 = skip the y store
 };
 
 template <typename T, int BLOCK, int QPT, bool VEC, bool FUSE_DOT>
@@ -172,6 +185,318 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs<T> a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Fast path (nRHS == 1, every BLOCK-row slice fits one chunk -- true for all stencil / FE matrices of the
+// reference): software-pipelined.  While the work-group gathers, multiplies and reduces row block i, the
+// 16-byte matrix loads of row block i+1 are already in flight into a second register set, so the HBM
+// stream of aValues/aCols never drains across the LDS phase.  With DBUF the products ping-pong between two
+// LDS buffers and one barrier per row block suffices.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int BLOCK, int QPT, bool NT>
+CG_DEV void load_quads(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
+                       T (&v)[QPT][4], int (&c)[QPT][4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+        const long long q = (long long)cfirst + 4 * (t + u * BLOCK);
+        if (q < p1) {
+            if (q + 4 <= nnz) {
+                if (NT) {
+                    ld4_nt<T>(vals + q, v[u]);
+                    const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(cols + q));
+                    c[u][0] = cc.x; c[u][1] = cc.y; c[u][2] = cc.z; c[u][3] = cc.w;
+                } else {
+                    constexpr int NV = sizeof(T) * 4 / 16;
+                    union { u32x4 raw[NV]; T w[4]; } uu;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) uu.raw[i] = reinterpret_cast<const u32x4 *>(vals + q)[i];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[u][k] = uu.w[k];
+                    const i32x4 cc = *reinterpret_cast<const i32x4 *>(cols + q);
+                    c[u][0] = cc.x; c[u][1] = cc.y; c[u][2] = cc.z; c[u][3] = cc.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool ok = q + k < nnz;
+                    v[u][k] = ok ? vals[q + k] : vzero<T>();
+                    c[u][k] = ok ? cols[q + k] : 0;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BLOCK, int QPT, bool DBUF, bool NT, bool FUSE_DOT>
+__global__ __launch_bounds__(BLOCK) void spmv_pipe_kernel(SpmvArgs<T> a) {
+    using A = typename VT<T>::acc;
+    constexpr int CHUNK = 4 * QPT * BLOCK;
+    __shared__ T prod[DBUF ? 2 : 1][CHUNK];
+    __shared__ A red[BLOCK / kWave];
+
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    const int L = xcd_remap(blockIdx.x, G);
+    const int rb_begin = (int)((long long)L * a.row_blocks / G);
+    const int rb_end = (int)((long long)(L + 1) * a.row_blocks / G);
+    A dot1 = vzero<A>();
+    if (rb_begin < rb_end) {
+        T v[QPT][4], vn[QPT][4];
+        int c[QPT][4], cn[QPT][4];
+        int p0 = a.ptr[rb_begin * BLOCK];
+        int p1 = a.ptr[min(rb_begin * BLOCK + BLOCK, a.n)];
+        load_quads<T, BLOCK, QPT, NT>(a.vals, a.cols, a.nnz, p0 & ~3, p1, v, c);
+        int buf = 0;
+        for (int rb = rb_begin; rb < rb_end; ++rb) {
+            const int r0 = rb * BLOCK;
+            const int row = r0 + t;
+            const int cfirst = p0 & ~3;
+            int s = 0, e = 0;
+            if (row < a.n) { s = a.ptr[row]; e = a.ptr[row + 1]; }
+            // prefetch the next row block's matrix slice
+            int p1n = p1;
+            if (rb + 1 < rb_end) {
+                p1n = a.ptr[min(r0 + 2 * BLOCK, a.n)];
+                load_quads<T, BLOCK, QPT, NT>(a.vals, a.cols, a.nnz, p1 & ~3, p1n, vn, cn);
+            }
+            T *pb = prod[DBUF ? buf : 0];
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                const long long q = (long long)cfirst + 4 * (t + u * BLOCK);
+                if (q < p1) {
+                    T pr[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pr[k] = vmul(v[u][k], a.x[c[u][k]]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pb[4 * (t + u * BLOCK) + k] = pr[k];
+                }
+            }
+            __syncthreads();
+            T sum = vzero<T>();
+            for (int k = s - cfirst; k < e - cfirst; ++k) sum = vadd(sum, pb[k]);
+            if (row < a.n) {
+                a.y[row] = sum;
+                if (FUSE_DOT) dot1 = vadd(dot1, to_acc(vmul(a.dvec[row], sum)));
+            }
+            if (!DBUF) __syncthreads();
+            buf ^= 1;
+            p0 = p1; p1 = p1n;
+#pragma unroll
+            for (int u = 0; u < QPT; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[u][k] = vn[u][k]; c[u][k] = cn[u][k]; }
+        }
+    }
+    if (FUSE_DOT) {
+        const A tot = block_sum<BLOCK>(dot1, red);
+        if (t == 0) a.partials[L] = tot;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fast path, "matrix through LDS, one lane per row" (variant 3).  The slice of aValues/aCols belonging to
+// BLOCK consecutive rows is streamed from HBM with 16 B coalesced (non-temporal) loads and parked RAW in
+// LDS; after the barrier lane t walks row t out of LDS.  The x gather of step k is then issued by 64 lanes
+// that sit in 64 consecutive rows: for stencil / FE matrices (all the reference feeds this path, SURVEY
+// App. B) their k-th columns are consecutive, so one wave-level gather touches ~4 cache lines instead of
+// the ~24 a nnz-per-lane mapping touches -- the L1->L2 request rate, not HBM, was what bounded the
+// nnz-per-lane kernels at 4.4-4.6 TB/s.  The next slice is prefetched into registers during the row walk.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int BLOCK, int QPT, bool NT, bool FUSE_DOT, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void spmv_rowlds_kernel(SpmvArgs<T> a) {
+    using A = typename VT<T>::acc;
+    constexpr int CHUNK = 4 * QPT * BLOCK;
+    __shared__ __attribute__((aligned(16))) T sv[CHUNK];
+    __shared__ __attribute__((aligned(16))) int sc[CHUNK];
+    __shared__ A red[BLOCK / kWave];
+
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    const int L = xcd_remap(blockIdx.x, G);
+    // Row-block schedule.  map 0: work-group L owns one contiguous run of row blocks.  map 1: the
+    // work-groups of one XCD (G/8 consecutive logical ids) sweep that XCD's row range together, block-
+    // cyclically, so that at any instant they cover one contiguous window of G/8 row blocks and the x
+    // entries shared through the stencil's far diagonals are reused while still in that XCD's L2.
+    int rb_begin, rb_end, rb_step;
+    if (a.map == 1 && (G & 7) == 0) {
+        const int per = G >> 3, xcd = L / per, w = L % per;
+        const int xb = (int)((long long)xcd * a.row_blocks / 8), xe = (int)((long long)(xcd + 1) * a.row_blocks / 8);
+        rb_begin = xb + w; rb_end = xe; rb_step = per;
+    } else {
+        rb_begin = (int)((long long)L * a.row_blocks / G);
+        rb_end = (int)((long long)(L + 1) * a.row_blocks / G);
+        rb_step = 1;
+    }
+    A dot1 = vzero<A>();
+    if (rb_begin < rb_end) {
+        T v[QPT][4];
+        int c[QPT][4];
+        int p0 = a.ptr[rb_begin * BLOCK];
+        int p1 = a.ptr[min(rb_begin * BLOCK + BLOCK, a.n)];
+        load_quads<T, BLOCK, QPT, NT>(a.vals, a.cols, a.nnz, p0 & ~3, p1, v, c);
+        for (int rb = rb_begin; rb < rb_end; rb += rb_step) {
+            const int r0 = rb * BLOCK;
+            const int row = r0 + t;
+            const int cfirst = p0 & ~3;
+            int s = 0, e = 0;
+            if (row < a.n) { s = a.ptr[row] - cfirst; e = a.ptr[row + 1] - cfirst; }
+            // park the raw slice in LDS (16 B stores)
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                const long long q = (long long)cfirst + 4 * (t + u * BLOCK);
+                if (q < p1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { sv[4 * (t + u * BLOCK) + k] = v[u][k]; sc[4 * (t + u * BLOCK) + k] = c[u][k]; }
+                }
+            }
+            // prefetch the next slice while this one is consumed
+            int p0n = p1, p1n = p1;
+            if (rb + rb_step < rb_end) {
+                const int rn = (rb + rb_step) * BLOCK;
+                p0n = a.ptr[rn];
+                p1n = a.ptr[min(rn + BLOCK, a.n)];
+                load_quads<T, BLOCK, QPT, NT>(a.vals, a.cols, a.nnz, p0n & ~3, p1n, v, c);
+            }
+            __syncthreads();
+            T sum = vzero<T>();
+            for (int k = s; k < e; k += UNROLL) {
+                T xv[UNROLL], av[UNROLL];
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j)
+                    if (k + j < e) { av[j] = sv[k + j]; xv[j] = (a.dbg & 1) ? av[j] : a.x[sc[k + j]]; }
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j)
+                    if (k + j < e) sum = vfma(av[j], xv[j], sum);
+            }
+            if (row < a.n) {
+                if (!(a.dbg & 2)) {
+                    if (a.dbg & 4) st_nt(a.y + row, sum);
+                    else a.y[row] = sum;
+                }
+                if (FUSE_DOT) dot1 = vadd(dot1, to_acc(vmul((a.dbg & 1) ? sum : a.dvec[row], sum)));
+            }
+            __syncthreads();
+            p0 = p0n; p1 = p1n;
+        }
+    }
+    if (FUSE_DOT) {
+        const A tot = block_sum<BLOCK>(dot1, red);
+        if (t == 0) a.partials[L] = tot;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fast path, variant 5 (default): ONE row block per work-group, no persistence -- the hardware dispatcher
+// keeps every CU stocked and balances the load; measured 12-15 % faster than the persistent forms.
+// Schedule: work-group b runs on XCD b%8 (round-robin dispatch) and is the (b/8)-th block of that XCD.
+// Each XCD owns one contiguous eighth of the row blocks and sweeps it in an order interleaved with
+// stride S = `far` row blocks (the distance of the matrix's far off-diagonals, sampled at plan time):
+// consecutive dispatches take blocks y, y+S, y+2S, ... so the blocks that share x entries through the
+// far diagonals (the z-neighbours of a 3-D stencil) are resident at the same time and hit the XCD's L2,
+// instead of re-fetching x once per far diagonal (measured: 3x x traffic without the interleave).
+// LDS: raw slice (values + columns) sized at launch from the plan's largest slice.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
+    using A = typename VT<T>::acc;
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    T *sv = reinterpret_cast<T *>(dyn_smem);                       // [cap]
+    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));   // [cap]
+    __shared__ A red[BLOCK / kWave];
+
+    const int t = threadIdx.x;
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int xb = (int)((long long)xcd * a.row_blocks / 8), xe = (int)((long long)(xcd + 1) * a.row_blocks / 8);
+    const int m = xe - xb;
+    if (i >= m) return;
+    int rb;
+    {
+        const int S = min(max(a.far, 1), m), q = m / S, rem = m % S;
+        int y, z;
+        if (i < rem * (q + 1)) { y = i / (q + 1); z = i % (q + 1); }
+        else { const int j = i - rem * (q + 1); y = rem + j / q; z = j % q; }
+        rb = xb + y + z * S;
+    }
+    const int r0 = rb * BLOCK;
+    const int row = r0 + t;
+    const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
+    const int cfirst = p0 & ~3;
+    int s = 0, e = 0;
+    if (row < a.n) { s = a.ptr[row] - cfirst; e = a.ptr[row + 1] - cfirst; }
+    // stream the slice: 16 B per lane per load, straight into LDS
+    for (long long q = (long long)cfirst + 4 * t; q < p1; q += 4 * BLOCK) {
+        T v[4];
+        int c[4];
+        if (q + 4 <= a.nnz) {
+            if (NT) {
+                ld4_nt<T>(a.vals + q, v);
+                const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(a.cols + q));
+                c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+            } else {
+                constexpr int NV = sizeof(T) * 4 / 16;
+                union { u32x4 raw[NV]; T w[4]; } uu;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) uu.raw[k] = reinterpret_cast<const u32x4 *>(a.vals + q)[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = uu.w[k];
+                const i32x4 cc = *reinterpret_cast<const i32x4 *>(a.cols + q);
+                c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = q + k < a.nnz;
+                v[k] = ok ? a.vals[q + k] : vzero<T>();
+                c[k] = ok ? a.cols[q + k] : 0;
+            }
+        }
+        const int o = (int)(q - cfirst);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sv[o + k] = v[k]; sc[o + k] = c[k]; }
+    }
+    __syncthreads();
+    T sum = vzero<T>();
+    for (int k = s; k < e; k += UNROLL) {
+        T xv[UNROLL], av[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j)
+            if (k + j < e) { av[j] = sv[k + j]; xv[j] = a.x[sc[k + j]]; }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j)
+            if (k + j < e) sum = vfma(av[j], xv[j], sum);
+    }
+    A dot1 = vzero<A>();
+    if (row < a.n) {
+        a.y[row] = sum;
+        if (FUSE_DOT) dot1 = to_acc(vmul(a.dvec[row], sum));
+    }
+    if (FUSE_DOT) {
+        const A tot = block_sum<BLOCK>(dot1, red);
+        if (t == 0) a.partials[rb] = tot;
+    }
+}
+
+// plan-time sample of the far off-diagonal distance: out[k] = max_j |col_j - row| for every `step`-th row
+__global__ void spmv_far_sample_kernel(int n, const int *__restrict__ ptr, const int *__restrict__ cols, int step,
+                                       int nsamples, int *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nsamples) return;
+    const int row = min((int)((long long)k * step), n - 1);
+    int far = 0;
+    for (int j = ptr[row]; j < ptr[row + 1]; ++j) far = max(far, abs(cols[j] - row));
+    out[k] = far;
+}
+
+// largest (4-aligned) non-zero span of any BLOCK-row slice: decides whether the fast path applies
+template <int BLOCK> __global__ void spmv_span_kernel(int n, const int *__restrict__ ptr, int row_blocks, int *out) {
+    int m = 0;
+    for (int rb = blockIdx.x * blockDim.x + threadIdx.x; rb < row_blocks; rb += gridDim.x * blockDim.x) {
+        const int p0 = ptr[rb * BLOCK], p1 = ptr[min(rb * BLOCK + BLOCK, n)];
+        m = max(m, p1 - (p0 & ~3));
+    }
+    if (m > 0) atomicMax(out, m);
+}
+
 // =================================================================================================
 // Streaming vector kernels.  grid = (G, nRHS); RHS r lives at base + r*ld.
 // =================================================================================================
@@ -278,73 +603,81 @@ __global__ __launch_bounds__(BLOCK) void ewise_kernel(int n, const T *__restrict
 }
 
 // =================================================================================================
-// Scalar kernels: one work-group; wave w owns RHS r = w, w+4, ...; fixed summation order.
+// Scalar kernels: one 256-thread work-group per RHS; fixed summation order (thread-strided, wave
+// shuffle, then the 4 wave sums in order) => bitwise reproducible.
 // =================================================================================================
-template <typename A> CG_DEV A sum_partials_wave(const A *p, int grid) {
+constexpr int kScalarBlock = 1024;
+template <typename A> CG_DEV A sum_partials_block(const A *p, int grid, A *smem) {
     A acc = vzero<A>();
-    for (int i = threadIdx.x & (kWave - 1); i < grid; i += kWave) acc = vadd(acc, p[i]);
-    return wave_sum(acc);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void reduce_to_value_kernel(const typename VT<T>::acc *partials, int grid, int nrhs,
-                                                              T *result) {
-    for (int r = threadIdx.x / kWave; r < nrhs; r += 256 / kWave) {
-        const auto s = sum_partials_wave(partials + (long long)r * grid, grid);
-        if ((threadIdx.x & (kWave - 1)) == 0) result[r] = from_acc<T>(s);
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void cg_delta0_kernel(const typename VT<T>::acc *partials, int grid, int nrhs, T *delta,
-                                                        T *history, int *iter) {
-    for (int r = threadIdx.x / kWave; r < nrhs; r += 256 / kWave) {
-        const auto s = sum_partials_wave(partials + (long long)r * grid, grid);
-        if ((threadIdx.x & (kWave - 1)) == 0) {
-            delta[r] = from_acc<T>(s);
-            history[r] = from_acc<T>(s);
-        }
-    }
-    if (threadIdx.x == 0) *iter = 0;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void cg_alpha_kernel(const typename VT<T>::acc *partials, int grid, int nrhs,
-                                                       const T *delta, T *alpha) {
-    for (int r = threadIdx.x / kWave; r < nrhs; r += 256 / kWave) {
-        const auto dq = sum_partials_wave(partials + (long long)r * grid, grid);
-        if ((threadIdx.x & (kWave - 1)) == 0) {
-            // the reference rounds dq to the value type before dividing (clcg.c:318-327)
-            const T dqT = from_acc<T>(dq);
-            alpha[r] = from_acc<T>(acc_div(to_acc(delta[r]), to_acc(dqT)));
-        }
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void cg_beta_kernel(const typename VT<T>::acc *partials, int grid, int nrhs, T *delta,
-                                                      T *beta, T *history, int history_cap, int *iter) {
-    const int it = *iter + 1;
-    for (int r = threadIdx.x / kWave; r < nrhs; r += 256 / kWave) {
-        const auto dn = sum_partials_wave(partials + (long long)r * grid, grid);
-        if ((threadIdx.x & (kWave - 1)) == 0) {
-            const T dnT = from_acc<T>(dn);
-            beta[r] = from_acc<T>(acc_div(to_acc(dnT), to_acc(delta[r])));   // clcg.c:389-391
-            delta[r] = dnT;
-            if (it < history_cap) history[(long long)it * nrhs + r] = dnT;
-        }
-    }
+#pragma unroll 4
+    for (int i = threadIdx.x; i < grid; i += kScalarBlock) acc = vadd(acc, p[i]);
+    acc = block_sum<kScalarBlock>(acc, smem);
     __syncthreads();
-    if (threadIdx.x == 0) *iter = it;
+    if (threadIdx.x == 0) smem[0] = acc;
+    __syncthreads();
+    return smem[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kScalarBlock) void reduce_to_value_kernel(const typename VT<T>::acc *partials, int grid, int nrhs,
+                                                              T *result) {
+    __shared__ typename VT<T>::acc smem[kScalarBlock / kWave];
+    const int r = blockIdx.x;
+    const auto s = sum_partials_block(partials + (long long)r * grid, grid, smem);
+    if (threadIdx.x == 0) result[r] = from_acc<T>(s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kScalarBlock) void cg_delta0_kernel(const typename VT<T>::acc *partials, int grid, int nrhs, T *delta,
+                                                        T *history, int *iter) {
+    __shared__ typename VT<T>::acc smem[kScalarBlock / kWave];
+    const int r = blockIdx.x;
+    const auto s = sum_partials_block(partials + (long long)r * grid, grid, smem);
+    if (threadIdx.x == 0) {
+        delta[r] = from_acc<T>(s);
+        history[r] = from_acc<T>(s);
+        if (r == 0) *iter = 0;
+    }
+}
+
+// alpha[r] = delta[r] / (d.q)[r].  Block 0 also advances the iteration counter: the counter is only READ by
+// the cg_beta kernel of the same iteration (a later launch), never inside this launch.
+template <typename T>
+__global__ __launch_bounds__(kScalarBlock) void cg_alpha_kernel(const typename VT<T>::acc *partials, int grid, int nrhs,
+                                                       const T *delta, T *alpha, int *iter) {
+    __shared__ typename VT<T>::acc smem[kScalarBlock / kWave];
+    const int r = blockIdx.x;
+    const auto dq = sum_partials_block(partials + (long long)r * grid, grid, smem);
+    if (threadIdx.x == 0) {
+        // the reference rounds dq to the value type before dividing (clcg.c:318-327)
+        const T dqT = from_acc<T>(dq);
+        alpha[r] = from_acc<T>(acc_div(to_acc(delta[r]), to_acc(dqT)));
+        if (r == 0) *iter = *iter + 1;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kScalarBlock) void cg_beta_kernel(const typename VT<T>::acc *partials, int grid, int nrhs, T *delta,
+                                                      T *beta, T *history, int history_cap, const int *iter) {
+    __shared__ typename VT<T>::acc smem[kScalarBlock / kWave];
+    const int r = blockIdx.x;
+    const auto dn = sum_partials_block(partials + (long long)r * grid, grid, smem);
+    if (threadIdx.x == 0) {
+        const int it = *iter;   // already advanced by cg_alpha of this iteration
+        const T dnT = from_acc<T>(dn);
+        beta[r] = from_acc<T>(acc_div(to_acc(dnT), to_acc(delta[r])));   // clcg.c:389-391
+        delta[r] = dnT;
+        if (it < history_cap) history[(long long)it * nrhs + r] = dnT;
+    }
 }
 
 // partials -> one accumulator value per RHS (input of the RCCL all-reduce in the multi-GPU loop)
 template <typename A>
-__global__ __launch_bounds__(256) void reduce_to_acc_kernel(const A *partials, int grid, int nrhs, A *out) {
-    for (int r = threadIdx.x / kWave; r < nrhs; r += 256 / kWave) {
-        const A s = sum_partials_wave(partials + (long long)r * grid, grid);
-        if ((threadIdx.x & (kWave - 1)) == 0) out[r] = s;
-    }
+__global__ __launch_bounds__(kScalarBlock) void reduce_to_acc_kernel(const A *partials, int grid, int nrhs, A *out) {
+    __shared__ A smem[kScalarBlock / kWave];
+    const int r = blockIdx.x;
+    const A s = sum_partials_block(partials + (long long)r * grid, grid, smem);
+    if (threadIdx.x == 0) out[r] = s;
 }
 
 // halo pack: out[k] = v[index[k]]  (boundary entries of d that neighbouring ranks gather in their SpMV)
@@ -444,20 +777,25 @@ static int check_launch(const char *what) {
 SpmvPlan make_spmv_plan(int n) {
     SpmvPlan p;
     p.row_blocks = (n + kBlock - 1) / kBlock;
-    int g = p.row_blocks < kMaxGrid ? p.row_blocks : kMaxGrid;
+    const int cap = g_tune.spmv_grid > 0 ? g_tune.spmv_grid : kMaxGrid;
+    int g = p.row_blocks < cap ? p.row_blocks : cap;
     if (g >= 8) g &= ~7;  // xcd_remap needs a multiple of 8
     if (g < 1) g = 1;
     p.grid = g;
+    p.n_partials = g;
     return p;
 }
 
 int vec_grid(long long n, int dtype) {
     const long long per_block = (long long)kBlock * (16 / (long long)dtype_size(dtype)) * 4;  // 4 packs per thread
     long long g = (n + per_block - 1) / per_block;
-    if (g > kMaxGrid) g = kMaxGrid;
+    const long long cap = g_tune.vec_grid > 0 ? g_tune.vec_grid : kMaxGrid;
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
 }
+
+Tuning g_tune;
 
 template <typename T>
 static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
@@ -471,10 +809,54 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     a.dvec = static_cast<const T *>(dvec);
     a.partials = static_cast<typename VT<T>::acc *>(partials);
     a.row_blocks = plan.row_blocks;
+    a.dbg = g_tune.spmv_dbg;
+    a.map = g_tune.spmv_map;
     const bool vec = aligned16(vals) && aligned16(cols);
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
     dim3 grid(plan.grid), block(kBlock);
+    const int variant = (vec && nrhs == 1) ? plan.kind : 0;
+    if (variant == 5) {
+        a.cap = (plan.max_span + 3) & ~3;
+        a.far = g_tune.spmv_far >= 0 ? g_tune.spmv_far : plan.far_blocks;
+        const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
+        int per_xcd = 0;
+        for (int x = 0; x < 8; ++x) {
+            const int m = (int)((long long)(x + 1) * plan.row_blocks / 8) - (int)((long long)x * plan.row_blocks / 8);
+            per_xcd = m > per_xcd ? m : per_xcd;
+        }
+        dim3 g5(per_xcd * 8);
+        const bool nt = g_tune.spmv_nt != 0;
+#define CG_RB(NT)                                                                                                \
+    do {                                                                                                         \
+        if (fuse) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, true, 8>), g5, block, lds, st, a);     \
+        else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, 8>), g5, block, lds, st, a);         \
+    } while (0)
+        if (nt) CG_RB(true); else CG_RB(false);
+#undef CG_RB
+        return check_launch("spmv_rowblock");
+    }
+    if (variant != 0) {
+        // fast path: software-pipelined single-chunk kernel
+#define CG_PIPE(DBUF, NT)                                                                                        \
+    do {                                                                                                         \
+        if (fuse) hipLaunchKernelGGL((spmv_pipe_kernel<T, kBlock, kQuadsPerThread, DBUF, NT, true>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((spmv_pipe_kernel<T, kBlock, kQuadsPerThread, DBUF, NT, false>), grid, block, 0, st, a);      \
+    } while (0)
+#define CG_ROWLDS(NT, UNR)                                                                                       \
+    do {                                                                                                         \
+        if (fuse) hipLaunchKernelGGL((spmv_rowlds_kernel<T, kBlock, kQuadsPerThread, NT, true, UNR>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((spmv_rowlds_kernel<T, kBlock, kQuadsPerThread, NT, false, UNR>), grid, block, 0, st, a);      \
+    } while (0)
+        const bool nt = g_tune.spmv_nt != 0;
+        if (variant == 1) { if (nt) CG_PIPE(false, true); else CG_PIPE(false, false); }
+        else if (variant == 2) { if (nt) CG_PIPE(true, true); else CG_PIPE(true, false); }
+        else if (variant == 4) { if (nt) CG_ROWLDS(true, 4); else CG_ROWLDS(false, 4); }
+        else { if (nt) CG_ROWLDS(true, 8); else CG_ROWLDS(false, 8); }
+#undef CG_PIPE
+#undef CG_ROWLDS
+        return check_launch("spmv_fast");
+    }
     if (vec) {
         if (fuse) hipLaunchKernelGGL((spmv_stream_kernel<T, kBlock, kQuadsPerThread, true, true>), grid, block, dyn, st, a);
         else hipLaunchKernelGGL((spmv_stream_kernel<T, kBlock, kQuadsPerThread, true, false>), grid, block, dyn, st, a);
@@ -483,6 +865,52 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         else hipLaunchKernelGGL((spmv_stream_kernel<T, kBlock, kQuadsPerThread, false, false>), grid, block, dyn, st, a);
     }
     return check_launch("spmv");
+}
+
+int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan) {
+    // (1) largest slice span -> which kernels apply, LDS size
+    const int row_blocks = (n + kBlock - 1) / kBlock;
+    CG_HIP(hipMemsetAsync(scratch_dev, 0, sizeof(int), st));
+    int g = (row_blocks + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL((spmv_span_kernel<kBlock>), dim3(g), dim3(256), 0, st, n, ptr_dev, row_blocks, scratch_dev);
+    if (int rc = check_launch("spmv_span")) return rc;
+    CG_HIP(hipMemcpyAsync(&plan->max_span, scratch_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    // (2) median far off-diagonal distance over <= 1024 sampled rows -> interleave stride of the schedule
+    constexpr int kSamples = 1024;
+    const int nsamples = n < kSamples ? n : kSamples;
+    const int step = n / nsamples > 0 ? n / nsamples : 1;
+    int *samples_dev = nullptr;
+    CG_HIP(hipMalloc(&samples_dev, sizeof(int) * kSamples));
+    hipLaunchKernelGGL(spmv_far_sample_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, st, n, ptr_dev, cols_dev, step,
+                       nsamples, samples_dev);
+    int rc = check_launch("spmv_far_sample");
+    int host[kSamples];
+    hipError_t e = rc ? hipSuccess : hipMemcpyAsync(host, samples_dev, sizeof(int) * nsamples, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(samples_dev);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("spmv plan: ") + hipGetErrorString(e));
+    std::nth_element(host, host + nsamples / 2, host + nsamples);
+    const long long far_rows = host[nsamples / 2];
+    long long S = (far_rows + kBlock / 2) / kBlock;   // in row blocks
+    // interleaving only pays when the far diagonals are further apart than one XCD's resident window
+    // (~200 row blocks) can bridge, and when an XCD's share holds at least a few strides
+    if (S < 32 || S * 4 > row_blocks / 8) S = 1;
+    plan->far_blocks = (int)S;
+    return CGAMD_OK;
+}
+
+// decides once which SpMV kernel a solver uses (and therefore how many dot partials it produces)
+void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, const void *vals, const int *cols) {
+    constexpr int CHUNK = 4 * kQuadsPerThread * kBlock;
+    int kind = g_tune.spmv_variant;
+    const bool vec = aligned16(vals) && aligned16(cols);
+    if (!vec || nrhs != 1 || plan->max_span <= 0) kind = 0;
+    if (kind == 5 && (size_t)plan->max_span * (dtype_size(dtype) + 4) > (size_t)kMaxSliceBytes) kind = 0;
+    if (kind >= 1 && kind <= 4 && plan->max_span > CHUNK) kind = 0;
+    plan->kind = kind;
+    plan->n_partials = kind == 5 ? plan->row_blocks : plan->grid;
 }
 
 int launch_spmv(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr,
@@ -515,7 +943,7 @@ int launch_dot_partials(int dtype, int n, const void *a, const void *b, long lon
 }
 
 template <typename T> static int reduce_impl(const void *partials, int grid, int nrhs, void *result, hipStream_t st) {
-    hipLaunchKernelGGL((reduce_to_value_kernel<T>), dim3(1), dim3(256), 0, st,
+    hipLaunchKernelGGL((reduce_to_value_kernel<T>), dim3(nrhs), dim3(kScalarBlock), 0, st,
                        static_cast<const typename VT<T>::acc *>(partials), grid, nrhs, static_cast<T *>(result));
     return check_launch("reduce");
 }
@@ -569,7 +997,7 @@ int launch_axpy2_dot(int dtype, int n, const void *d, void *x, const void *q, vo
 }
 
 template <typename T> static int delta0_impl(const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
-    hipLaunchKernelGGL((cg_delta0_kernel<T>), dim3(1), dim3(256), 0, st, static_cast<const typename VT<T>::acc *>(partials),
+    hipLaunchKernelGGL((cg_delta0_kernel<T>), dim3(nrhs), dim3(kScalarBlock), 0, st, static_cast<const typename VT<T>::acc *>(partials),
                        grid, nrhs, (T *)s.delta, (T *)s.history, s.iter);
     return check_launch("cg_delta0");
 }
@@ -577,15 +1005,15 @@ int launch_cg_delta0(int dtype, const void *partials, int grid, int nrhs, const 
     CG_DISPATCH(dtype, delta0_impl, partials, grid, nrhs, s, st);
 }
 template <typename T> static int alpha_impl(const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
-    hipLaunchKernelGGL((cg_alpha_kernel<T>), dim3(1), dim3(256), 0, st, static_cast<const typename VT<T>::acc *>(partials),
-                       grid, nrhs, (const T *)s.delta, (T *)s.alpha);
+    hipLaunchKernelGGL((cg_alpha_kernel<T>), dim3(nrhs), dim3(kScalarBlock), 0, st, static_cast<const typename VT<T>::acc *>(partials),
+                       grid, nrhs, (const T *)s.delta, (T *)s.alpha, s.iter);
     return check_launch("cg_alpha");
 }
 int launch_cg_alpha(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
     CG_DISPATCH(dtype, alpha_impl, partials, grid, nrhs, s, st);
 }
 template <typename T> static int beta_impl(const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
-    hipLaunchKernelGGL((cg_beta_kernel<T>), dim3(1), dim3(256), 0, st, static_cast<const typename VT<T>::acc *>(partials),
+    hipLaunchKernelGGL((cg_beta_kernel<T>), dim3(nrhs), dim3(kScalarBlock), 0, st, static_cast<const typename VT<T>::acc *>(partials),
                        grid, nrhs, (T *)s.delta, (T *)s.beta, (T *)s.history, s.history_cap, s.iter);
     return check_launch("cg_beta");
 }
@@ -616,9 +1044,9 @@ int launch_gen_poisson2d(int dtype, int N, void *vals, int *ptr, int *cols, hipS
 
 int launch_reduce_to_acc(int dtype, const void *partials, int grid, int nrhs, void *out, hipStream_t st) {
     if (dtype == CGAMD_F32 || dtype == CGAMD_F64)
-        hipLaunchKernelGGL((reduce_to_acc_kernel<double>), dim3(1), dim3(256), 0, st, (const double *)partials, grid, nrhs, (double *)out);
+        hipLaunchKernelGGL((reduce_to_acc_kernel<double>), dim3(nrhs), dim3(kScalarBlock), 0, st, (const double *)partials, grid, nrhs, (double *)out);
     else
-        hipLaunchKernelGGL((reduce_to_acc_kernel<double2>), dim3(1), dim3(256), 0, st, (const double2 *)partials, grid, nrhs, (double2 *)out);
+        hipLaunchKernelGGL((reduce_to_acc_kernel<double2>), dim3(nrhs), dim3(kScalarBlock), 0, st, (const double2 *)partials, grid, nrhs, (double2 *)out);
     return check_launch("reduce_to_acc");
 }
 

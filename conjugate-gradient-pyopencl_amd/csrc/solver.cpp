@@ -68,7 +68,7 @@ static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
     int rc;
     if (!(s->flags & CGAMD_UNFUSED)) {
         if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
-        if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.grid, nr, s->sc, st))) return rc;
+        if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
         if ((rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st))) return rc;
         if ((rc = launch_cg_beta(dt, s->part_rr, s->vgrid, nr, s->sc, st))) return rc;
         return launch_aypx(dt, n, s->r, s->d, n, s->sc.beta, nr, st);
@@ -158,13 +158,15 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) rc = dmalloc(&s->d, vbytes, "d");
     if (!rc) rc = dmalloc(&s->q, vbytes, "q");
     if (!rc) rc = dmalloc(&s->b, vbytes, "b");
-    if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * (size_t)s->plan.grid * nRHS, "partials_dq");
+    if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * (size_t)std::max(s->plan.grid, s->plan.row_blocks) * nRHS, "partials_dq");
     if (!rc) rc = dmalloc(&s->part_rr, acc_size(dtype) * (size_t)s->vgrid * nRHS, "partials_rr");
     if (!rc) rc = dmalloc(&s->sc.alpha, vs * nRHS, "alpha");
     if (!rc) rc = dmalloc(&s->sc.beta, vs * nRHS, "beta");
     if (!rc) rc = dmalloc(&s->sc.delta, vs * nRHS, "delta");
     if (!rc) rc = dmalloc((void **)&s->sc.iter, 16, "iter");
     if (!rc) rc = ensure_history(s, 1024);
+    if (!rc) rc = compute_spmv_plan(s->ptr, s->cols, size, s->sc.iter, ctx->stream, &s->plan);
+    if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, s->vals, s->cols);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(ctx->stream);  // host matrix arrays may go away after return
         if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("solver_create sync: ") + hipGetErrorString(e));

@@ -50,6 +50,11 @@ const char *cgamd_last_error(void);
 int cgamd_version(void);
 size_t cgamd_dtype_size(int dtype);
 
+/* run-time tuning knob (A/B experiments and profiling): keys "spmv_variant" (0 generic CSR-stream, 1 pipelined,
+ * 2 pipelined + LDS ping-pong = default), "spmv_nt" (non-temporal matrix loads, default 1), "spmv_grid",
+ * "vec_grid" (0 = auto).  Affects solvers created afterwards (grids) / launches issued afterwards (variants). */
+int cgamd_tune(const char *key, int value);
+
 /* ---- devices / context (reference cl.py:16-31) -------------------------- */
 int cgamd_device_count(void);                                /* <0 on error */
 int cgamd_device_name(int device, char *buf, size_t buflen);

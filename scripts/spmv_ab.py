@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""In-process interleaved A/B of SpMV / CG-iteration variants (cdna_hip_programming.md §5.4 rule 24).
+usage: python scripts/spmv_ab.py [--grid 250x200x200] [--dtype f64] [--rounds 5] cfg1 cfg2 ...
+  where cfg = comma-separated key=value tuning pairs, e.g.  spmv_variant=0  spmv_variant=2,spmv_grid=1024
+"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", default="250x200x200")
+    ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("cfgs", nargs="*", default=["spmv_variant=0", "spmv_variant=1", "spmv_variant=2"])
+    args = ap.parse_args()
+    import torch
+    pkg = importlib.import_module("conjugate-gradient-pyopencl_amd")
+    lib = pkg._lib.load()
+    dtype = {"f32": np.float32, "f64": np.float64, "c64": np.complex64, "c128": np.complex128}[args.dtype]
+    nx, ny, nz = (int(v) for v in args.grid.split("x"))
+    n = nx * ny * nz
+    ctx = pkg.Context(0)
+    dev = torch.device("cuda", 0)
+    indptr, indices, data = pkg.generators.laplace3d(ctx, nx, ny, nz, dtype=dtype)
+    nnz = int(indices.numel())
+    tdt = pkg.generators.torch_dtype(dtype)
+    b = torch.full((n,), 5.0, dtype=tdt, device=dev)
+    xs = torch.rand(n, dtype=torch.float64, device=dev).to(tdt)
+    ys = torch.empty(n, dtype=tdt, device=dev)
+    torch.cuda.synchronize()
+    ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    defaults = {"spmv_variant": 5, "spmv_nt": 1, "spmv_grid": 0, "vec_grid": 0, "spmv_dbg": 0, "spmv_map": 0, "spmv_far": -1}
+    solvers = []
+    for cfg in args.cfgs:
+        kv = dict(defaults)
+        for pair in cfg.split(","):
+            if pair:
+                k, v = pair.split("=")
+                kv[k] = int(v)
+        for k, v in kv.items():
+            pkg._lib.check(lib.cgamd_tune(k.encode(), v))
+        s = pkg.Solver(ctx, n, nnz, data, indptr, indices, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=dtype)
+        solvers.append((cfg, kv, s))
+    res = {cfg: {"spmv": [], "iter": []} for cfg, _, _ in solvers}
+    ref = None
+    for rnd in range(args.rounds):
+        for cfg, kv, s in solvers:
+            for k, v in kv.items():
+                lib.cgamd_tune(k.encode(), v)       # variant/nt are read at launch time
+            for _ in range(3):
+                s.spmv(xs, ys, fused_dot=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ext)
+            for _ in range(args.reps):
+                s.spmv(xs, ys, fused_dot=True)
+            e1.record(ext)
+            e1.synchronize()
+            res[cfg]["spmv"].append(e0.elapsed_time(e1) / args.reps * 1e3)
+            if rnd == 0 and not (kv.get("spmv_dbg", 0) & 3):
+                y = ys.clone()
+                if ref is None:
+                    ref = y
+                else:
+                    err = (y - ref).abs().max().item() / ref.abs().max().item()
+                    assert err < 1e-12, (cfg, err)
+            if kv.get("spmv_dbg", 0) & 3:
+                res[cfg]["iter"].append(1.0)
+                continue
+            # whole CG iterations (graph is captured with the tuning active at first iterate())
+            s.set_rhs(b, None, on_device=True)
+            s.iterate(10)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            s.iterate(args.iters)
+            ctx.synchronize()
+            res[cfg]["iter"].append((time.perf_counter() - t0) / args.iters * 1e6)
+    sb = solvers[0][2].spmv_bytes
+    ib = solvers[0][2].iter_bytes(False)
+    print(f"grid {args.grid} {args.dtype}: n={n} nnz={nnz} spmv_bytes={sb} iter_bytes(14NV)={ib}")
+    for cfg, _, _ in solvers:
+        sp, it = np.array(res[cfg]["spmv"]), np.array(res[cfg]["iter"])
+        print(f"{cfg:45s} spmv us med {np.median(sp):8.1f} min {sp.min():8.1f}  ({sb / np.median(sp) / 1e3:7.1f} GB/s, "
+              f"{sb / np.median(sp) / 1e3 / 80:5.1f}% of 8TB/s) | iter us med {np.median(it):8.1f} min {it.min():8.1f} "
+              f"({1e6 / np.median(it):7.1f} it/s, {ib / np.median(it) / 1e3 / 80:5.1f}%)")
+
+
+if __name__ == "__main__":
+    main()
