@@ -31,9 +31,8 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmv_nt") g_tune.spmv_nt = value;
     else if (k == "spmv_grid") g_tune.spmv_grid = value;
     else if (k == "vec_grid") g_tune.vec_grid = value;
-    else if (k == "spmv_dbg") g_tune.spmv_dbg = value;
-    else if (k == "spmv_map") g_tune.spmv_map = value;
     else if (k == "spmv_far") g_tune.spmv_far = value;
+    else if (k == "spmv_unroll") g_tune.spmv_unroll = value;
     else return fail(CGAMD_ERR_INVALID, "tune: unknown key " + k);
     return CGAMD_OK;
 }

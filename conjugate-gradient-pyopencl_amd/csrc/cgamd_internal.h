@@ -37,23 +37,21 @@ struct SpmvPlan {
     int max_span = 0;    // largest 4-aligned nnz span of a kBlock-row slice (0 = unknown -> generic kernel)
     int kind = 0;        // kernel chosen by finalize_spmv_plan (0 generic ... 5 row-block)
     int n_partials = 0;  // fused-dot partials per RHS written by that kernel
-    int far_blocks = 1;  // schedule interleave stride (median far off-diagonal distance in row blocks; 1 = none)
 };
 SpmvPlan make_spmv_plan(int n);
-// fills plan->max_span / far_blocks from the matrix structure; synchronises `st`; scratch_dev: >= 4 bytes
+// fills plan->max_span from the matrix structure; synchronises `st`; scratch_dev: >= 4 bytes
 int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan);
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, const void *vals, const int *cols);
 constexpr int kMaxSliceBytes = 64 * 1024;   // variant 5: largest LDS slice accepted (else the generic chunked kernel runs)
 
 // run-time tuning knobs (cgamd_tune); defaults are the shipped configuration
 struct Tuning {
-    int spmv_far = -1;      // -1 = plan's stride, >= 0 overrides (1 = no interleave)
-    int spmv_variant = 5;   // 0 generic CSR-stream, 1/2 pipelined product staging, 3/4 matrix-through-LDS row walk (unroll 8/4)
+    int spmv_variant = 5;   // 5 = row-block kernel (matrix through LDS, one row block per work-group), 0 = generic chunked
     int spmv_nt = 1;        // non-temporal matrix loads
-    int spmv_grid = 0;      // 0 = auto (<= kMaxGrid)
-    int vec_grid = 0;       // 0 = auto
-    int spmv_map = 0;       // 0 contiguous row-block run per work-group, 1 block-cyclic inside each XCD
-    int spmv_dbg = 0;       // experiments: 1 skip x gather, 2 skip y store (results are then wrong by design)
+    int spmv_unroll = 8;    // row walk: LDS reads + gathers in flight per lane (4 or 8)
+    int spmv_far = 1;       // row-block schedule interleave stride (1 = none)
+    int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)
+    int vec_grid = 0;       // vector kernels: 0 = auto
 };
 extern Tuning g_tune;
 int vec_grid(long long n_elems_per_rhs, int dtype);

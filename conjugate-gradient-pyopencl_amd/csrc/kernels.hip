@@ -73,10 +73,8 @@ template <typename T> struct SpmvArgs {
     const T *dvec;                  // fused dot: sum dvec[row] * y[row]
     typename VT<T>::acc *partials;  // [nrhs][grid]
     int row_blocks;
-    int cap;   // variant 5: LDS slice capacity in entries (multiple of 4)
-    int far;   // variant 5: interleave stride in row blocks (far off-diagonal distance)
-    int map;   // row-block schedule of the fast kernels (0 contiguous per work-group, 1 XCD block-cyclic)
-    int dbg;   // experiments only (cgamd_tune spmv_dbg): 1 = skip the x gather, 2 = skip the y store
+    int cap;   // row-block kernel: LDS slice capacity in entries (multiple of 4)
+    int far;   // row-block kernel: schedule interleave stride in row blocks (1 = none)
 };
 
 template <typename T, int BLOCK, int QPT, bool VEC, bool FUSE_DOT>
@@ -186,215 +184,25 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs<T> a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Fast path (nRHS == 1, every BLOCK-row slice fits one chunk -- true for all stencil / FE matrices of the
-// reference): software-pipelined.  While the work-group gathers, multiplies and reduces row block i, the
-// 16-byte matrix loads of row block i+1 are already in flight into a second register set, so the HBM
-// stream of aValues/aCols never drains across the LDS phase.  With DBUF the products ping-pong between two
-// LDS buffers and one barrier per row block suffices.
-// -------------------------------------------------------------------------------------------------
-template <typename T, int BLOCK, int QPT, bool NT>
-CG_DEV void load_quads(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
-                       T (&v)[QPT][4], int (&c)[QPT][4]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int u = 0; u < QPT; ++u) {
-        const long long q = (long long)cfirst + 4 * (t + u * BLOCK);
-        if (q < p1) {
-            if (q + 4 <= nnz) {
-                if (NT) {
-                    ld4_nt<T>(vals + q, v[u]);
-                    const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(cols + q));
-                    c[u][0] = cc.x; c[u][1] = cc.y; c[u][2] = cc.z; c[u][3] = cc.w;
-                } else {
-                    constexpr int NV = sizeof(T) * 4 / 16;
-                    union { u32x4 raw[NV]; T w[4]; } uu;
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) uu.raw[i] = reinterpret_cast<const u32x4 *>(vals + q)[i];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[u][k] = uu.w[k];
-                    const i32x4 cc = *reinterpret_cast<const i32x4 *>(cols + q);
-                    c[u][0] = cc.x; c[u][1] = cc.y; c[u][2] = cc.z; c[u][3] = cc.w;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool ok = q + k < nnz;
-                    v[u][k] = ok ? vals[q + k] : vzero<T>();
-                    c[u][k] = ok ? cols[q + k] : 0;
-                }
-            }
-        }
-    }
-}
-
-template <typename T, int BLOCK, int QPT, bool DBUF, bool NT, bool FUSE_DOT>
-__global__ __launch_bounds__(BLOCK) void spmv_pipe_kernel(SpmvArgs<T> a) {
-    using A = typename VT<T>::acc;
-    constexpr int CHUNK = 4 * QPT * BLOCK;
-    __shared__ T prod[DBUF ? 2 : 1][CHUNK];
-    __shared__ A red[BLOCK / kWave];
-
-    const int t = threadIdx.x;
-    const int G = gridDim.x;
-    const int L = xcd_remap(blockIdx.x, G);
-    const int rb_begin = (int)((long long)L * a.row_blocks / G);
-    const int rb_end = (int)((long long)(L + 1) * a.row_blocks / G);
-    A dot1 = vzero<A>();
-    if (rb_begin < rb_end) {
-        T v[QPT][4], vn[QPT][4];
-        int c[QPT][4], cn[QPT][4];
-        int p0 = a.ptr[rb_begin * BLOCK];
-        int p1 = a.ptr[min(rb_begin * BLOCK + BLOCK, a.n)];
-        load_quads<T, BLOCK, QPT, NT>(a.vals, a.cols, a.nnz, p0 & ~3, p1, v, c);
-        int buf = 0;
-        for (int rb = rb_begin; rb < rb_end; ++rb) {
-            const int r0 = rb * BLOCK;
-            const int row = r0 + t;
-            const int cfirst = p0 & ~3;
-            int s = 0, e = 0;
-            if (row < a.n) { s = a.ptr[row]; e = a.ptr[row + 1]; }
-            // prefetch the next row block's matrix slice
-            int p1n = p1;
-            if (rb + 1 < rb_end) {
-                p1n = a.ptr[min(r0 + 2 * BLOCK, a.n)];
-                load_quads<T, BLOCK, QPT, NT>(a.vals, a.cols, a.nnz, p1 & ~3, p1n, vn, cn);
-            }
-            T *pb = prod[DBUF ? buf : 0];
-#pragma unroll
-            for (int u = 0; u < QPT; ++u) {
-                const long long q = (long long)cfirst + 4 * (t + u * BLOCK);
-                if (q < p1) {
-                    T pr[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) pr[k] = vmul(v[u][k], a.x[c[u][k]]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) pb[4 * (t + u * BLOCK) + k] = pr[k];
-                }
-            }
-            __syncthreads();
-            T sum = vzero<T>();
-            for (int k = s - cfirst; k < e - cfirst; ++k) sum = vadd(sum, pb[k]);
-            if (row < a.n) {
-                a.y[row] = sum;
-                if (FUSE_DOT) dot1 = vadd(dot1, to_acc(vmul(a.dvec[row], sum)));
-            }
-            if (!DBUF) __syncthreads();
-            buf ^= 1;
-            p0 = p1; p1 = p1n;
-#pragma unroll
-            for (int u = 0; u < QPT; ++u)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { v[u][k] = vn[u][k]; c[u][k] = cn[u][k]; }
-        }
-    }
-    if (FUSE_DOT) {
-        const A tot = block_sum<BLOCK>(dot1, red);
-        if (t == 0) a.partials[L] = tot;
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Fast path, "matrix through LDS, one lane per row" (variant 3).  The slice of aValues/aCols belonging to
-// BLOCK consecutive rows is streamed from HBM with 16 B coalesced (non-temporal) loads and parked RAW in
-// LDS; after the barrier lane t walks row t out of LDS.  The x gather of step k is then issued by 64 lanes
-// that sit in 64 consecutive rows: for stencil / FE matrices (all the reference feeds this path, SURVEY
-// App. B) their k-th columns are consecutive, so one wave-level gather touches ~4 cache lines instead of
-// the ~24 a nnz-per-lane mapping touches -- the L1->L2 request rate, not HBM, was what bounded the
-// nnz-per-lane kernels at 4.4-4.6 TB/s.  The next slice is prefetched into registers during the row walk.
-// -------------------------------------------------------------------------------------------------
-template <typename T, int BLOCK, int QPT, bool NT, bool FUSE_DOT, int UNROLL>
-__global__ __launch_bounds__(BLOCK) void spmv_rowlds_kernel(SpmvArgs<T> a) {
-    using A = typename VT<T>::acc;
-    constexpr int CHUNK = 4 * QPT * BLOCK;
-    __shared__ __attribute__((aligned(16))) T sv[CHUNK];
-    __shared__ __attribute__((aligned(16))) int sc[CHUNK];
-    __shared__ A red[BLOCK / kWave];
-
-    const int t = threadIdx.x;
-    const int G = gridDim.x;
-    const int L = xcd_remap(blockIdx.x, G);
-    // Row-block schedule.  map 0: work-group L owns one contiguous run of row blocks.  map 1: the
-    // work-groups of one XCD (G/8 consecutive logical ids) sweep that XCD's row range together, block-
-    // cyclically, so that at any instant they cover one contiguous window of G/8 row blocks and the x
-    // entries shared through the stencil's far diagonals are reused while still in that XCD's L2.
-    int rb_begin, rb_end, rb_step;
-    if (a.map == 1 && (G & 7) == 0) {
-        const int per = G >> 3, xcd = L / per, w = L % per;
-        const int xb = (int)((long long)xcd * a.row_blocks / 8), xe = (int)((long long)(xcd + 1) * a.row_blocks / 8);
-        rb_begin = xb + w; rb_end = xe; rb_step = per;
-    } else {
-        rb_begin = (int)((long long)L * a.row_blocks / G);
-        rb_end = (int)((long long)(L + 1) * a.row_blocks / G);
-        rb_step = 1;
-    }
-    A dot1 = vzero<A>();
-    if (rb_begin < rb_end) {
-        T v[QPT][4];
-        int c[QPT][4];
-        int p0 = a.ptr[rb_begin * BLOCK];
-        int p1 = a.ptr[min(rb_begin * BLOCK + BLOCK, a.n)];
-        load_quads<T, BLOCK, QPT, NT>(a.vals, a.cols, a.nnz, p0 & ~3, p1, v, c);
-        for (int rb = rb_begin; rb < rb_end; rb += rb_step) {
-            const int r0 = rb * BLOCK;
-            const int row = r0 + t;
-            const int cfirst = p0 & ~3;
-            int s = 0, e = 0;
-            if (row < a.n) { s = a.ptr[row] - cfirst; e = a.ptr[row + 1] - cfirst; }
-            // park the raw slice in LDS (16 B stores)
-#pragma unroll
-            for (int u = 0; u < QPT; ++u) {
-                const long long q = (long long)cfirst + 4 * (t + u * BLOCK);
-                if (q < p1) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { sv[4 * (t + u * BLOCK) + k] = v[u][k]; sc[4 * (t + u * BLOCK) + k] = c[u][k]; }
-                }
-            }
-            // prefetch the next slice while this one is consumed
-            int p0n = p1, p1n = p1;
-            if (rb + rb_step < rb_end) {
-                const int rn = (rb + rb_step) * BLOCK;
-                p0n = a.ptr[rn];
-                p1n = a.ptr[min(rn + BLOCK, a.n)];
-                load_quads<T, BLOCK, QPT, NT>(a.vals, a.cols, a.nnz, p0n & ~3, p1n, v, c);
-            }
-            __syncthreads();
-            T sum = vzero<T>();
-            for (int k = s; k < e; k += UNROLL) {
-                T xv[UNROLL], av[UNROLL];
-#pragma unroll
-                for (int j = 0; j < UNROLL; ++j)
-                    if (k + j < e) { av[j] = sv[k + j]; xv[j] = (a.dbg & 1) ? av[j] : a.x[sc[k + j]]; }
-#pragma unroll
-                for (int j = 0; j < UNROLL; ++j)
-                    if (k + j < e) sum = vfma(av[j], xv[j], sum);
-            }
-            if (row < a.n) {
-                if (!(a.dbg & 2)) {
-                    if (a.dbg & 4) st_nt(a.y + row, sum);
-                    else a.y[row] = sum;
-                }
-                if (FUSE_DOT) dot1 = vadd(dot1, to_acc(vmul((a.dbg & 1) ? sum : a.dvec[row], sum)));
-            }
-            __syncthreads();
-            p0 = p0n; p1 = p1n;
-        }
-    }
-    if (FUSE_DOT) {
-        const A tot = block_sum<BLOCK>(dot1, red);
-        if (t == 0) a.partials[L] = tot;
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Fast path, variant 5 (default): ONE row block per work-group, no persistence -- the hardware dispatcher
-// keeps every CU stocked and balances the load; measured 12-15 % faster than the persistent forms.
-// Schedule: work-group b runs on XCD b%8 (round-robin dispatch) and is the (b/8)-th block of that XCD.
-// Each XCD owns one contiguous eighth of the row blocks and sweeps it in an order interleaved with
-// stride S = `far` row blocks (the distance of the matrix's far off-diagonals, sampled at plan time):
-// consecutive dispatches take blocks y, y+S, y+2S, ... so the blocks that share x entries through the
-// far diagonals (the z-neighbours of a 3-D stencil) are resident at the same time and hit the XCD's L2,
-// instead of re-fetching x once per far diagonal (measured: 3x x traffic without the interleave).
-// LDS: raw slice (values + columns) sized at launch from the plan's largest slice.
+// Fast path (nRHS == 1, slice of BLOCK rows fits LDS; all stencil / FE matrices of the reference):
+// "matrix through LDS, one lane per row", ONE row block per work-group, no persistence.
+//   * The slice of aValues/aCols that belongs to BLOCK consecutive rows is contiguous; it is streamed with
+//     16 B per lane coalesced non-temporal loads (start rounded down to a multiple of 4 entries so every
+//     load is aligned) and parked RAW in LDS.
+//   * After one barrier lane t walks row t out of LDS (up to UNROLL entries in flight).  The x gather of
+//     step k is issued by 64 lanes sitting in 64 consecutive rows: for banded matrices their k-th columns are
+//     consecutive, so one wave-level gather touches ~4 cache lines (a nnz-per-lane mapping touches ~24).
+//   * y is written coalesced; the fused d.q partial is one value per row block (fixed order later).
+//   * Schedule: work-group b runs on XCD b%8 (round-robin dispatch) as the (b/8)-th block of that XCD; each
+//     XCD owns one contiguous eighth of the row blocks, so the x window it gathers from stays in its own
+//     L2.  Measured on the N=10M 7-point system: HBM reads 982 MB against 957 MB algorithmic (x fetched
+//     ~once), whereas persistent work-groups re-fetched x once per far diagonal (1128 MB) and ran
+//     12-15 % slower; software-pipelined persistent variants were no faster either
+//     (profiles/r1_experiments/ab*.log, pmc_*_summary.txt).
+//   * Optional interleave stride `far` (cgamd_tune "spmv_far", default 1 = off): consecutive dispatches of
+//     an XCD take blocks y, y+far, y+2far, ... (z-neighbours of a 3-D stencil resident together).  It did
+//     not pay at N=10M (x already stays in L2/Infinity Cache) and is kept only as a tuning knob.
+// LDS is sized at launch from the plan's largest slice (values + columns).
 // -------------------------------------------------------------------------------------------------
 template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL>
 __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
@@ -474,17 +282,6 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
         const A tot = block_sum<BLOCK>(dot1, red);
         if (t == 0) a.partials[rb] = tot;
     }
-}
-
-// plan-time sample of the far off-diagonal distance: out[k] = max_j |col_j - row| for every `step`-th row
-__global__ void spmv_far_sample_kernel(int n, const int *__restrict__ ptr, const int *__restrict__ cols, int step,
-                                       int nsamples, int *out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nsamples) return;
-    const int row = min((int)((long long)k * step), n - 1);
-    int far = 0;
-    for (int j = ptr[row]; j < ptr[row + 1]; ++j) far = max(far, abs(cols[j] - row));
-    out[k] = far;
 }
 
 // largest (4-aligned) non-zero span of any BLOCK-row slice: decides whether the fast path applies
@@ -809,8 +606,6 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     a.dvec = static_cast<const T *>(dvec);
     a.partials = static_cast<typename VT<T>::acc *>(partials);
     a.row_blocks = plan.row_blocks;
-    a.dbg = g_tune.spmv_dbg;
-    a.map = g_tune.spmv_map;
     const bool vec = aligned16(vals) && aligned16(cols);
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
@@ -818,7 +613,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     const int variant = (vec && nrhs == 1) ? plan.kind : 0;
     if (variant == 5) {
         a.cap = (plan.max_span + 3) & ~3;
-        a.far = g_tune.spmv_far >= 0 ? g_tune.spmv_far : plan.far_blocks;
+        a.far = g_tune.spmv_far > 0 ? g_tune.spmv_far : 1;
         const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
         int per_xcd = 0;
         for (int x = 0; x < 8; ++x) {
@@ -827,35 +622,15 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         }
         dim3 g5(per_xcd * 8);
         const bool nt = g_tune.spmv_nt != 0;
-#define CG_RB(NT)                                                                                                \
+#define CG_RB(NT, UNR)                                                                                           \
     do {                                                                                                         \
-        if (fuse) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, true, 8>), g5, block, lds, st, a);     \
-        else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, 8>), g5, block, lds, st, a);         \
+        if (fuse) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, true, UNR>), g5, block, lds, st, a);   \
+        else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, UNR>), g5, block, lds, st, a);       \
     } while (0)
-        if (nt) CG_RB(true); else CG_RB(false);
+        if (g_tune.spmv_unroll == 4) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
+        else { if (nt) CG_RB(true, 8); else CG_RB(false, 8); }
 #undef CG_RB
         return check_launch("spmv_rowblock");
-    }
-    if (variant != 0) {
-        // fast path: software-pipelined single-chunk kernel
-#define CG_PIPE(DBUF, NT)                                                                                        \
-    do {                                                                                                         \
-        if (fuse) hipLaunchKernelGGL((spmv_pipe_kernel<T, kBlock, kQuadsPerThread, DBUF, NT, true>), grid, block, 0, st, a);  \
-        else hipLaunchKernelGGL((spmv_pipe_kernel<T, kBlock, kQuadsPerThread, DBUF, NT, false>), grid, block, 0, st, a);      \
-    } while (0)
-#define CG_ROWLDS(NT, UNR)                                                                                       \
-    do {                                                                                                         \
-        if (fuse) hipLaunchKernelGGL((spmv_rowlds_kernel<T, kBlock, kQuadsPerThread, NT, true, UNR>), grid, block, 0, st, a);  \
-        else hipLaunchKernelGGL((spmv_rowlds_kernel<T, kBlock, kQuadsPerThread, NT, false, UNR>), grid, block, 0, st, a);      \
-    } while (0)
-        const bool nt = g_tune.spmv_nt != 0;
-        if (variant == 1) { if (nt) CG_PIPE(false, true); else CG_PIPE(false, false); }
-        else if (variant == 2) { if (nt) CG_PIPE(true, true); else CG_PIPE(true, false); }
-        else if (variant == 4) { if (nt) CG_ROWLDS(true, 4); else CG_ROWLDS(false, 4); }
-        else { if (nt) CG_ROWLDS(true, 8); else CG_ROWLDS(false, 8); }
-#undef CG_PIPE
-#undef CG_ROWLDS
-        return check_launch("spmv_fast");
     }
     if (vec) {
         if (fuse) hipLaunchKernelGGL((spmv_stream_kernel<T, kBlock, kQuadsPerThread, true, true>), grid, block, dyn, st, a);
@@ -876,39 +651,18 @@ int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scrat
     hipLaunchKernelGGL((spmv_span_kernel<kBlock>), dim3(g), dim3(256), 0, st, n, ptr_dev, row_blocks, scratch_dev);
     if (int rc = check_launch("spmv_span")) return rc;
     CG_HIP(hipMemcpyAsync(&plan->max_span, scratch_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-    // (2) median far off-diagonal distance over <= 1024 sampled rows -> interleave stride of the schedule
-    constexpr int kSamples = 1024;
-    const int nsamples = n < kSamples ? n : kSamples;
-    const int step = n / nsamples > 0 ? n / nsamples : 1;
-    int *samples_dev = nullptr;
-    CG_HIP(hipMalloc(&samples_dev, sizeof(int) * kSamples));
-    hipLaunchKernelGGL(spmv_far_sample_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, st, n, ptr_dev, cols_dev, step,
-                       nsamples, samples_dev);
-    int rc = check_launch("spmv_far_sample");
-    int host[kSamples];
-    hipError_t e = rc ? hipSuccess : hipMemcpyAsync(host, samples_dev, sizeof(int) * nsamples, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(samples_dev);
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("spmv plan: ") + hipGetErrorString(e));
-    std::nth_element(host, host + nsamples / 2, host + nsamples);
-    const long long far_rows = host[nsamples / 2];
-    long long S = (far_rows + kBlock / 2) / kBlock;   // in row blocks
-    // interleaving only pays when the far diagonals are further apart than one XCD's resident window
-    // (~200 row blocks) can bridge, and when an XCD's share holds at least a few strides
-    if (S < 32 || S * 4 > row_blocks / 8) S = 1;
-    plan->far_blocks = (int)S;
+    CG_HIP(hipStreamSynchronize(st));
+    (void)cols_dev;
     return CGAMD_OK;
 }
 
 // decides once which SpMV kernel a solver uses (and therefore how many dot partials it produces)
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, const void *vals, const int *cols) {
-    constexpr int CHUNK = 4 * kQuadsPerThread * kBlock;
     int kind = g_tune.spmv_variant;
     const bool vec = aligned16(vals) && aligned16(cols);
     if (!vec || nrhs != 1 || plan->max_span <= 0) kind = 0;
     if (kind == 5 && (size_t)plan->max_span * (dtype_size(dtype) + 4) > (size_t)kMaxSliceBytes) kind = 0;
-    if (kind >= 1 && kind <= 4 && plan->max_span > CHUNK) kind = 0;
+    if (kind != 5) kind = 0;
     plan->kind = kind;
     plan->n_partials = kind == 5 ? plan->row_blocks : plan->grid;
 }

@@ -50,9 +50,10 @@ const char *cgamd_last_error(void);
 int cgamd_version(void);
 size_t cgamd_dtype_size(int dtype);
 
-/* run-time tuning knob (A/B experiments and profiling): keys "spmv_variant" (0 generic CSR-stream, 1 pipelined,
- * 2 pipelined + LDS ping-pong = default), "spmv_nt" (non-temporal matrix loads, default 1), "spmv_grid",
- * "vec_grid" (0 = auto).  Affects solvers created afterwards (grids) / launches issued afterwards (variants). */
+/* run-time tuning knobs (A/B experiments and profiling): "spmv_variant" (5 = row-block kernel, default;
+ * 0 = generic chunked kernel), "spmv_nt" (non-temporal matrix loads, default 1), "spmv_far" (row-block
+ * schedule interleave stride, default 1), "spmv_grid" / "vec_grid" (0 = auto).  Read when a solver is created
+ * (variant, grids) or at launch (nt, far). */
 int cgamd_tune(const char *key, int value);
 
 /* ---- devices / context (reference cl.py:16-31) -------------------------- */

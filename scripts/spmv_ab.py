@@ -40,7 +40,7 @@ def main():
     ys = torch.empty(n, dtype=tdt, device=dev)
     torch.cuda.synchronize()
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-    defaults = {"spmv_variant": 5, "spmv_nt": 1, "spmv_grid": 0, "vec_grid": 0, "spmv_dbg": 0, "spmv_map": 0, "spmv_far": -1}
+    defaults = {"spmv_variant": 5, "spmv_nt": 1, "spmv_grid": 0, "vec_grid": 0, "spmv_far": 1, "spmv_unroll": 8}
     solvers = []
     for cfg in args.cfgs:
         kv = dict(defaults)
