@@ -34,6 +34,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7 / libhsa-runtime64 / librccl.so.1.  Two HIP runtimes in one process do
+    # not coexist ("No HIP GPUs are available" in whichever comes second), so when torch is installed it is
+    # imported FIRST and libcgamd.so then binds to the copies already loaded (same SONAMEs).  Without torch
+    # (plain ctypes hosts, the C CLI) the library uses /opt/rocm/lib through its RPATH.
+    if os.environ.get("CGAMD_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "

@@ -1,0 +1,328 @@
+"""Row-partitioned multi-GPU CG: one process per GPU, torch.distributed for the plumbing, RCCL over xGMI
+inside the C loop (csrc/dist.cpp).
+
+The reference's only multi-GPU mode replicates the matrix on every device and splits the right-hand
+sides over devices with no communication (p_h-PY_C-CL-multi-GPU.py:2123-2181, cl.py:203-360); that mode
+is `cl.conjugate_gradient_multi_gpu`.  BASELINE.json's north star asks for the MATRIX to be row-
+partitioned across the 8 GPUs with an all-reduce for the two dot products of every iteration and a
+boundary exchange for A*d; this module is that (new design, no reference counterpart):
+
+  1. `row_ranges`           contiguous row blocks [n*g//G, n*(g+1)//G)
+  2. `build_halo_plan`      from the GLOBAL column indices of a rank's rows: which entries of d it needs
+                            from which rank (halo), which of its own rows the others need (send lists),
+                            and the columns renumbered to [0,n_local) U [n_local, n_local+n_halo)
+  3. `DistSolver`           the C loop: pack -> ncclSend/ncclRecv -> SpMV(+d.q) -> ncclAllReduce ->
+                            x/r update(+r.r) -> ncclAllReduce -> d update; no host sync inside
+  4. `cg_loop`              the same recurrence written against two small interfaces (local ops, comm);
+                            used by the CPU/gloo tests with the oracle's kernels, and usable on GPUs as a
+                            slow cross-check of the C loop (per-iteration torch.distributed calls).
+
+Everything in steps 1-2 is backend agnostic (CPU tensors + gloo, or CUDA tensors + nccl).
+"""
+import ctypes
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def row_ranges(n, world):
+    """[(begin, end)] of the contiguous row block of every rank."""
+    return [(n * g // world, n * (g + 1) // world) for g in range(world)]
+
+
+@dataclass
+class HaloPlan:
+    rank: int
+    world: int
+    row_begin: int
+    row_end: int
+    n_local: int
+    n_halo: int
+    cols_local: object                 # torch int32, columns renumbered to local U halo
+    halo_global: object                # torch int64 [n_halo], sorted global ids of the halo entries
+    peers: List[int] = field(default_factory=list)         # ranks exchanged with, ascending
+    send_counts: List[int] = field(default_factory=list)   # entries sent to each peer
+    recv_counts: List[int] = field(default_factory=list)   # entries received from each peer (halo order)
+    send_index: object = None          # torch int32: concatenated LOCAL row ids to send, peer by peer
+
+
+def build_halo_plan(cols_global, ranges, rank, group=None):
+    """Partition plan of one rank.  cols_global: 1-D torch integer tensor with the GLOBAL column index
+    of every stored entry of this rank's rows (CPU or CUDA).  Collective over `group` when world > 1."""
+    import torch
+    import torch.distributed as dist
+    world = len(ranges)
+    rb, re = ranges[rank]
+    n_local = re - rb
+    c = cols_global.to(torch.int64)
+    off = (c < rb) | (c >= re)
+    halo_global = torch.unique(c[off])                      # sorted
+    starts = torch.tensor([r[0] for r in ranges] + [ranges[-1][1]], dtype=torch.int64, device=c.device)
+    owner = torch.searchsorted(starts, halo_global, right=True) - 1
+    # columns -> local numbering
+    cols_local = torch.where(off, n_local + torch.searchsorted(halo_global, c), c - rb).to(torch.int32)
+    need = {}                                               # owner rank -> global ids wanted from it (sorted)
+    if halo_global.numel():
+        owners, counts = torch.unique_consecutive(owner, return_counts=True)
+        pos = 0
+        for o, k in zip(owners.tolist(), counts.tolist()):
+            need[int(o)] = halo_global[pos:pos + k].cpu()
+            pos += k
+    # tell every owner which of its rows we need (setup only: object all-gather keeps this backend agnostic)
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, need, group=group)
+    else:
+        gathered = [need]
+    wanted_from_me = {src: req[rank] for src, req in enumerate(gathered) if src != rank and rank in req}
+    peers = sorted(set(need) | set(wanted_from_me))
+    send_counts, recv_counts, send_lists = [], [], []
+    for p in peers:
+        s = wanted_from_me.get(p)
+        send_counts.append(0 if s is None else int(s.numel()))
+        if s is not None:
+            send_lists.append((s - rb).to(torch.int32))
+        recv_counts.append(int(need[p].numel()) if p in need else 0)
+    send_index = (torch.cat(send_lists) if send_lists else torch.zeros(0, dtype=torch.int32)).to(c.device)
+    return HaloPlan(rank, world, rb, re, n_local, int(halo_global.numel()), cols_local, halo_global, peers,
+                    send_counts, recv_counts, send_index)
+
+
+# ---------------------------------------------------------------------------------------------------
+# generic distributed recurrence (reference clcg.c:250-430 with the two extra communication steps)
+# ---------------------------------------------------------------------------------------------------
+class TorchComm:
+    """halo exchange + scalar all-reduce over torch.distributed (gloo on CPU, nccl = RCCL on GPUs)."""
+
+    def __init__(self, plan, group=None):
+        self.plan, self.group = plan, group
+
+    def exchange(self, v_ext):
+        """fill v_ext[n_local:] with the neighbours' entries; v_ext is a torch tensor"""
+        import torch
+        import torch.distributed as dist
+        p = self.plan
+        if not p.peers:
+            return
+        ops, so, ro = [], 0, p.n_local
+        sendbuf = v_ext[p.send_index.long()]
+        for peer, sc, rc in zip(p.peers, p.send_counts, p.recv_counts):
+            if sc:
+                ops.append(dist.P2POp(dist.isend, sendbuf[so:so + sc].contiguous(), peer, group=self.group))
+            if rc:
+                ops.append(dist.P2POp(dist.irecv, v_ext[ro:ro + rc], peer, group=self.group))
+            so += sc
+            ro += rc
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def allreduce(self, t):
+        import torch.distributed as dist
+        if self.plan.world > 1:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+
+def cg_loop(ops, comm, plan, b_local, x0_local, n_iterations):
+    """Distributed fixed-iteration (CO)CG on torch tensors.
+
+    ops: local kernels on this rank's rows --
+         ops.spmv(v_ext) -> A_local @ v_ext, ops.dot(a, b) -> 0-d tensor (unconjugated, local part).
+    Returns (x_local, history[n_iterations+1]) with history[k] = global r_k . r_k.
+    """
+    import torch
+    n = plan.n_local
+    x = x0_local.clone()
+    d_ext = torch.zeros(n + plan.n_halo, dtype=b_local.dtype, device=b_local.device)
+    d_ext[:n] = x
+    comm.exchange(d_ext)
+    r = b_local - ops.spmv(d_ext)                                   # clcg.c:255-260
+    d_ext[:n] = r                                                   # :264
+    delta_new = comm.allreduce(ops.dot(r, r).reshape(1).clone())    # :268-279 + all-reduce
+    hist = [delta_new.clone()]
+    for _ in range(n_iterations):                                   # :297
+        comm.exchange(d_ext)                                        # boundary exchange of d
+        q = ops.spmv(d_ext)                                         # :299-305
+        dq = comm.allreduce(ops.dot(d_ext[:n], q).reshape(1).clone())   # :309-324 + all-reduce
+        alpha = delta_new / dq                                      # :326-327
+        x = x + alpha * d_ext[:n]                                   # :338-342
+        r = r - alpha * q                                           # :345-349
+        delta_old = delta_new
+        delta_new = comm.allreduce(ops.dot(r, r).reshape(1).clone())    # :369-387 + all-reduce
+        beta = delta_new / delta_old                                # :389-391
+        d_ext[:n] = beta * d_ext[:n] + r                            # :415
+        hist.append(delta_new.clone())
+    return x, torch.cat(hist)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the C loop
+# ---------------------------------------------------------------------------------------------------
+def broadcast_unique_id(rank, group=None, device=None):
+    """rank 0 creates the RCCL unique id through the C ABI; torch.distributed carries the 128 bytes."""
+    import torch
+    import torch.distributed as dist
+    lib = _lib.load()
+    buf = np.zeros(128, dtype=np.uint8)
+    if rank == 0:
+        check(lib.cgamd_comm_unique_id(ptr(buf)))
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=0, group=group)
+    return t.cpu().numpy().copy()
+
+
+class DistSolver:
+    """Row-partitioned CG on this rank's GPU (csrc/dist.cpp).  All arrays are torch CUDA tensors that
+    must outlive the solver; columns are plan.cols_local."""
+
+    def __init__(self, ctx, plan, indptr_local, values, dtype, unique_id=None, flags=0):
+        import torch
+        self.ctx, self.plan, self.dtype = ctx, plan, np.dtype(dtype)
+        self._lib = _lib.load()
+        peers = np.asarray(plan.peers, dtype=np.int32)
+        sc = np.asarray(plan.send_counts, dtype=np.int32)
+        rc = np.asarray(plan.recv_counts, dtype=np.int32)
+        self._keep = (indptr_local, values, plan.cols_local, plan.send_index, peers, sc, rc)
+        if plan.world > 1 and unique_id is None:
+            raise ValueError("unique_id is required when world > 1")
+        idbuf = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)
+        torch.cuda.synchronize()
+        h = ctypes.c_void_p()
+        check(self._lib.cgamd_dist_create(
+            ctx.handle, ptr(idbuf), plan.rank, plan.world, _lib.DTYPE_CODE[self.dtype], plan.n_local, plan.n_halo,
+            int(plan.cols_local.numel()), ptr(values), ptr(indptr_local), ptr(plan.cols_local), len(plan.peers),
+            ptr(peers) if len(peers) else None, ptr(sc) if len(sc) else None, ptr(rc) if len(rc) else None,
+            ptr(plan.send_index) if plan.send_index.numel() else None, int(flags), ctypes.byref(h)))
+        self.handle = h
+        self.iterations = 0
+
+    def set_rhs(self, b_local, x0_local=None):
+        check(self._lib.cgamd_dist_set_rhs(self.handle, ptr(b_local), ptr(x0_local)))
+        self.iterations = 0
+
+    def iterate(self, n):
+        check(self._lib.cgamd_dist_iterate(self.handle, int(n)))
+        self.iterations += int(n)
+
+    def synchronize(self):
+        check(self._lib.cgamd_dist_synchronize(self.handle))
+
+    def x(self, out):
+        check(self._lib.cgamd_dist_get_x(self.handle, ptr(out)))
+        self.synchronize()
+        return out
+
+    def history(self):
+        out = np.empty(self.iterations + 1, dtype=self.dtype)
+        got = self._lib.cgamd_dist_history(self.handle, ptr(out), len(out))
+        if got < 0:
+            check(-got)
+        return out[:got]
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self._lib.cgamd_dist_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipOps:
+    """local kernels for cg_loop on torch CUDA tensors through the C ABI (cross-check of the C loop)."""
+
+    def __init__(self, ctx, plan, indptr_local, values, dtype):
+        from . import cl
+        self.ctx, self.plan, self.dtype = ctx, plan, np.dtype(dtype)
+        self.indptr, self.values = indptr_local, values
+        self._lib = _lib.load()
+        self.kern = cl.load_and_build_kernels(ctx, 1)
+        self.queue = cl.CommandQueue(ctx)
+
+    def spmv(self, v_ext):
+        import torch
+        p = self.plan
+        # the stand-alone op takes a square system of size n_local + n_halo rows; pad the row pointers
+        y = torch.zeros(p.n_local + p.n_halo, dtype=v_ext.dtype, device=v_ext.device)
+        if not hasattr(self, "_ptr_ext"):
+            last = self.indptr[-1:].expand(p.n_halo)
+            self._ptr_ext = torch.cat([self.indptr, last]).contiguous()
+        torch.cuda.synchronize()
+        self.kern["spmv"](self.queue, p.n_local + p.n_halo, self.values, self._ptr_ext, p.cols_local, v_ext, y)
+        self.ctx.synchronize()
+        return y[:p.n_local]
+
+    def dot(self, a, b):
+        import torch
+        res = torch.zeros(1, dtype=a.dtype, device=a.device)
+        a, b = a.contiguous(), b.contiguous()
+        torch.cuda.synchronize()
+        self.kern["vdot"](self.queue, a, b, res, a.numel())
+        self.ctx.synchronize()
+        return res[0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py --gpus N (N > 1): strong scaling of the N=10M system, z-slab row partition
+# ---------------------------------------------------------------------------------------------------
+def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, rank, world):
+    import time
+    n = nx * ny * nz
+    ranges = row_ranges(n, world)
+    rb, re = ranges[rank]
+    indptr, cols_global, data = pkg.generators.laplace3d(ctx, nx, ny, nz, dtype=dtype, row_begin=rb, row_end=re)
+    plan = build_halo_plan(cols_global, ranges, rank)
+    del cols_global
+    uid = broadcast_unique_id(rank, device=dev)
+    flags = _lib.DIST_GRAPH if getattr(args, "dist_graph", False) else 0
+    solver = DistSolver(ctx, plan, indptr, data, dtype, unique_id=uid, flags=flags)
+    tdt = pkg.generators.torch_dtype(dtype)
+    b = torch.full((plan.n_local,), 5.0, dtype=tdt, device=dev)          # main.c:44: b = (r+1)*5, x0 = 0
+    torch.cuda.synchronize()
+    solver.set_rhs(b, None)
+    solver.iterate(args.warmup)
+    solver.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    solver.iterate(args.steps)
+    solver.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    hist = solver.history()
+    nnz_total = pkg.generators.laplace3d_nnz(nx, ny, nz)
+    V = np.dtype(dtype).itemsize
+    iter_bytes = nnz_total * (V + 4) + (n + 1) * 4 + 14 * n * V
+    it_s = args.steps / dt
+    res = {
+        "metric": "CG iterations/sec + SpMV effective HBM GB/s (% of 8 TB/s peak), N=10M CSR",
+        "value": it_s, "unit": "CG iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"3D 7-pt Laplacian {nx}x{ny}x{nz} CSR, N={n}, nnz={nnz_total}, {args.dtype}, 1 RHS, b=5, "
+                               f"x0=0, fixed-iteration CG, rows partitioned in {world} contiguous z-slabs, "
+                               f"halo {plan.n_halo} entries/rank, RCCL send/recv + 2 scalar all-reduces per iteration",
+                   "rows": n, "nnz": nnz_total, "parallelism": f"row-partition x{world}"},
+        "cg_iter_algorithmic_gbs": iter_bytes * it_s / 1e9,
+        "cg_iter_pct_of_aggregate_hbm_peak": 100.0 * iter_bytes * it_s / 1e9 / (8000.0 * world),
+        "residual_check": {"delta_0": float(abs(hist[0])), "delta_last": float(abs(hist[-1])),
+                           "iterations": int(len(hist) - 1)},
+        "roofline": {"bound": "hbm", "kernel": "whole CG iteration (all ranks)", "achieved": iter_bytes * it_s / 1e9,
+                     "peak": 8000.0 * world, "unit": "GB/s", "frac": iter_bytes * it_s / 1e9 / (8000.0 * world),
+                     "traffic": None},
+    }
+    solver.close()
+    return res
