@@ -42,24 +42,45 @@ def parse():
 NP_DTYPE = {"f32": np.float32, "f64": np.float64, "c64": np.complex64, "c128": np.complex128}
 
 
+def host_cores():
+    """cores this process may really use: cgroup quota if any, affinity mask, and at most 16 -- a one-GPU box
+    of the pool owns a 16-core CPU share even though it sees every core of the host."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("CG_BASELINE_THREADS", "16"))))
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r1_pmc_traffic.json, written by scripts/pmc_traffic.py); None when absent."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(nx, ny, nz_full, dtype, budget_s=20.0):
     """The CPU oracle (C restatement of the reference op structure, OpenMP) on a bounded sample:
     the same 7-point system truncated along z so that ~10-30 s of host work are timed."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cg_numpy
     import cg_oracle
-    cores = os.cpu_count() or 1
-    threads = cg_oracle.set_threads(cores)
+    threads = cg_oracle.set_threads(host_cores())
     nz = max(2, min(nz_full, 20))                      # 250x200x20 = 1M rows
     indptr, indices, data = cg_numpy.laplace3d(nx, ny, nz, dtype=dtype)
     n = nx * ny * nz
     b = np.full(n, 5.0, dtype=dtype)                   # main.c:44 convention
     t0 = time.perf_counter()
-    cg_oracle.cg(indptr, indices, data, b, n_iterations=2, mode=cg_oracle.MODE_SEQUENTIAL)
+    cg_oracle.cg(indptr, indices, data, b, n_iterations=2, mode=cg_oracle.MODE_FAST)
     per_it = (time.perf_counter() - t0) / 3.0
     iters = int(max(5, min(400, budget_s / max(per_it, 1e-6))))
     t0 = time.perf_counter()
-    cg_oracle.cg(indptr, indices, data, b, n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
+    cg_oracle.cg(indptr, indices, data, b, n_iterations=iters, mode=cg_oracle.MODE_FAST)
     dt = time.perf_counter() - t0
     it_s_sample = iters / dt
     # iterations/s scale inversely with rows for this bandwidth-bound loop: quote it on the full system
@@ -166,9 +187,9 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
         "cg_iter_algorithmic_gbs": iter_bytes * it_s / 1e9,
         "cg_iter_pct_of_8tbs": 100.0 * iter_bytes * it_s / 1e9 / HBM_PEAK_GBS,
         "residual_check": {"delta_0": float(delta0), "delta_last": float(deltak), "iterations": int(hist.shape[0] - 1)},
-        "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel (CSR SpMV fused with d.q partials)",
+        "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel (CSR SpMV fused with d.q partials)",
                      "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms},
+                     "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms},
     }
     solver.close()
     return res

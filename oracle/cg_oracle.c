@@ -14,7 +14,9 @@
  * OpenCL device; the container has none), so there is no oracle/_ref.
  *
  * Entry points take a dtype code: 0=f32 1=f64 2=c64 3=c128 (interleaved re,im).
- * mode 0 = reference summation order, mode 1 = sequential.
+ * mode bits: 0 = reference summation order everywhere; bit 0 = sequential row sums
+ * in spmv; bit 1 = sequential dot.  3 = everything sequential, 1 = sequential rows + reference-order dot
+ * (deterministic and OpenMP-parallel: the CPU baseline).
  */
 #include <complex.h>
 #include <stdlib.h>

@@ -15,7 +15,8 @@ _LIB = os.path.join(_HERE, "_build", "libcgoracle.so")
 DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1,
           np.dtype(np.complex64): 2, np.dtype(np.complex128): 3}
 MODE_REFERENCE_ORDER = 0   # lane-strided + tree, WG tree + host sum
-MODE_SEQUENTIAL = 1        # left-to-right sums (scipy csr_matvec order)
+MODE_SEQUENTIAL = 3        # left-to-right sums everywhere (scipy csr_matvec order; serial dot)
+MODE_FAST = 1              # sequential row sums + reference-order (work-group tree) dot: parallel, deterministic
 
 
 def build(force=False):

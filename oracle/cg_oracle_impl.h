@@ -32,7 +32,7 @@ static inline T FN(sub)(T a, T b) { return a - b; }
 /* ---- spmv: kernel/real/spmv.cl:5-50, kernel/complex/spmv.cl:7-53 ---------
  * mode 0 (reference order): lane L of WAVE_SIZE=32 sums elements p+L, p+L+32,...
  * left to right (:23-26), then the stride-1,2,4,8,16 adjacent-pair tree (:32-43).
- * mode 1 (sequential): plain left-to-right row sum (scipy csr_matvec order,
+ * mode bit 0 set (sequential): plain left-to-right row sum (scipy csr_matvec order,
  * which is what helmFE_var.py:520 `A.dot(d)` executes). */
 static void FN(spmv)(int size, const T *aValues, const int *aPointers, const int *aCols,
                      const T *x, T *y, int nRHS, int mode) {
@@ -42,7 +42,7 @@ static void FN(spmv)(int size, const T *aValues, const int *aPointers, const int
 #pragma omp parallel for schedule(static)
         for (int row = 0; row < size; row++) {
             const int row_start = aPointers[row], row_end = aPointers[row + 1];
-            if (mode == 1) {
+            if (mode & 1) {
                 T s = FN(mk)(0, 0);
                 for (int j = row_start; j < row_end; j++) s = FN(add)(s, FN(mul)(aValues[j], xr[aCols[j]]));
                 yr[row] = s;
@@ -66,13 +66,13 @@ static void FN(spmv)(int size, const T *aValues, const int *aPointers, const int
 /* ---- vdot: kernel/real/vdot.cl:2-38 + host sum clcg.c:274-279,317-324 ----
  * mode 0: per work-group of WG_SIZE=256 an adjacent-pair tree (:20-29), then the
  * host adds the partials sequentially in work-group order.
- * mode 1: numpy.dot order is implementation defined; use plain sequential sum
+ * mode bit 1 set: numpy.dot order is implementation defined; use plain sequential sum
  * (tests compare with tolerance). */
 static void FN(vdot)(int size, const T *a, const T *b, T *out, int nRHS, int mode) {
     const int workGroups = 1 + (size - 1) / ORACLE_WG_SIZE;          /* clcg.c:124 */
     for (int r = 0; r < nRHS; r++) {
         const T *ar = a + (size_t)r * size, *br = b + (size_t)r * size;
-        if (mode == 1) {
+        if (mode & 2) {
             T s = FN(mk)(0, 0);
             for (int i = 0; i < size; i++) s = FN(add)(s, FN(mul)(ar[i], br[i]));
             out[r] = s;
