@@ -241,6 +241,8 @@ class Solver:
             out = np.empty(self.size * self.n_rhs, dtype=self.dtype)
         on_device = not isinstance(out, np.ndarray)
         check(self._lib.cgamd_solver_get_x(self.handle, ptr(out), int(on_device)))
+        if on_device:
+            self.ctx.synchronize()      # the copy ran on the solver's stream; make it visible to the caller's
         return out
 
     def history(self):

@@ -33,6 +33,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "vec_grid") g_tune.vec_grid = value;
     else if (k == "spmv_far") g_tune.spmv_far = value;
     else if (k == "spmv_unroll") g_tune.spmv_unroll = value;
+    else if (k == "spmm_rb") g_tune.spmm_rb = value;
     else return fail(CGAMD_ERR_INVALID, "tune: unknown key " + k);
     return CGAMD_OK;
 }

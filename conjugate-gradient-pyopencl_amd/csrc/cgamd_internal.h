@@ -49,6 +49,7 @@ struct Tuning {
     int spmv_variant = 5;   // 5 = row-block kernel (matrix through LDS, one row block per work-group), 0 = generic chunked
     int spmv_nt = 1;        // non-temporal matrix loads
     int spmv_unroll = 8;    // row walk: LDS reads + gathers in flight per lane (4 or 8)
+    int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = 8 for 4/8-byte values, 4 for 16-byte)
     int spmv_far = 1;       // row-block schedule interleave stride (1 = none)
     int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)
     int vec_grid = 0;       // vector kernels: 0 = auto

@@ -183,6 +183,70 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs<T> a) {
     }
 }
 
+// 4 consecutive matrix entries (values + columns) starting at the 4-aligned entry q: 16-byte loads.  FULL = the
+// caller knows q + 4 <= nnz; otherwise the guarded scalar path covers the last, partial quad of the matrix.
+template <typename T, bool NT, bool FULL> CG_DEV void load_quad(const T *__restrict__ vals, const int *__restrict__ cols,
+                                                                long long nnz, long long q, T (&v)[4], int (&c)[4]) {
+    if (FULL || q + 4 <= nnz) {
+        if (NT) {
+            ld4_nt<T>(vals + q, v);
+            const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(cols + q));
+            c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+        } else {
+            constexpr int NV = sizeof(T) * 4 / 16;
+            union { u32x4 raw[NV]; T w[4]; } uu;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) uu.raw[k] = reinterpret_cast<const u32x4 *>(vals + q)[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = uu.w[k];
+            const i32x4 cc = *reinterpret_cast<const i32x4 *>(cols + q);
+            c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = q + k < nnz;
+            v[k] = ok ? vals[q + k] : vzero<T>();
+            c[k] = ok ? cols[q + k] : 0;
+        }
+    }
+}
+
+// Park the slice [cfirst, p1) of aValues/aCols raw in LDS.  Every lane issues the loads of TWO quads before it
+// waits for either (a plain loop made hipcc wait for quad 1 before issuing quad 2: one more dependent HBM
+// round trip per work-group, and the work-group's lifetime is a chain of such round trips).
+template <typename T, int BLOCK, bool NT, bool FULL>
+CG_DEV void stage_slice_impl(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
+                             T *sv, int *sc) {
+    const int t = threadIdx.x;
+    for (long long base = cfirst; base < p1; base += 8 * BLOCK) {
+        const long long q0 = base + 4 * t, q1 = q0 + 4 * BLOCK;
+        const bool h0 = q0 < p1, h1 = q1 < p1;
+        T v0[4], v1[4];
+        int c0[4], c1[4];
+        if (h0) load_quad<T, NT, FULL>(vals, cols, nnz, q0, v0, c0);
+        if (h1) load_quad<T, NT, FULL>(vals, cols, nnz, q1, v1, c1);
+        if (h0) {
+            const int o = (int)(q0 - cfirst);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sv[o + k] = v0[k]; sc[o + k] = c0[k]; }
+        }
+        if (h1) {
+            const int o = (int)(q1 - cfirst);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sv[o + k] = v1[k]; sc[o + k] = c1[k]; }
+        }
+    }
+}
+template <typename T, int BLOCK, bool NT>
+CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1, T *sv,
+                        int *sc) {
+    // only the work-group that owns the very end of the matrix can meet a partial quad: block-uniform branch,
+    // so the common path carries no per-lane tail handling (whose control flow made hipcc serialise the loads)
+    if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_impl<T, BLOCK, NT, true>(vals, cols, nnz, cfirst, p1, sv, sc);
+    else stage_slice_impl<T, BLOCK, NT, false>(vals, cols, nnz, cfirst, p1, sv, sc);
+}
+
 // -------------------------------------------------------------------------------------------------
 // Fast path (nRHS == 1, slice of BLOCK rows fits LDS; all stencil / FE matrices of the reference):
 // "matrix through LDS, one lane per row", ONE row block per work-group, no persistence.
@@ -227,51 +291,36 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     }
     const int r0 = rb * BLOCK;
     const int row = r0 + t;
+    // The work-group's lifetime is a chain of dependent memory round trips; keep it at three: {row pointers}
+    // -> {matrix slice} -> {x gather}.  The per-row pointers are loaded here, branch-free (clamped row), together
+    // with the slice bounds, and only consumed after the barrier.
+    const int rclamp = min(row, a.n - 1);
+    const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
-    int s = 0, e = 0;
-    if (row < a.n) { s = a.ptr[row] - cfirst; e = a.ptr[row + 1] - cfirst; }
-    // stream the slice: 16 B per lane per load, straight into LDS
-    for (long long q = (long long)cfirst + 4 * t; q < p1; q += 4 * BLOCK) {
-        T v[4];
-        int c[4];
-        if (q + 4 <= a.nnz) {
-            if (NT) {
-                ld4_nt<T>(a.vals + q, v);
-                const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(a.cols + q));
-                c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
-            } else {
-                constexpr int NV = sizeof(T) * 4 / 16;
-                union { u32x4 raw[NV]; T w[4]; } uu;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) uu.raw[k] = reinterpret_cast<const u32x4 *>(a.vals + q)[k];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = uu.w[k];
-                const i32x4 cc = *reinterpret_cast<const i32x4 *>(a.cols + q);
-                c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool ok = q + k < a.nnz;
-                v[k] = ok ? a.vals[q + k] : vzero<T>();
-                c[k] = ok ? a.cols[q + k] : 0;
-            }
-        }
-        const int o = (int)(q - cfirst);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { sv[o + k] = v[k]; sc[o + k] = c[k]; }
-    }
+    stage_slice<T, BLOCK, NT>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+    const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
     __syncthreads();
+    // Row walk, branch-free inside a batch: out-of-range slots re-read the row's LAST entry (a valid LDS slot
+    // and a column this row uses anyway) and their term is dropped by a select.  Per-slot `if`s made hipcc emit
+    // one exec-masked branch + LDS wait per entry, which serialised the issue of the gathers.
     T sum = vzero<T>();
     for (int k = s; k < e; k += UNROLL) {
         T xv[UNROLL], av[UNROLL];
+        int cj[UNROLL];
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j)
-            if (k + j < e) { av[j] = sv[k + j]; xv[j] = a.x[sc[k + j]]; }
+        for (int j = 0; j < UNROLL; ++j) {
+            const int idx = min(k + j, e - 1);
+            cj[j] = sc[idx];
+            av[j] = sv[idx];
+        }
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j)
-            if (k + j < e) sum = vfma(av[j], xv[j], sum);
+        for (int j = 0; j < UNROLL; ++j) xv[j] = a.x[cj[j]];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const T nxt = vfma(av[j], xv[j], sum);
+            sum = (k + j < e) ? nxt : sum;
+        }
     }
     A dot1 = vzero<A>();
     if (row < a.n) {
@@ -281,6 +330,88 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     if (FUSE_DOT) {
         const A tot = block_sum<BLOCK>(dot1, red);
         if (t == 0) a.partials[rb] = tot;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// SpMM fast path (nRHS > 1, RHS-major vectors as the reference ABI defines them: element i of RHS r at
+// i + r*ld).  Same structure as spmv_rowblock_kernel -- the block's matrix slice goes through LDS ONCE -- and
+// lane t then walks row t for RB right-hand sides at a time, keeping RB row sums in registers:
+//     sum[j] += a_k * x[col_k + (r0+j)*ld]
+// For every (k, j) the 64 lanes of a wave gather 64 consecutive rows' k-th column of RHS r0+j: coalesced
+// exactly like the single-RHS kernel, with RB (x2 unrolled) independent gathers in flight per lane.  The
+// matrix is read from HBM once per SpMM however many right-hand sides there are (the reference re-reads it
+// per RHS through L2 at best: spmv.cl:23-26 loops r inside j).
+// Fused d.q: per RHS the 64 lane contributions are summed by shuffles and parked per wave in LDS; after the
+// last group, thread r adds the 4 wave sums of RHS r -> partials[r*row_blocks + rb].
+// -------------------------------------------------------------------------------------------------
+template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int RB>
+__global__ __launch_bounds__(BLOCK) void spmm_rowblock_kernel(SpmvArgs<T> a) {
+    using A = typename VT<T>::acc;
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    T *sv = reinterpret_cast<T *>(dyn_smem);                                   // [cap]
+    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));   // [cap]
+    A *wavedot = reinterpret_cast<A *>(dyn_smem + (size_t)a.cap * (sizeof(T) + 4));   // [nrhs][BLOCK/64]
+
+    const int t = threadIdx.x;
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int xb = (int)((long long)xcd * a.row_blocks / 8), xe = (int)((long long)(xcd + 1) * a.row_blocks / 8);
+    if (i >= xe - xb) return;
+    const int rb = xb + i;
+    const int r0 = rb * BLOCK;
+    const int row = r0 + t;
+    // The work-group's lifetime is a chain of dependent memory round trips; keep it at three: {row pointers}
+    // -> {matrix slice} -> {x gather}.  The per-row pointers are loaded here, branch-free (clamped row), together
+    // with the slice bounds, and only consumed after the barrier.
+    const int rclamp = min(row, a.n - 1);
+    const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
+    const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
+    const int cfirst = p0 & ~3;
+    stage_slice<T, BLOCK, NT>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+    const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
+    __syncthreads();
+    const int wave = t / kWave, lane = t & (kWave - 1);
+    for (int g0 = 0; g0 < a.nrhs; g0 += RB) {
+        T sum[RB];
+        long long joff[RB];     // out-of-range right-hand sides of the last group alias the group's first one
+#pragma unroll
+        for (int j = 0; j < RB; ++j) { sum[j] = vzero<T>(); joff[j] = (g0 + j < a.nrhs) ? (long long)j * a.ldx : 0; }
+        const T *xg = a.x + (long long)g0 * a.ldx;
+        for (int k = s; k < e; k += 2) {         // two entries x RB right-hand sides in flight, branch-free
+            const int i0 = k, i1 = min(k + 1, e - 1);
+            const T a0 = sv[i0], a1 = sv[i1];
+            const int c0 = sc[i0], c1 = sc[i1];
+            T x0[RB], x1[RB];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) { x0[j] = xg[c0 + joff[j]]; x1[j] = xg[c1 + joff[j]]; }
+            const bool two = k + 1 < e;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                sum[j] = vfma(a0, x0[j], sum[j]);
+                const T nxt = vfma(a1, x1[j], sum[j]);
+                sum[j] = two ? nxt : sum[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            if (g0 + j < a.nrhs) {       // wave-uniform
+                if (row < a.n) a.y[row + (long long)(g0 + j) * a.ldy] = sum[j];
+                if (FUSE_DOT) {
+                    const A contrib = (row < a.n) ? to_acc(vmul(a.dvec[row + (long long)(g0 + j) * a.ldx], sum[j])) : vzero<A>();
+                    const A w = wave_sum(contrib);
+                    if (lane == 0) wavedot[(g0 + j) * (BLOCK / kWave) + wave] = w;
+                }
+            }
+        }
+    }
+    if (FUSE_DOT) {
+        __syncthreads();
+        for (int r = t; r < a.nrhs; r += BLOCK) {
+            A tot = wavedot[r * (BLOCK / kWave)];
+#pragma unroll
+            for (int w = 1; w < BLOCK / kWave; ++w) tot = vadd(tot, wavedot[r * (BLOCK / kWave) + w]);
+            a.partials[(long long)r * a.row_blocks + rb] = tot;
+        }
     }
 }
 
@@ -406,8 +537,15 @@ __global__ __launch_bounds__(BLOCK) void ewise_kernel(int n, const T *__restrict
 constexpr int kScalarBlock = 1024;
 template <typename A> CG_DEV A sum_partials_block(const A *p, int grid, A *smem) {
     A acc = vzero<A>();
-#pragma unroll 4
-    for (int i = threadIdx.x; i < grid; i += kScalarBlock) acc = vadd(acc, p[i]);
+    int i = threadIdx.x;
+    for (; i + 7 * kScalarBlock < grid; i += 8 * kScalarBlock) {   // 8 loads in flight; same summation order
+        A v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[i + k * kScalarBlock];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = vadd(acc, v[k]);
+    }
+    for (; i < grid; i += kScalarBlock) acc = vadd(acc, p[i]);
     acc = block_sum<kScalarBlock>(acc, smem);
     __syncthreads();
     if (threadIdx.x == 0) smem[0] = acc;
@@ -610,7 +748,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
     dim3 grid(plan.grid), block(kBlock);
-    const int variant = (vec && nrhs == 1) ? plan.kind : 0;
+    const int variant = (vec && nrhs == 1 && plan.kind == 5) ? 5 : 0;
     if (variant == 5) {
         a.cap = (plan.max_span + 3) & ~3;
         a.far = g_tune.spmv_far > 0 ? g_tune.spmv_far : 1;
@@ -627,10 +765,43 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         if (fuse) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, true, UNR>), g5, block, lds, st, a);   \
         else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, UNR>), g5, block, lds, st, a);       \
     } while (0)
-        if (g_tune.spmv_unroll == 4) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
+        // 8 gathers in flight per lane for 4/8-byte values; 4 for complex128 (8 would cost 3 waves/SIMD of occupancy)
+        if (g_tune.spmv_unroll == 4 || sizeof(T) > 8) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
         else { if (nt) CG_RB(true, 8); else CG_RB(false, 8); }
 #undef CG_RB
         return check_launch("spmv_rowblock");
+    }
+    if (vec && nrhs > 1 && plan.kind == 6) {
+        a.cap = (plan.max_span + 3) & ~3;
+        a.far = 1;
+        const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave);
+        int per_xcd = 0;
+        for (int x = 0; x < 8; ++x) {
+            const int m = (int)((long long)(x + 1) * plan.row_blocks / 8) - (int)((long long)x * plan.row_blocks / 8);
+            per_xcd = m > per_xcd ? m : per_xcd;
+        }
+        dim3 g6(per_xcd * 8);
+        constexpr int RB = sizeof(T) <= 8 ? 8 : 4;
+        // One launch per group of <= RB right-hand sides: the matrix (small next to nRHS vectors) is re-read per
+        // group, but the x window an XCD gathers from (rows in flight x group size) then fits its 4 MiB L2, so x
+        // is fetched about once instead of once per stencil neighbour (measured at nRHS = 32: 220 -> see DESIGN.md).
+        const int cap_rb = (g_tune.spmm_rb > 0 && g_tune.spmm_rb < RB) ? g_tune.spmm_rb : RB;
+        const int passes = (nrhs + cap_rb - 1) / cap_rb;
+        const int chunk = (nrhs + passes - 1) / passes;
+        for (int g0 = 0; g0 < nrhs; g0 += chunk) {
+            SpmvArgs<T> b = a;
+            b.nrhs = (nrhs - g0 < chunk) ? nrhs - g0 : chunk;
+            b.x = a.x + (long long)g0 * ldx;
+            b.y = a.y + (long long)g0 * ldy;
+            if (fuse) {
+                b.dvec = a.dvec + (long long)g0 * ldx;
+                b.partials = a.partials + (long long)g0 * plan.row_blocks;
+                hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, true, true, RB>), g6, block, lds, st, b);
+            } else {
+                hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, true, false, RB>), g6, block, lds, st, b);
+            }
+        }
+        return check_launch("spmm_rowblock");
     }
     if (vec) {
         if (fuse) hipLaunchKernelGGL((spmv_stream_kernel<T, kBlock, kQuadsPerThread, true, true>), grid, block, dyn, st, a);
@@ -660,11 +831,13 @@ int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scrat
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, const void *vals, const int *cols) {
     int kind = g_tune.spmv_variant;
     const bool vec = aligned16(vals) && aligned16(cols);
-    if (!vec || nrhs != 1 || plan->max_span <= 0) kind = 0;
-    if (kind == 5 && (size_t)plan->max_span * (dtype_size(dtype) + 4) > (size_t)kMaxSliceBytes) kind = 0;
+    if (!vec || plan->max_span <= 0) kind = 0;
+    if (kind == 5 && (size_t)plan->max_span * (dtype_size(dtype) + 4) + acc_size(dtype) * (size_t)nrhs * (kBlock / 64) >
+                         (size_t)kMaxSliceBytes) kind = 0;
     if (kind != 5) kind = 0;
+    if (kind == 5 && nrhs > 1) kind = 6;      // SpMM form of the row-block kernel
     plan->kind = kind;
-    plan->n_partials = kind == 5 ? plan->row_blocks : plan->grid;
+    plan->n_partials = kind ? plan->row_blocks : plan->grid;
 }
 
 int launch_spmv(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr,

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json configs 2-4 (parity-test cases, not the bench line):
+prints one JSON line per config: CG it/s, SpMV/SpMM GB/s (algorithmic bytes)."""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch  # noqa: E402
+
+pkg = importlib.import_module("conjugate-gradient-pyopencl_amd")
+lib = pkg._lib.load()
+ctx = pkg.Context(0)
+dev = torch.device("cuda", 0)
+ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
+NPD = {"f32": np.float32, "f64": np.float64, "c64": np.complex64, "c128": np.complex128}
+
+
+def run(name, indptr, indices, data, dtype, nrhs, iters=200, reps=30):
+    n = indptr.numel() - 1
+    nnz = indices.numel()
+    tdt = pkg.generators.torch_dtype(dtype)
+    s = pkg.Solver(ctx, n, nnz, data, indptr, indices, nrhs, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=dtype)
+    b = torch.full((n * nrhs,), 5.0, dtype=tdt, device=dev)
+    torch.cuda.synchronize()
+    s.set_rhs(b, None, on_device=True)
+    s.iterate(20)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    s.iterate(iters)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    xs = torch.ones(n * nrhs, dtype=tdt, device=dev)
+    ys = torch.empty(n * nrhs, dtype=tdt, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        s.spmv(xs, ys, fused_dot=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(ext)
+    for _ in range(reps):
+        s.spmv(xs, ys, fused_dot=True)
+    e1.record(ext)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    sb, ib = s.spmv_bytes, s.iter_bytes(False)
+    print(json.dumps({"config": name, "n": n, "nnz": nnz, "dtype": np.dtype(dtype).name, "nrhs": nrhs,
+                      "cg_it_per_s": iters / dt, "us_per_iter": dt / iters * 1e6,
+                      "cg_pct_of_8tbs_unfused_model": 100 * ib * iters / dt / 8e12,
+                      "spmv_us": us, "spmv_gbs": sb / us / 1e3, "spmv_pct_of_8tbs": 100 * sb / us / 1e3 / 8000}), flush=True)
+    s.close()
+
+
+which = [w for w in sys.argv[1:] if "=" not in w] or ["c2", "c3", "c4", "m32", "c2f32", "c3c64"]
+for kv in sys.argv[1:]:
+    if "=" in kv:
+        k, v = kv.split("=")
+        pkg._lib.check(lib.cgamd_tune(k.encode(), int(v)))
+if "c2" in which:
+    ip, ix, da = pkg.generators.poisson2d(ctx, 1000, dtype=np.float64)
+    run("C2 2D 5-pt N=1M f64", ip, ix, da, np.float64, 1)
+if "c2f32" in which:
+    ip, ix, da = pkg.generators.poisson2d(ctx, 1000, dtype=np.float32)
+    run("C2 2D 5-pt N=1M f32", ip, ix, da, np.float32, 1)
+if "c3" in which or "c3c64" in which:
+    import cg_numpy
+    N = 500
+    hp, hx, hd = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    ip, ix = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
+    if "c3" in which:
+        run("C3 Helmholtz FE N=250k c128", ip, ix, torch.from_numpy(hd).to(dev), np.complex128, 1)
+    if "c3c64" in which:
+        run("C3 Helmholtz FE N=250k c64 (reference dtype)", ip, ix, torch.from_numpy(hd.astype(np.complex64)).to(dev), np.complex64, 1)
+        run("C3 Helmholtz FE N=250k c64 nrhs=9 (as_prec shape)", ip, ix, torch.from_numpy(hd.astype(np.complex64)).to(dev), np.complex64, 9, iters=100)
+if "c4" in which:
+    ip, ix, da = pkg.generators.poisson2d(ctx, 1000, dtype=np.float64)
+    run("C4 SpMM nrhs=32 N=1M f64", ip, ix, da, np.float64, 32, iters=50, reps=10)
+if "m32" in which:
+    ip, ix, da = pkg.generators.laplace3d(ctx, 250, 200, 200, dtype=np.float32)
+    run("M 3D 7-pt N=10M f32", ip, ix, da, np.float32, 1)

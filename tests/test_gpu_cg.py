@@ -73,7 +73,7 @@ def test_golden_poisson8_real_and_multi_rhs(pkg, gpu, golden):
 
 
 @pytest.mark.parametrize("dtype,rtol", [(np.complex64, 1e-4), (np.float32, 1e-4), (np.float64, 1e-10), (np.complex128, 1e-10)])
-@pytest.mark.parametrize("flags", [0, 4, 2])   # fused+graph, reference op structure, no graph
+@pytest.mark.parametrize("flags", [0, 4, 2])   # fused+graph (default), reference op structure, no graph
 def test_residual_history_vs_oracle(pkg, gpu, golden, dtype, rtol, flags):
     """delta history on Helmholtz N=32 (complex) / Poisson 40x40 (real) vs the fp64 C oracle"""
     if np.dtype(dtype).kind == "c":
@@ -132,3 +132,28 @@ def test_size_below_256_and_odd_sizes(pkg, gpu):
         xo, ho = cg_oracle.cg(A.indptr, A.indices, A.data, b, n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
         keep = np.abs(ho[:, 0]) > 1e-12 * np.abs(ho[0, 0])
         assert np.allclose(h[keep, 0], ho[keep, 0], rtol=1e-8), n
+
+
+def test_long_run_reproducible_across_graph_replays(pkg, gpu):
+    """300 iterations in 6 graph-replayed batches: bitwise reproducible run to run, and equal to plain launches"""
+    import torch
+    ctx, queue, kernels = gpu
+    N = 700
+    indptr, indices, data = pkg.generators.poisson2d(ctx, N, dtype=np.float64)
+    n = N * N
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(11)
+    b = torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+    out = []
+    for flags in (0, 0, pkg._lib.NO_GRAPH):
+        s = pkg.Solver(ctx, n, indices.numel(), data, indptr, indices, 1, flags=pkg._lib.MATRIX_ON_DEVICE | flags, dtype=np.float64)
+        torch.cuda.synchronize()
+        s.set_rhs(b, None, on_device=True)
+        for _ in range(6):
+            s.iterate(50)
+        x = s.x(torch.empty(n, dtype=torch.float64, device=dev))
+        out.append((x.clone(), s.history().copy()))
+        s.close()
+    for k in (1, 2):
+        assert torch.equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1])
+    assert out[0][1].shape == (301, 1) and np.all(np.isfinite(out[0][1]))
