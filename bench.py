@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", type=str, default="250x200x200", help="global grid nx x ny x nz")
-    ap.add_argument("--dist-graph", action="store_true", help="N>1: replay iterations (incl. RCCL ops) from a hipGraph")
+    ap.add_argument("--no-dist-graph", action="store_true", help="N>1: plain stream launches instead of hipGraph replay of the RCCL loop")
     ap.add_argument("--dtype", type=str, default="f64", choices=["f32", "f64", "c64", "c128"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="reference op structure (6 kernels/iteration)")
@@ -105,7 +105,7 @@ def main():
         local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("CG_FORCE_DIST", "0") == "1":
         dist.init_process_group(backend="nccl", device_id=dev)
 
     pkg = importlib.import_module(PKG)
@@ -114,7 +114,7 @@ def main():
     nx, ny, nz = (int(v) for v in args.grid.split("x"))
     ctx = pkg.Context(local_rank)
 
-    if world == 1:
+    if world == 1 and os.environ.get("CG_FORCE_DIST", "0") != "1":
         result = bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype)
     else:
         from importlib import import_module
@@ -129,7 +129,7 @@ def main():
                 result["cpu_baseline"] = {"value": None, "unit": "CG iterations/s", "cores": os.cpu_count(),
                                           "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
