@@ -12,6 +12,7 @@ No CPU fallback: importing works anywhere, computing needs the built library and
 from . import _lib, cl, mmio, generators  # noqa: F401
 from ._lib import CgAmdError, LIB_PATH, LEGACY_LIB_PATH  # noqa: F401
 from .cl import (CG, Context, CommandQueue, Device, DeviceBuffer, Solver, conjugate_gradient_multi_gpu,  # noqa: F401
+                 solve_subdomains,
                  get_gpu_devices, initialize_cl_environment, initialize_cl_environment_with_device,
                  load_and_build_kernels)
 

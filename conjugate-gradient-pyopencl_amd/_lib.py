@@ -84,6 +84,8 @@ def load():
         "cgamd_solver_vector": (vp, [vp, ci]),
         "cgamd_solver_solve": (ci, [vp, vp, vp, ci, vp]),
         "cgamd_solver_spmv": (ci, [vp, vp, vp, ci]),
+        "cgamd_solver_spmm_rowmajor": (ci, [vp, vp, vp, ci]),
+        "cgamd_transpose": (ci, [vp, ci, ci, ci, vp, vp]),
         "cgamd_solver_spmv_bytes": (ll, [vp]),
         "cgamd_solver_iter_bytes": (ll, [vp, ci]),
         "cgamd_cg": (ci, [ci, ci, ll, vp, vp, vp, vp, vp, ci, ci, vp, ci]),

@@ -128,6 +128,11 @@ class DeviceBuffer:
             pass
 
 
+def transpose(ctx, dtype, rows, cols, src, dst):
+    """dst[c*rows + r] = src[r*cols + c] on the device: RHS-major [n_rhs][size] <-> row-major [size][n_rhs]"""
+    check(_lib.load().cgamd_transpose(ctx.handle, _lib.DTYPE_CODE[np.dtype(dtype)], int(rows), int(cols), ptr(src), ptr(dst)))
+
+
 def get_gpu_devices():
     """reference cl.py:26-31 -- list of GPU devices."""
     n = _lib.load().cgamd_device_count()
@@ -262,6 +267,10 @@ class Solver:
     def spmv(self, x, y, fused_dot=False):
         check(self._lib.cgamd_solver_spmv(self.handle, ptr(x), ptr(y), int(fused_dot)))
 
+    def spmm_rowmajor(self, x, y, n_rhs):
+        """Y[size][n_rhs] = A X on the matrix cores; x, y ROW-MAJOR device arrays, n_rhs in {16, 32}, f32/f64"""
+        check(self._lib.cgamd_solver_spmm_rowmajor(self.handle, ptr(x), ptr(y), int(n_rhs)))
+
     def vector(self, which):
         return self._lib.cgamd_solver_vector(self.handle, {"x": 0, "r": 1, "d": 2, "q": 3}[which])
 
@@ -282,6 +291,56 @@ class Solver:
             self.close()
         except Exception:
             pass
+
+
+    def solve_tol(self, b, x0=None, tol=1e-5, maxit=1000, check_every=8):
+        """Tolerance-stopping variant of the reference's NumPy sub-solver (p_h-PY_C-CL.py:1338-1369, UseCG==5):
+        iterate until sqrt(|r.r|) < tol, looking at the device-resident history every `check_every`
+        iterations (one small read-back instead of the reference's per-iteration host reductions).
+        Returns (x, iterations_run, history).  Single right-hand side."""
+        if self.n_rhs != 1:
+            raise ValueError("solve_tol handles one right-hand side")
+        self.set_rhs(b, x0)
+        done = 0
+        while done < maxit:
+            step = min(check_every, maxit - done)
+            self.iterate(step)
+            done += step
+            h = self.history()
+            below = np.nonzero(np.sqrt(np.abs(h[:, 0])) < tol)[0]
+            if below.size or not np.all(np.isfinite(h[-1])):
+                break
+        return self.x(), done, self.history()
+
+
+def solve_subdomains(ctx, P0, residuals, n_iterations, dtype=np.csingle, solver=None):
+    """The batched sub-domain solve of the reference's Additive-Schwarz preconditioner, `as_prec` with
+    UseCG in {2, 3} (p_h-PY_C-CL.py:1918-1937, 1938-1953): all n_my sub-domains share ONE matrix P[0];
+    their residuals are stacked RHS-major into one b, solved with n_rhs = n_my and a fixed number of
+    iterations, and split back.  P0: scipy CSR (or (indptr, indices, data)); residuals: list of arrays.
+    Pass `solver` (a Solver built for P0 with n_rhs = len(residuals)) to keep the matrix resident across
+    the outer GMRES iterations -- the reference re-uploads it on every call (clcg.c:202-211).
+    Returns a list of complex arrays shaped like the inputs (`x[p*size:(p+1)*size].astype(complex)`)."""
+    if hasattr(P0, "indptr"):
+        indptr, indices, data = P0.indptr, P0.indices, P0.data
+    else:
+        indptr, indices, data = P0
+    size = len(indptr) - 1
+    n_my = len(residuals)
+    b_values = np.zeros(size * n_my, dtype=dtype)
+    for p in range(n_my):
+        b_values[p * size:(p + 1) * size] = np.asarray(residuals[p]).ravel()
+    own = solver is None
+    if own:
+        solver = Solver(ctx, size, len(indices), np.asarray(data, dtype=dtype), indptr, indices, n_my)
+    try:
+        solver.set_rhs(b_values, None)
+        solver.iterate(n_iterations)
+        x = solver.x()
+    finally:
+        if own:
+            solver.close()
+    return [x[p * size:(p + 1) * size].astype(complex).reshape(np.shape(residuals[p])) for p in range(n_my)]
 
 
 # ---- reference entry points --------------------------------------------------------------------

@@ -201,6 +201,12 @@ int cgamd_sub(cgamd_ctx *c, int dtype, int size, const void *a, const void *b, v
     return launch_sub(dtype, size, a, b, result, size, nRHS, c->stream);
 }
 
+int cgamd_transpose(cgamd_ctx *c, int dtype, int rows, int cols, const void *in, void *out) {
+    if (int rc = check_op(c, dtype, rows, 1, "transpose")) return rc;
+    if (cols < 0 || ((long long)rows * cols > 0 && (!in || !out || in == out))) return fail(CGAMD_ERR_INVALID, "transpose: bad argument");
+    return launch_transpose(dtype, rows, cols, in, out, c->stream);
+}
+
 // ---- generators --------------------------------------------------------------------------------
 int cgamd_gen_laplace3d(cgamd_ctx *c, int dtype, int nx, int ny, int nz, long long row_begin, long long row_end,
                         void *aValues, int *aPointers, int *aCols, long long *nnz_out) {

@@ -96,6 +96,12 @@ int launch_cg_beta(int dtype, const void *partials, int grid, int nrhs, const Cg
 int launch_reduce_to_acc(int dtype, const void *partials, int grid, int nrhs, void *out, hipStream_t st);
 int launch_pack(int dtype, int count, const int *index, const void *v, void *out, hipStream_t st);
 
+// Y[n][nrhs] = A X[ncols][nrhs], ROW-MAJOR right-hand-side block, nrhs in {16, 32}, f32/f64, on the matrix cores;
+// plan.max_span must be known and the slice must fit LDS.  [rows][cols] -> [cols][rows] transpose for the layout change.
+int launch_spmm_mfma(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr,
+                     const int *cols, const void *x, void *y, int nrhs, hipStream_t st);
+int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);
+
 // synthetic generators (device)
 int launch_gen_laplace3d(int dtype, int nx, int ny, int nz, long long row_begin, long long row_end, void *vals,
                          int *ptr, int *cols, hipStream_t st);

@@ -415,6 +415,109 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowblock_kernel(SpmvArgs<T> a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// SpMM on the matrix cores for a ROW-MAJOR block of right-hand sides, Y[N][R] = A * X[N][R], R = 16 or 32
+// (BASELINE config 4: "MFMA tall-B tile path").  In row-major form the operand gathered for one non-zero,
+// X[col][0:R], is a dense contiguous row (128/256 B), and the product over a 16-row strip of A is a real
+// contraction:   Y_tile(16 x 16) += S(16 x 4) * Xg(4 x 16)
+// where the 4 K-slots are 4 consecutive non-zeros of the strip (CSR order), Xg[k][n] = X[col_k][n0+n] is the
+// tall dense B tile, and S[m][k] = a_k if non-zero k belongs to row m, else 0 (each lane decides with its own
+// row's [s,e) bounds: two compares, no search).  One v_mfma_{f64,f32}_16x16x4 per 4 non-zeros per 16 columns
+// of X replaces the LDS/shuffle row reduction; accumulation order inside a row is CSR order (the MFMA adds
+// its 4 K-slots in k order, slots of other rows contribute exact zeros).
+// Only 1 of the 16 S entries of a slot is non-zero, so the matrix pipe runs at 1/16 useful rate; that is
+// affordable only because the kernel is bound by the X gather, not by FLOPs.  A non-finite X entry reaches all
+// 16 rows of its strip (0 * inf); CG with non-finite iterates is lost anyway.
+// Work-group = 256 rows = 16 strips, 4 per wave; the block's matrix slice goes through LDS as in
+// spmv_rowblock_kernel.  Lane maps: A/B one element per lane, A[m=l&15][k=l>>4], B[k=l>>4][n=l&15];
+// C/D f64: row = (l>>4) + 4*reg, f32: row = 4*(l>>4) + reg (cdna_hip_programming.md §3).
+// -------------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+CG_DEV f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+CG_DEV f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+template <typename T> struct Mfma;
+template <> struct Mfma<double> { using acc = f64x4; static CG_DEV int row(int lane, int reg) { return (lane >> 4) + 4 * reg; } };
+template <> struct Mfma<float> { using acc = f32x4; static CG_DEV int row(int lane, int reg) { return 4 * (lane >> 4) + reg; } };
+
+template <typename T> struct SpmmMfmaArgs {
+    int n, nrhs, row_blocks, cap;
+    long long nnz;
+    const T *vals;
+    const int *ptr, *cols;
+    const T *x;   // [n_cols][nrhs] row-major
+    T *y;         // [n][nrhs] row-major
+};
+
+template <typename T, int BLOCK, int NH>
+__global__ __launch_bounds__(BLOCK) void spmm_mfma_kernel(SpmmMfmaArgs<T> a) {
+    using Acc = typename Mfma<T>::acc;
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    T *sv = reinterpret_cast<T *>(dyn_smem);
+    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int xb = (int)((long long)xcd * a.row_blocks / 8), xe = (int)((long long)(xcd + 1) * a.row_blocks / 8);
+    if (i >= xe - xb) return;
+    const int r0 = (xb + i) * BLOCK;
+    const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
+    const int cfirst = p0 & ~3;
+    stage_slice<T, BLOCK, true>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+    __syncthreads();
+    const int m = lane & 15, kq = lane >> 4;
+#pragma unroll 1
+    for (int tt = 0; tt < 4; ++tt) {                                  // 64 rows per wave = 4 strips of 16
+        const int rowbase = r0 + wave * 64 + tt * 16;
+        if (rowbase >= a.n) break;                                     // wave-uniform
+        const int s_m = a.ptr[min(rowbase + m, a.n)] - cfirst;
+        const int e_m = a.ptr[min(rowbase + m + 1, a.n)] - cfirst;
+        const int t_begin = __shfl(s_m, 0, kWave);                   // strip = [start of row 0, end of row 15)
+        const int t_end = __shfl(e_m, 15, kWave);
+        Acc acc[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[h] = Acc{0, 0, 0, 0};
+        constexpr int U = 4;                                           // K-steps whose X rows are in flight together
+        for (int j0 = t_begin; j0 < t_end; j0 += 4 * U) {
+            T a_op[U], bv[U][NH];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 4 * u + kq;
+                const int jc = min(j, t_end - 1);                     // clamped slot: a valid LDS entry of this strip
+                const T v = sv[jc];
+                const int c = sc[jc];
+                a_op[u] = (j >= s_m && j < e_m) ? v : (T)0;            // j >= t_end never lies inside a row
+                const T *xr = a.x + (long long)c * a.nrhs + m;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) bv[u][h] = xr[h * 16];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) acc[h] = mfma16(a_op[u], bv[u][h], acc[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = rowbase + Mfma<T>::row(lane, reg);
+                if (row < a.n) a.y[(long long)row * a.nrhs + h * 16 + m] = acc[h][reg];
+            }
+    }
+}
+
+// [rows][cols] -> [cols][rows]: RHS-major (the reference ABI, nRHS x N) <-> row-major (N x nRHS)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, const T *__restrict__ in, T *__restrict__ out) {
+    __shared__ T tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int k = ty; k < 32; k += 8)
+        if (by + k < rows && bx + tx < cols) tile[k][tx] = in[(long long)(by + k) * cols + bx + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (bx + k < cols && by + tx < rows) out[(long long)(bx + k) * rows + by + tx] = tile[tx][k];
+}
+
 // largest (4-aligned) non-zero span of any BLOCK-row slice: decides whether the fast path applies
 template <int BLOCK> __global__ void spmv_span_kernel(int n, const int *__restrict__ ptr, int row_blocks, int *out) {
     int m = 0;
@@ -986,6 +1089,40 @@ template <typename T> static int pack_impl(int count, const int *index, const vo
 int launch_pack(int dtype, int count, const int *index, const void *v, void *out, hipStream_t st) {
     if (count <= 0) return CGAMD_OK;
     CG_DISPATCH(dtype, pack_impl, count, index, v, out, st);
+}
+
+template <typename T>
+static int spmm_mfma_impl(const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
+                          const void *x, void *y, int nrhs, hipStream_t st) {
+    SpmmMfmaArgs<T> a;
+    a.n = n; a.nrhs = nrhs; a.row_blocks = plan.row_blocks; a.cap = (plan.max_span + 3) & ~3; a.nnz = nnz;
+    a.vals = (const T *)vals; a.ptr = ptr; a.cols = cols; a.x = (const T *)x; a.y = (T *)y;
+    const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
+    int per_xcd = 0;
+    for (int xx = 0; xx < 8; ++xx) {
+        const int m = (int)((long long)(xx + 1) * plan.row_blocks / 8) - (int)((long long)xx * plan.row_blocks / 8);
+        per_xcd = m > per_xcd ? m : per_xcd;
+    }
+    dim3 g(per_xcd * 8), b(kBlock);
+    if (nrhs == 16) hipLaunchKernelGGL((spmm_mfma_kernel<T, kBlock, 1>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((spmm_mfma_kernel<T, kBlock, 2>), g, b, lds, st, a);
+    return check_launch("spmm_mfma");
+}
+int launch_spmm_mfma(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr,
+                     const int *cols, const void *x, void *y, int nrhs, hipStream_t st) {
+    if (dtype == CGAMD_F64) return spmm_mfma_impl<double>(plan, n, nnz, vals, ptr, cols, x, y, nrhs, st);
+    if (dtype == CGAMD_F32) return spmm_mfma_impl<float>(plan, n, nnz, vals, ptr, cols, x, y, nrhs, st);
+    return fail(CGAMD_ERR_INVALID, "spmm_mfma: real value types only (f32, f64)");
+}
+
+template <typename T> static int transpose_impl(int rows, int cols, const void *in, void *out, hipStream_t st) {
+    dim3 g((cols + 31) / 32, (rows + 31) / 32);
+    hipLaunchKernelGGL((transpose_kernel<T>), g, dim3(256), 0, st, rows, cols, (const T *)in, (T *)out);
+    return check_launch("transpose");
+}
+int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return CGAMD_OK;
+    CG_DISPATCH(dtype, transpose_impl, rows, cols, in, out, st);
 }
 
 }  // namespace cgamd

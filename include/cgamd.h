@@ -119,6 +119,12 @@ void *cgamd_solver_vector(cgamd_solver *s, int which);
 int cgamd_solver_solve(cgamd_solver *s, const void *b, void *x, int nIterations, void *history);
 /* the solver's SpMV (optionally fused with the d.q partial reduction) on caller vectors -- bench/profiling */
 int cgamd_solver_spmv(cgamd_solver *s, const void *x, void *y, int fused_dot);
+/* SpMM on the matrix cores (BASELINE config 4, "MFMA tall-B tile path"): Y[size][nRHS] = A * X[size][nRHS] with
+ * the right-hand-side block in ROW-MAJOR layout (element i of RHS r at [i*nRHS + r]), nRHS = 16 or 32, f32/f64.
+ * cgamd_transpose converts between the reference's RHS-major blocks ([nRHS][size]) and this layout:
+ * out[c*rows + r] = in[r*cols + c]. */
+int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS);
+int cgamd_transpose(cgamd_ctx *ctx, int dtype, int rows, int cols, const void *in, void *out);
 /* algorithmic HBM bytes of one SpMV / one CG iteration of this solver (SURVEY §8d formulae) */
 long long cgamd_solver_spmv_bytes(cgamd_solver *s);
 long long cgamd_solver_iter_bytes(cgamd_solver *s, int fused);

@@ -80,6 +80,30 @@ if "c3" in which or "c3c64" in which:
 if "c4" in which:
     ip, ix, da = pkg.generators.poisson2d(ctx, 1000, dtype=np.float64)
     run("C4 SpMM nrhs=32 N=1M f64", ip, ix, da, np.float64, 32, iters=50, reps=10)
+if "c4" in which or "c4mfma" in which:
+    # the same product on the matrix cores, row-major RHS block (transposes excluded: layout is kept by a caller)
+    for dt, tdt_, nm in ((np.float64, torch.float64, "f64"), (np.float32, torch.float32, "f32")):
+        ip, ix, da = pkg.generators.poisson2d(ctx, 1000, dtype=dt)
+        n = 1000 * 1000
+        s = pkg.Solver(ctx, n, ix.numel(), da, ip, ix, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=dt)
+        for nrhs in (32, 16):
+            xs = torch.rand(n * nrhs, dtype=tdt_, device=dev)
+            ys = torch.empty(n * nrhs, dtype=tdt_, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                s.spmm_rowmajor(xs, ys, nrhs)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ext)
+            for _ in range(10):
+                s.spmm_rowmajor(xs, ys, nrhs)
+            e1.record(ext)
+            e1.synchronize()
+            us = e0.elapsed_time(e1) / 10 * 1e3
+            V = np.dtype(dt).itemsize
+            sb = ix.numel() * (V + 4) + (n + 1) * 4 + 2 * n * V * nrhs
+            print(json.dumps({"config": f"C4 SpMM MFMA row-major nrhs={nrhs} N=1M {nm}", "spmm_us": us, "spmm_gbs": sb / us / 1e3,
+                              "spmm_pct_of_8tbs": 100 * sb / us / 1e3 / 8000}), flush=True)
+        s.close()
 if "m32" in which:
     ip, ix, da = pkg.generators.laplace3d(ctx, 250, 200, 200, dtype=np.float32)
     run("M 3D 7-pt N=10M f32", ip, ix, da, np.float32, 1)

@@ -157,3 +157,39 @@ def test_long_run_reproducible_across_graph_replays(pkg, gpu):
     for k in (1, 2):
         assert torch.equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1])
     assert out[0][1].shape == (301, 1) and np.all(np.isfinite(out[0][1]))
+
+
+def test_as_prec_shaped_batched_solve(pkg, gpu, golden):
+    """n_my sub-domain residuals, one shared matrix, complex64, fixed iterations
+    (p_h-PY_C-CL.py:1918-1937); checked per sub-domain against the fp64 oracle"""
+    ctx, queue, kernels = gpu
+    d = golden["driver_generators"]
+    ip, ix, da = d["local_rect_indptr"], d["local_rect_indices"], d["local_rect_data"]      # reference local_rect()
+    n = len(ip) - 1
+    rng = np.random.default_rng(2)
+    res = [(rng.standard_normal((6, 9)) + 1j * rng.standard_normal((6, 9))) for _ in range(5)]
+    assert n == 54
+    out = pkg.solve_subdomains(ctx, (ip, ix, da), res, 20)
+    assert len(out) == 5 and out[0].shape == (6, 9) and out[0].dtype == np.complex128
+    for p in range(5):
+        xo, _ = cg_oracle.cg(ip, ix, da, res[p].ravel(), n_iterations=20, mode=cg_oracle.MODE_SEQUENTIAL)
+        assert np.linalg.norm(out[p].ravel() - xo) / np.linalg.norm(xo) < 5e-4       # complex64 vs fp64
+    # resident-matrix form: same numbers, bit for bit
+    s = pkg.Solver(ctx, n, len(ix), da.astype(np.csingle), ip, ix, 5)
+    out2 = pkg.solve_subdomains(ctx, (ip, ix, da), res, 20, solver=s)
+    s.close()
+    assert all(np.array_equal(a, b) for a, b in zip(out, out2))
+
+
+def test_tolerance_stopping_mode(pkg, gpu, golden):
+    """the reference's tol-stopping NumPy CG (p_h-PY_C-CL.py:1338-1369) as a mode of the handle"""
+    ctx, queue, kernels = gpu
+    g = golden["cg_iterates"]
+    ip, ix, da, b = g["poisson8_indptr"], g["poisson8_indices"], g["poisson8_data"], g["poisson8_b"]
+    s = pkg.Solver(ctx, 64, len(ix), da, ip, ix, 1)
+    x, its, h = s.solve_tol(b, tol=1e-8, maxit=200, check_every=4)
+    s.close()
+    want = g["poisson8_tol1e-8_x"].real          # reference run stopped after 23 iterations
+    assert 23 <= its <= 28
+    assert np.linalg.norm(x - want) / np.linalg.norm(want) < 1e-8
+    assert np.sqrt(abs(h[-1, 0])) < 1e-8

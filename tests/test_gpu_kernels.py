@@ -103,3 +103,27 @@ def test_axpy_aypx_sub(pkg, gpu, dtype, n, nrhs):
     rb = _buf(pkg, ctx, np.zeros_like(x))
     kernels["sub"](queue, _buf(pkg, ctx, x), _buf(pkg, ctx, y), rb, n, n_rhs=nrhs)
     assert np.array_equal(rb.get(), cg_oracle.sub(x, y, nrhs=nrhs))    # a single rounding: bit-exact
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,avg,nrhs", [(16, 3, 16), (100, 5, 32), (257, 7, 16), (1000, 7, 32), (5003, 12, 32), (40000, 5, 16)])
+def test_spmm_mfma_rowmajor_matches_oracle(pkg, gpu, dtype, n, avg, nrhs):
+    """config 4: SpMM with a row-major RHS block on the matrix cores (v_mfma_*_16x16x4), against the oracle's
+    per-RHS SpMV; also checks the RHS-major <-> row-major transposes around it"""
+    ctx, queue, kernels = gpu
+    rng = np.random.default_rng(n + nrhs)
+    indptr, indices, data = rand_csr(rng, n, avg, dtype, empty_rows=n > 50)
+    X = rand_vec(rng, n * nrhs, dtype)                                  # RHS-major [nrhs][n]
+    want = cg_oracle.spmv(indptr, indices, data, X, nrhs=nrhs, mode=cg_oracle.MODE_SEQUENTIAL)
+    s = pkg.Solver(ctx, n, len(indices), data, indptr, indices, 1)
+    xb, xt = _buf(pkg, ctx, X), _buf(pkg, ctx, np.zeros_like(X))
+    yt, yb = _buf(pkg, ctx, np.zeros_like(X)), _buf(pkg, ctx, np.zeros_like(X))
+    pkg.cl.transpose(ctx, dtype, nrhs, n, xb, xt)                       # -> [n][nrhs]
+    assert np.array_equal(xt.get().reshape(n, nrhs), X.reshape(nrhs, n).T)
+    s.spmm_rowmajor(xt, yt, nrhs)
+    pkg.cl.transpose(ctx, dtype, n, nrhs, yt, yb)                       # -> [nrhs][n]
+    got = yb.get()
+    s.close()
+    import scipy.sparse as sp
+    scale = (np.abs(sp.csr_matrix((np.abs(data), indices, indptr), shape=(n, n))) @ np.abs(X.reshape(nrhs, n).T)).T.reshape(-1) + 1e-30
+    assert np.max(np.abs(got - want) / scale) < RTOL[np.dtype(dtype)]
