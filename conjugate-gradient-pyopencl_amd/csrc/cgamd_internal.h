@@ -48,8 +48,8 @@ constexpr int kMaxSliceBytes = 64 * 1024;   // variant 5: largest LDS slice acce
 struct Tuning {
     int spmv_variant = 5;   // 5 = row-block kernel (matrix through LDS, one row block per work-group), 0 = generic chunked
     int spmv_nt = 1;        // non-temporal matrix loads
-    int spmv_unroll = 8;    // row walk: LDS reads + gathers in flight per lane (4 or 8)
-    int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = 8 for 4/8-byte values, 4 for 16-byte)
+    int spmv_unroll = 0;    // row walk: LDS reads + gathers in flight per lane (4 or 8; 0 = 8, or 4 for 16-byte values)
+    int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = all in one launch)
     int spmv_far = 1;       // row-block schedule interleave stride (1 = none)
     int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)
     int vec_grid = 0;       // vector kernels: 0 = auto
@@ -91,6 +91,11 @@ int launch_cg_delta0(int dtype, const void *partials, int grid, int nrhs, const 
 int launch_cg_alpha(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st);
 // dn = sum partials_rr ; beta = dn/delta ; delta = dn ; history[++iter] = dn
 int launch_cg_beta(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st);
+
+// d = beta d + r with beta = (sum of the P r.r partials) / history[iter-1] computed in every work-group's prologue;
+// work-group 0 records delta, beta and history[iter] (the cg_beta launch folded into aypx)
+int launch_aypx_beta(int dtype, int n, const void *x, void *y, long long ld, const void *partials, int P, int nrhs,
+                     const CgScalars &sc, hipStream_t st);
 
 // partials -> accumulator-precision scalar per RHS (all-reduce input); halo pack out[k] = v[index[k]]
 int launch_reduce_to_acc(int dtype, const void *partials, int grid, int nrhs, void *out, hipStream_t st);

@@ -52,6 +52,12 @@ CG_DEV double vmul(double a, double b) { return a * b; }
 CG_DEV float2 vmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 CG_DEV double2 vmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
+// c ? a : b, component-wise (a ?: on the HIP vector structs is lowered through scratch memory)
+CG_DEV float vsel(bool c, float a, float b) { return c ? a : b; }
+CG_DEV double vsel(bool c, double a, double b) { return c ? a : b; }
+CG_DEV float2 vsel(bool c, float2 a, float2 b) { return make_float2(c ? a.x : b.x, c ? a.y : b.y); }
+CG_DEV double2 vsel(bool c, double2 a, double2 b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
+
 // c + a*b
 template <typename T> CG_DEV T vfma(T a, T b, T c) { return vadd(c, vmul(a, b)); }
 

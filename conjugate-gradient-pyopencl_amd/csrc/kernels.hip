@@ -32,6 +32,7 @@ template <typename T> struct Pack {
 template <typename T> CG_DEV Pack<T> ld_pack(const T *p) { return *reinterpret_cast<const Pack<T> *>(p); }
 template <typename T> CG_DEV void st_pack(T *p, const Pack<T> &v) { *reinterpret_cast<Pack<T> *>(p) = v; }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 CG_DEV void st_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
@@ -39,16 +40,31 @@ CG_DEV void st_nt(double *p, double v) { __builtin_nontemporal_store(v, p); }
 CG_DEV void st_nt(float2 *p, float2 v) { f32x2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<f32x2 *>(p)); }
 CG_DEV void st_nt(double2 *p, double2 v) { f64x2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<f64x2 *>(p)); }
 
-template <typename T> CG_DEV void ld4_nt(const T *p, T (&out)[4]) {
-    // 4 consecutive values = sizeof(T)/4 sixteen-byte non-temporal loads
-    constexpr int NV = sizeof(T) * 4 / 16;
-    union { u32x4 raw[NV]; T v[4]; } u;
-    const u32x4 *q = reinterpret_cast<const u32x4 *>(p);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) u.raw[i] = __builtin_nontemporal_load(q + i);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = u.v[i];
+// 4 consecutive values by 16-byte loads, register to register (a union of ext-vectors and HIP vector structs
+// sent the complex128 instance through scratch memory: 2x slower).  NT = non-temporal.
+template <typename V, bool NT> CG_DEV V ld16(const void *p) {
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(p)) : *reinterpret_cast<const V *>(p);
 }
+template <bool NT> CG_DEV void ld4(const float *p, float (&o)[4]) {
+    const f32x4 w = ld16<f32x4, NT>(p);
+    o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = w.w;
+}
+template <bool NT> CG_DEV void ld4(const double *p, double (&o)[4]) {
+    const f64x2 a = ld16<f64x2, NT>(p), b = ld16<f64x2, NT>(p + 2);
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+}
+template <bool NT> CG_DEV void ld4(const float2 *p, float2 (&o)[4]) {
+    const f32x4 a = ld16<f32x4, NT>(p), b = ld16<f32x4, NT>(p + 2);
+    o[0] = make_float2(a.x, a.y); o[1] = make_float2(a.z, a.w); o[2] = make_float2(b.x, b.y); o[3] = make_float2(b.z, b.w);
+}
+template <bool NT> CG_DEV void ld4(const double2 *p, double2 (&o)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f64x2 a = ld16<f64x2, NT>(p + i);
+        o[i] = make_double2(a.x, a.y);
+    }
+}
+template <typename T> CG_DEV void ld4_nt(const T *p, T (&out)[4]) { ld4<true>(p, out); }
 
 // =================================================================================================
 // SpMV / SpMM, CSR-stream: a work-group owns BLOCK consecutive rows at a time.  Their non-zeros are one
@@ -188,20 +204,9 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs<T> a) {
 template <typename T, bool NT, bool FULL> CG_DEV void load_quad(const T *__restrict__ vals, const int *__restrict__ cols,
                                                                 long long nnz, long long q, T (&v)[4], int (&c)[4]) {
     if (FULL || q + 4 <= nnz) {
-        if (NT) {
-            ld4_nt<T>(vals + q, v);
-            const i32x4 cc = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(cols + q));
-            c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
-        } else {
-            constexpr int NV = sizeof(T) * 4 / 16;
-            union { u32x4 raw[NV]; T w[4]; } uu;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) uu.raw[k] = reinterpret_cast<const u32x4 *>(vals + q)[k];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = uu.w[k];
-            const i32x4 cc = *reinterpret_cast<const i32x4 *>(cols + q);
-            c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
-        }
+        ld4<NT>(vals + q, v);
+        const i32x4 cc = ld16<i32x4, NT>(cols + q);
+        c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
             const T nxt = vfma(av[j], xv[j], sum);
-            sum = (k + j < e) ? nxt : sum;
+            sum = vsel(k + j < e, nxt, sum);
         }
     }
     A dot1 = vzero<A>();
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowblock_kernel(SpmvArgs<T> a) {
             for (int j = 0; j < RB; ++j) {
                 sum[j] = vfma(a0, x0[j], sum[j]);
                 const T nxt = vfma(a1, x1[j], sum[j]);
-                sum[j] = two ? nxt : sum[j];
+                sum[j] = vsel(two, nxt, sum[j]);
             }
         }
 #pragma unroll
@@ -433,7 +438,6 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowblock_kernel(SpmvArgs<T> a) {
 // C/D f64: row = (l>>4) + 4*reg, f32: row = 4*(l>>4) + reg (cdna_hip_programming.md §3).
 // -------------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 CG_DEV f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 CG_DEV f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 template <typename T> struct Mfma;
@@ -631,6 +635,57 @@ __global__ __launch_bounds__(BLOCK) void ewise_kernel(int n, const T *__restrict
     }
     for (long long i = i0; i < n; i += stride)
         y[i] = f(x[i], OP != 3 ? y[i] : vzero<T>(), OP == 3 ? b2[i] : vzero<T>());
+}
+
+// d = beta d + r with beta computed in the prologue (replaces the cg_beta launch of the 5-launch loop):
+// every work-group adds the P partials of r.r in the same fixed order (thread-strided, wave tree, 4 wave
+// sums), so all of them hold the bit-identical delta_new and beta = delta_new / delta_old
+// (clcg.c:376-391); delta_old is history[iter-1] -- nothing in this launch writes that entry, work-group 0
+// alone writes delta/beta/history[iter].  The iteration counter was advanced by cg_alpha.
+template <typename T, int BLOCK, bool VEC>
+__global__ __launch_bounds__(BLOCK) void aypx_beta_kernel(int n, const T *__restrict__ x, T *__restrict__ y, long long ld,
+                                                          const typename VT<T>::acc *__restrict__ partials, int P,
+                                                          int nrhs, T *delta, T *beta, T *history, const int *iter) {
+    using A = typename VT<T>::acc;
+    __shared__ A red[BLOCK / kWave];
+    __shared__ T beta_s;
+    const int r = blockIdx.y;
+    {
+        A acc = vzero<A>();
+        const A *p = partials + (long long)r * P;
+        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, p[i]);
+        const A tot = block_sum<BLOCK>(acc, red);
+        if (threadIdx.x == 0) {
+            const int it = *iter;
+            const T dnT = from_acc<T>(tot);
+            const T dold = history[(long long)(it - 1) * nrhs + r];
+            const T b = from_acc<T>(acc_div(to_acc(dnT), to_acc(dold)));
+            beta_s = b;
+            if (blockIdx.x == 0) {
+                beta[r] = b;
+                delta[r] = dnT;
+                history[(long long)it * nrhs + r] = dnT;
+            }
+        }
+        __syncthreads();
+    }
+    const T al = beta_s;
+    x += (long long)r * ld; y += (long long)r * ld;
+    constexpr int E = Pack<T>::N;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (VEC) {
+        const long long npack = n / E;
+        for (long long i = i0; i < npack; i += stride) {
+            const Pack<T> px = ld_pack(x + i * E);
+            Pack<T> py = ld_pack(y + i * E);
+#pragma unroll
+            for (int k = 0; k < E; ++k) py.v[k] = vadd(vmul(al, py.v[k]), px.v[k]);
+            st_pack(y + i * E, py);
+        }
+        i0 += npack * E;
+    }
+    for (long long i = i0; i < n; i += stride) y[i] = vadd(vmul(al, y[i]), x[i]);
 }
 
 // =================================================================================================
@@ -869,7 +924,8 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, UNR>), g5, block, lds, st, a);       \
     } while (0)
         // 8 gathers in flight per lane for 4/8-byte values; 4 for complex128 (8 would cost 3 waves/SIMD of occupancy)
-        if (g_tune.spmv_unroll == 4 || sizeof(T) > 8) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
+        const int unroll = g_tune.spmv_unroll ? g_tune.spmv_unroll : (sizeof(T) > 8 ? 4 : 8);
+        if (unroll == 4) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
         else { if (nt) CG_RB(true, 8); else CG_RB(false, 8); }
 #undef CG_RB
         return check_launch("spmv_rowblock");
@@ -885,12 +941,10 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         }
         dim3 g6(per_xcd * 8);
         constexpr int RB = sizeof(T) <= 8 ? 8 : 4;
-        // One launch per group of <= RB right-hand sides: the matrix (small next to nRHS vectors) is re-read per
-        // group, but the x window an XCD gathers from (rows in flight x group size) then fits its 4 MiB L2, so x
-        // is fetched about once instead of once per stencil neighbour (measured at nRHS = 32: 220 -> see DESIGN.md).
-        const int cap_rb = (g_tune.spmm_rb > 0 && g_tune.spmm_rb < RB) ? g_tune.spmm_rb : RB;
-        const int passes = (nrhs + cap_rb - 1) / cap_rb;
-        const int chunk = (nrhs + passes - 1) / passes;
+        // One launch covers all right-hand sides (groups of RB inside the kernel).  Splitting into one launch per
+        // group (cgamd_tune "spmm_rb") re-reads the matrix per group and shrinks the x window per XCD; measured
+        // slower at nRHS = 32 (253 vs 220 us) and at nRHS = 9 -- kept as an experiment knob only.
+        const int chunk = (g_tune.spmm_rb > 0 && g_tune.spmm_rb < nrhs) ? g_tune.spmm_rb : nrhs;
         for (int g0 = 0; g0 < nrhs; g0 += chunk) {
             SpmvArgs<T> b = a;
             b.nrhs = (nrhs - g0 < chunk) ? nrhs - g0 : chunk;
@@ -1123,6 +1177,22 @@ template <typename T> static int transpose_impl(int rows, int cols, const void *
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st) {
     if (rows <= 0 || cols <= 0) return CGAMD_OK;
     CG_DISPATCH(dtype, transpose_impl, rows, cols, in, out, st);
+}
+
+template <typename T>
+static int aypx_beta_impl(int n, const void *x, void *y, long long ld, const void *partials, int P, int nrhs,
+                          const CgScalars &sc, bool vec, hipStream_t st) {
+    dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
+    auto *pp = static_cast<const typename VT<T>::acc *>(partials);
+    if (vec) hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.iter);
+    else hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.iter);
+    return check_launch("aypx_beta");
+}
+int launch_aypx_beta(int dtype, int n, const void *x, void *y, long long ld, const void *partials, int P, int nrhs,
+                     const CgScalars &sc, hipStream_t st) {
+    if (n <= 0) return CGAMD_OK;
+    const bool v = vec_ok(dtype, ld, nrhs, {x, y});
+    CG_DISPATCH(dtype, aypx_beta_impl, n, x, y, ld, partials, P, nrhs, sc, v, st);
 }
 
 }  // namespace cgamd

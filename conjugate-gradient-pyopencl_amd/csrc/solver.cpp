@@ -2,12 +2,11 @@
 // helmFE_var.py:507-544) with every scalar kept on the device, no host synchronisation inside the
 // loop, and the per-iteration kernel sequence replayed from a hipGraph.
 //
-// Per iteration (fused, default) -- 5 launches instead of the reference's 6 kernels + 4 blocking copies:
+// Per iteration (fused, default) -- 4 launches instead of the reference's 6 kernels + 4 blocking copies:
 //   spmv+dot   q = A d, partials of d.q                     (clcg.c:299-315)
 //   cg_alpha   alpha = delta / (d.q)                          (clcg.c:317-334, done on the host there)
 //   axpy2_dot  x += alpha d ; r -= alpha q ; partials of r.r (clcg.c:338-374)
-//   cg_beta    beta = delta_new/delta_old ; history           (clcg.c:376-411)
-//   aypx       d = beta d + r                                 (clcg.c:415)
+//   aypx_beta  beta = delta_new/delta_old ; history ; d = beta d + r   (clcg.c:376-415; beta in the prologue)
 // CGAMD_UNFUSED replays the reference's own op structure (spmv, vdot, axpy, axpy, vdot, aypx).
 #include <algorithm>
 #include <cstring>
@@ -70,8 +69,7 @@ static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
         if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
         if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
         if ((rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st))) return rc;
-        if ((rc = launch_cg_beta(dt, s->part_rr, s->vgrid, nr, s->sc, st))) return rc;
-        return launch_aypx(dt, n, s->r, s->d, n, s->sc.beta, nr, st);
+        return launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
     }
     if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, nullptr, nullptr, st))) return rc;
     if ((rc = launch_dot_partials(dt, n, s->d, s->q, n, nr, s->part_rr, s->vgrid, st))) return rc;

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--helm", type=int, default=0, help="use the Helmholtz FE matrix helm_fe_var(N) instead of the 3-D stencil")
     ap.add_argument("cfgs", nargs="*", default=["spmv_variant=0", "spmv_variant=1", "spmv_variant=2"])
     args = ap.parse_args()
     import torch
@@ -32,15 +33,25 @@ def main():
     n = nx * ny * nz
     ctx = pkg.Context(0)
     dev = torch.device("cuda", 0)
-    indptr, indices, data = pkg.generators.laplace3d(ctx, nx, ny, nz, dtype=dtype)
+    if args.helm:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import cg_numpy
+        hp, hx, hd = cg_numpy.helm_fe_var(args.helm, 12.0, np.ones((args.helm - 1, args.helm - 1)), 0.15, args.helm, args.helm)
+        n = args.helm ** 2
+        indptr, indices = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
+        data = torch.from_numpy(hd.astype(dtype)).to(dev)
+    else:
+        indptr, indices, data = pkg.generators.laplace3d(ctx, nx, ny, nz, dtype=dtype)
     nnz = int(indices.numel())
     tdt = pkg.generators.torch_dtype(dtype)
     b = torch.full((n,), 5.0, dtype=tdt, device=dev)
     xs = torch.rand(n, dtype=torch.float64, device=dev).to(tdt)
+    if np.dtype(dtype).kind == "c":
+        b = b * (1 + 0.5j)
     ys = torch.empty(n, dtype=tdt, device=dev)
     torch.cuda.synchronize()
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-    defaults = {"spmv_variant": 5, "spmv_nt": 1, "spmv_grid": 0, "vec_grid": 0, "spmv_far": 1, "spmv_unroll": 8}
+    defaults = {"spmv_variant": 5, "spmv_nt": 1, "spmv_grid": 0, "vec_grid": 0, "spmv_far": 1, "spmv_unroll": 0}
     solvers = []
     for cfg in args.cfgs:
         kv = dict(defaults)
