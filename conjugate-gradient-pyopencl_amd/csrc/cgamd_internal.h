@@ -63,7 +63,9 @@ int vec_grid(long long n_elems_per_rhs, int dtype);
 // laid out partials[r * plan.grid + wg] in accumulator precision.
 int launch_spmv(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr,
                 const int *cols, const void *x, long long ldx, void *y, long long ldy, int nrhs,
-                const void *dvec, void *partials, hipStream_t st);
+                const void *dvec, void *partials, hipStream_t st, const int *rb_list = nullptr, int rb_count = 0);
+// flag[rb] = 1 when row block rb references a column >= n_local (needs the halo); kBlock rows per block
+int launch_halo_flags(int n, const int *ptr, const int *cols, int n_local, int row_blocks, int *flag, hipStream_t st);
 // partial sums of a.b -> partials[r*grid + wg]
 int launch_dot_partials(int dtype, int n, const void *a, const void *b, long long ld, int nrhs, void *partials,
                         int grid, hipStream_t st);

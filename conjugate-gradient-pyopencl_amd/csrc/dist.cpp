@@ -100,6 +100,12 @@ struct cgamd_dist {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     bool graph_failed = false;
+    // overlap of the boundary exchange with the SpMV of the interior row blocks
+    bool overlap = false;
+    int *interior_list = nullptr, *boundary_list = nullptr;   // device
+    int n_interior = 0, n_boundary = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static int dalloc(void **p, size_t bytes, const char *what) {
@@ -140,8 +146,23 @@ static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
     const long long ldx = (long long)d->n_local + d->n_halo;
     char *red = (char *)d->red;
     int rc;
-    if ((rc = exchange(d, d->d_ext, st))) return rc;
-    if ((rc = launch_spmv(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, ldx, d->q, n, 1, d->d_ext, d->part_dq, st))) return rc;
+    if (d->overlap) {
+        // fork: the exchange runs on the comm stream while the row blocks that reference no halo column are
+        // multiplied; the boundary blocks follow once the halo has landed.  Both launches write disjoint
+        // entries of q and of the d.q partials.
+        CG_HIP(hipEventRecord(d->ev_fork, st));
+        CG_HIP(hipStreamWaitEvent(d->comm_stream, d->ev_fork, 0));
+        if ((rc = exchange(d, d->d_ext, d->comm_stream))) return rc;
+        CG_HIP(hipEventRecord(d->ev_join, d->comm_stream));
+        if ((rc = launch_spmv(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, ldx, d->q, n, 1, d->d_ext, d->part_dq, st,
+                              d->interior_list, d->n_interior))) return rc;
+        CG_HIP(hipStreamWaitEvent(st, d->ev_join, 0));
+        if ((rc = launch_spmv(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, ldx, d->q, n, 1, d->d_ext, d->part_dq, st,
+                              d->boundary_list, d->n_boundary))) return rc;
+    } else {
+        if ((rc = exchange(d, d->d_ext, st))) return rc;
+        if ((rc = launch_spmv(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, ldx, d->q, n, 1, d->d_ext, d->part_dq, st))) return rc;
+    }
     if ((rc = launch_reduce_to_acc(dt, d->part_dq, d->plan.n_partials, 1, red, st))) return rc;
     if ((rc = allreduce_scalar(d, red, st))) return rc;
     if ((rc = launch_cg_alpha(dt, red, 1, 1, d->sc, st))) return rc;
@@ -150,6 +171,35 @@ static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
     if ((rc = allreduce_scalar(d, red + 16, st))) return rc;
     if ((rc = launch_cg_beta(dt, red + 16, 1, 1, d->sc, st))) return rc;
     return launch_aypx(dt, n, d->r, d->d_ext, n, d->sc.beta, 1, st);
+}
+
+// classify the row blocks once: boundary = references a halo column
+static int build_overlap_lists(cgamd_dist *d) {
+    const int nb = d->plan.row_blocks;
+    if (d->n_halo == 0 || d->plan.kind != 5 || nb < 16) return CGAMD_OK;
+    int *flags_dev = nullptr;
+    if (int rc = dalloc((void **)&flags_dev, sizeof(int) * (size_t)nb, "halo flags")) return rc;
+    int rc = launch_halo_flags(d->n_local, d->ptr, d->cols, d->n_local, nb, flags_dev, d->ctx->stream);
+    std::vector<int> flags((size_t)nb);
+    hipError_t e = rc ? hipSuccess : hipMemcpyAsync(flags.data(), flags_dev, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, d->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->ctx->stream);
+    (void)hipFree(flags_dev);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("halo flags: ") + hipGetErrorString(e));
+    std::vector<int> interior, boundary;
+    for (int rb = 0; rb < nb; ++rb) (flags[(size_t)rb] ? boundary : interior).push_back(rb);
+    if (boundary.empty() || boundary.size() * 2 > (size_t)nb) return CGAMD_OK;   // nothing to hide it behind
+    if ((rc = dalloc((void **)&d->interior_list, sizeof(int) * interior.size(), "interior list"))) return rc;
+    if ((rc = dalloc((void **)&d->boundary_list, sizeof(int) * boundary.size(), "boundary list"))) return rc;
+    CG_HIP(hipMemcpy(d->interior_list, interior.data(), sizeof(int) * interior.size(), hipMemcpyHostToDevice));
+    CG_HIP(hipMemcpy(d->boundary_list, boundary.data(), sizeof(int) * boundary.size(), hipMemcpyHostToDevice));
+    d->n_interior = (int)interior.size();
+    d->n_boundary = (int)boundary.size();
+    CG_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+    CG_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+    CG_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+    d->overlap = true;
+    return CGAMD_OK;
 }
 
 static int ensure_history(cgamd_dist *d, int entries) {
@@ -196,7 +246,7 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
         return fail(CGAMD_ERR_INVALID, "dist_create: local problem exceeds int32 indexing");
     if (!aValues || !aPointers || !aCols) return fail(CGAMD_ERR_INVALID, "dist_create: null matrix pointer");
     if (n_peers > 0 && (!peer_rank || !send_count || !recv_count)) return fail(CGAMD_ERR_INVALID, "dist_create: null plan arrays");
-    if (nranks > 1 && !id128) return fail(CGAMD_ERR_INVALID, "dist_create: a communicator id is required for nranks > 1");
+    if ((nranks > 1 || n_peers > 0) && !id128) return fail(CGAMD_ERR_INVALID, "dist_create: a communicator id is required when there are peers");
     CG_HIP(hipSetDevice(ctx->device));
 
     cgamd_dist *d = new cgamd_dist();
@@ -206,7 +256,7 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     d->vgrid = vec_grid(n_local, dtype);
     long long so = 0, ro = 0;
     for (int p = 0; p < n_peers; ++p) {
-        if (peer_rank[p] < 0 || peer_rank[p] >= nranks || peer_rank[p] == rank || send_count[p] < 0 || recv_count[p] < 0) {
+        if (peer_rank[p] < 0 || peer_rank[p] >= nranks || send_count[p] < 0 || recv_count[p] < 0) {
             delete d;
             return fail(CGAMD_ERR_INVALID, "dist_create: bad peer entry");
         }
@@ -250,6 +300,9 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
             if (r != ncclSuccess) rc = fail(CGAMD_ERR_COMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
         }
     }
+    // hipGraph capture of the two-stream fork/join around RCCL send/recv crashed in the runtime (ROCm 7.0/7.2,
+    // RCCL 2.26): the graph mode therefore runs the exchange in line, the plain-launch mode overlaps it.
+    if (!rc && !(flags & (CGAMD_DIST_NO_OVERLAP | CGAMD_DIST_GRAPH)) && d->comm) rc = build_overlap_lists(d);
     if (rc) {
         std::string keep = cgamd_last_error();
         cgamd_dist_destroy(d);
@@ -267,6 +320,11 @@ int cgamd_dist_destroy(cgamd_dist *d) {
     if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
     if (d->graph) (void)hipGraphDestroy(d->graph);
     if (d->comm) (void)g_rccl.CommDestroy(d->comm);
+    if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
+    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+    if (d->ev_join) (void)hipEventDestroy(d->ev_join);
+    if (d->interior_list) (void)hipFree(d->interior_list);
+    if (d->boundary_list) (void)hipFree(d->boundary_list);
     void *bufs[] = {d->x, d->r, d->q, d->b, d->d_ext, d->sendbuf, d->part_dq, d->part_rr, d->red, d->sc.alpha,
                     d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter};
     for (void *p : bufs)

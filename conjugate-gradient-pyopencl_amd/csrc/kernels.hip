@@ -89,6 +89,8 @@ template <typename T> struct SpmvArgs {
     const T *dvec;                  // fused dot: sum dvec[row] * y[row]
     typename VT<T>::acc *partials;  // [nrhs][grid]
     int row_blocks;
+    const int *rb_list;             // row-block kernel: optional explicit list of row blocks (multi-GPU interior / boundary split)
+    int rb_count;
     int cap;   // row-block kernel: LDS slice capacity in entries (multiple of 4)
     int far;   // row-block kernel: schedule interleave stride in row blocks (1 = none)
 };
@@ -282,12 +284,15 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     __shared__ A red[BLOCK / kWave];
 
     const int t = threadIdx.x;
-    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-    const int xb = (int)((long long)xcd * a.row_blocks / 8), xe = (int)((long long)(xcd + 1) * a.row_blocks / 8);
-    const int m = xe - xb;
-    if (i >= m) return;
     int rb;
-    {
+    if (a.rb_list) {                       // explicit subset (interior or boundary row blocks of a partition)
+        if ((int)blockIdx.x >= a.rb_count) return;
+        rb = a.rb_list[blockIdx.x];
+    } else {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int xb = (int)((long long)xcd * a.row_blocks / 8), xe = (int)((long long)(xcd + 1) * a.row_blocks / 8);
+        const int m = xe - xb;
+        if (i >= m) return;
         const int S = min(max(a.far, 1), m), q = m / S, rem = m % S;
         int y, z;
         if (i < rem * (q + 1)) { y = i / (q + 1); z = i % (q + 1); }
@@ -520,6 +525,19 @@ __global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, cons
     __syncthreads();
     for (int k = ty; k < 32; k += 8)
         if (bx + k < cols && by + tx < rows) out[(long long)(bx + k) * rows + by + tx] = tile[tx][k];
+}
+
+// flag[rb] = 1 if any entry of row block rb references a halo column (col >= n_local): the blocks that must wait
+// for the boundary exchange in the row-partitioned loop
+template <int BLOCK> __global__ void rowblock_halo_flag_kernel(int n, const int *__restrict__ ptr, const int *__restrict__ cols,
+                                                                int n_local, int row_blocks, int *flag) {
+    const int rb = blockIdx.x;
+    if (rb >= row_blocks) return;
+    const int p0 = ptr[rb * BLOCK], p1 = ptr[min(rb * BLOCK + BLOCK, n)];
+    int any = 0;
+    for (int j = p0 + (int)threadIdx.x; j < p1; j += blockDim.x) any |= cols[j] >= n_local;
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) flag[rb] = any ? 1 : 0;
 }
 
 // largest (4-aligned) non-zero span of any BLOCK-row slice: decides whether the fast path applies
@@ -893,7 +911,7 @@ Tuning g_tune;
 template <typename T>
 static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
                      const void *x, long long ldx, void *y, long long ldy, int nrhs, const void *dvec, void *partials,
-                     hipStream_t st) {
+                     const int *rb_list, int rb_count, hipStream_t st) {
     SpmvArgs<T> a;
     a.n = n; a.nrhs = nrhs; a.nnz = nnz;
     a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
@@ -902,6 +920,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     a.dvec = static_cast<const T *>(dvec);
     a.partials = static_cast<typename VT<T>::acc *>(partials);
     a.row_blocks = plan.row_blocks;
+    a.rb_list = rb_list; a.rb_count = rb_count;
     const bool vec = aligned16(vals) && aligned16(cols);
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
@@ -916,7 +935,8 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
             const int m = (int)((long long)(x + 1) * plan.row_blocks / 8) - (int)((long long)x * plan.row_blocks / 8);
             per_xcd = m > per_xcd ? m : per_xcd;
         }
-        dim3 g5(per_xcd * 8);
+        dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : per_xcd * 8);
+        if (rb_list && rb_count <= 0) return CGAMD_OK;
         const bool nt = g_tune.spmv_nt != 0;
 #define CG_RB(NT, UNR)                                                                                           \
     do {                                                                                                         \
@@ -997,11 +1017,17 @@ void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, const void *vals, c
     plan->n_partials = kind ? plan->row_blocks : plan->grid;
 }
 
+int launch_halo_flags(int n, const int *ptr, const int *cols, int n_local, int row_blocks, int *flag, hipStream_t st) {
+    hipLaunchKernelGGL((rowblock_halo_flag_kernel<kBlock>), dim3(row_blocks), dim3(256), 0, st, n, ptr, cols, n_local, row_blocks, flag);
+    return check_launch("halo_flags");
+}
+
 int launch_spmv(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr,
                 const int *cols, const void *x, long long ldx, void *y, long long ldy, int nrhs, const void *dvec,
-                void *partials, hipStream_t st) {
+                void *partials, hipStream_t st, const int *rb_list, int rb_count) {
     if (n <= 0) return CGAMD_OK;
-    CG_DISPATCH(dtype, spmv_impl, plan, n, nnz, vals, ptr, cols, x, ldx, y, ldy, nrhs, dvec, partials, st);
+    if (rb_list && !(plan.kind == 5 && nrhs == 1)) return fail(CGAMD_ERR_INVALID, "spmv: row-block lists need the row-block kernel");
+    CG_DISPATCH(dtype, spmv_impl, plan, n, nnz, vals, ptr, cols, x, ldx, y, ldy, nrhs, dvec, partials, rb_list, rb_count, st);
 }
 
 static bool vec_ok(int dtype, long long ld, int nrhs, std::initializer_list<const void *> ptrs) {

@@ -189,8 +189,8 @@ class DistSolver:
         sc = np.asarray(plan.send_counts, dtype=np.int32)
         rc = np.asarray(plan.recv_counts, dtype=np.int32)
         self._keep = (indptr_local, values, plan.cols_local, plan.send_index, peers, sc, rc)
-        if plan.world > 1 and unique_id is None:
-            raise ValueError("unique_id is required when world > 1")
+        if (plan.world > 1 or plan.peers) and unique_id is None:
+            raise ValueError("unique_id is required when there are peers")
         idbuf = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)
         torch.cuda.synchronize()
         h = ctypes.c_void_p()

@@ -97,6 +97,7 @@ int cgamd_sub(cgamd_ctx *ctx, int dtype, int size, const void *a, const void *b,
 #define CGAMD_MATRIX_ON_DEVICE 1   /* aValues/aPointers/aCols are device pointers, borrowed (not copied) */
 #define CGAMD_NO_GRAPH 2           /* plain stream launches instead of hipGraph replay */
 #define CGAMD_UNFUSED 4            /* reference op structure: spmv, vdot, axpy, axpy, vdot, aypx (6 kernels) */
+#define CGAMD_DIST_NO_OVERLAP 32    /* cgamd_dist_create: exchange first, then one SpMV (no interior/boundary overlap) */
 #define CGAMD_DIST_GRAPH 8         /* cgamd_dist_create: replay each iteration (incl. RCCL ops) from a hipGraph */
 
 int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, const void *aValues,
@@ -157,6 +158,8 @@ void cgamd_mm_free(void *p);
  * See DESIGN.md "Multi-GPU" for the plan layout. */
 typedef struct cgamd_dist cgamd_dist;
 int cgamd_comm_unique_id(void *id128);      /* rank 0: 128 bytes to broadcast */
+/* A peer may be the rank itself (periodic coupling inside one partition; also how a single GPU exercises the
+ * exchange): its send list is then gathered into its own halo slots through ncclSend/ncclRecv to self. */
 int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, int dtype,
                       int n_local, int n_halo, long long nnz_local, const void *aValues,
                       const int *aPointers, const int *aCols, /* device, cols in [0,n_local+n_halo) */

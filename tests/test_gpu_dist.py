@@ -88,3 +88,42 @@ def test_device_generators_match_oracle_generators(pkg, gpu):
     ip, ix, da = cg_numpy.poisson2d(13)
     assert np.array_equal(ipd.cpu().numpy(), ip) and np.array_equal(ixd.cpu().numpy(), ix)
     assert np.array_equal(dad.cpu().numpy(), da)
+
+
+@pytest.mark.parametrize("flags", ["overlap", "no_overlap", "graph"])
+def test_exchange_and_overlap_through_self_halo(pkg, gpu, flags):
+    """One GPU cannot host two RCCL ranks, but a rank may be its own peer: the columns < h referenced by rows >= h
+    are routed through halo slots that the rank fills from its own first h entries with ncclSend/ncclRecv to
+    self.  The product is unchanged, so the run must reproduce the plain single-GPU solver -- while exercising
+    pack, grouped send/recv, the interior/boundary row-block split on two streams (plain launches) and the
+    hipGraph replay of the in-line exchange."""
+    import torch
+    ctx, queue, kernels = gpu
+    dmod = importlib.import_module(PKG_NAME + ".dist")
+    lib = pkg._lib.load()
+    nx, ny, nz = 20, 20, 30
+    ip, ix, da = cg_numpy.laplace3d(nx, ny, nz)
+    n, h = nx * ny * nz, nx * ny
+    rows = np.repeat(np.arange(n), np.diff(ip))
+    route = (ix < h) & (rows >= h)
+    assert route.sum() == h                      # exactly the plane below
+    cols_local = np.where(route, n + ix, ix).astype(np.int32)
+    dev = torch.device("cuda", 0)
+    plan = dmod.HaloPlan(0, 1, 0, n, n, h, torch.from_numpy(cols_local).to(dev), torch.arange(h), [0], [h], [h],
+                         torch.arange(h, dtype=torch.int32, device=dev))
+    buf = np.zeros(128, dtype=np.uint8)
+    pkg._lib.check(lib.cgamd_comm_unique_id(pkg._lib.ptr(buf)))
+    fl = {"overlap": 0, "no_overlap": pkg._lib.DIST_NO_OVERLAP, "graph": pkg._lib.DIST_GRAPH}[flags]
+    vals, indptr = torch.from_numpy(da).to(dev), torch.from_numpy(ip).to(dev)
+    s = dmod.DistSolver(ctx, plan, indptr, vals, np.float64, unique_id=buf, flags=fl)
+    b = np.linspace(1.0, 2.0, n)
+    bl = torch.from_numpy(b).to(dev)
+    iters = 30
+    s.set_rhs(bl, None)
+    s.iterate(iters)
+    x = s.x(torch.empty(n, dtype=torch.float64, device=dev)).cpu().numpy()
+    hist = s.history()
+    s.close()
+    xo, ho = cg_oracle.cg(ip, ix, da, b, n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
+    assert np.max(np.abs(hist - ho[:, 0]) / np.abs(ho[:, 0])) < 1e-10
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-9

@@ -127,3 +127,73 @@ def test_spmm_mfma_rowmajor_matches_oracle(pkg, gpu, dtype, n, avg, nrhs):
     import scipy.sparse as sp
     scale = (np.abs(sp.csr_matrix((np.abs(data), indices, indptr), shape=(n, n))) @ np.abs(X.reshape(nrhs, n).T)).T.reshape(-1) + 1e-30
     assert np.max(np.abs(got - want) / scale) < RTOL[np.dtype(dtype)]
+
+
+def test_unaligned_pointers_take_the_scalar_paths(pkg, gpu):
+    """device pointers that are only 8-byte aligned (e.g. views into a larger allocation) must still be correct:
+    the 16-byte-load kernels are replaced by their scalar forms (VEC = false / generic SpMV)"""
+    import ctypes
+    ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
+    rng = np.random.default_rng(8)
+    n, nrhs = 1003, 2
+    dtype = np.float64
+    indptr, indices, data = rand_csr(rng, n, 6, dtype, empty_rows=True)
+    x, y = rand_vec(rng, n * nrhs, dtype), rand_vec(rng, n * nrhs, dtype)
+    a = rand_vec(rng, nrhs, dtype)
+
+    def shifted(arr, off_bytes):
+        big = pkg.DeviceBuffer(ctx, nbytes=arr.nbytes + 64, dtype=arr.dtype)
+        pkg._lib.check(lib.cgamd_memcpy_h2d(ctx.handle, ctypes.c_void_p(big.ptr + off_bytes), pkg._lib.ptr(arr), arr.nbytes))
+        return big, big.ptr + off_bytes
+
+    keep = []
+    def dev(arr, off):
+        b, p = shifted(np.ascontiguousarray(arr), off)
+        keep.append(b)
+        return p
+    pv, pc, pp = dev(data, 8), dev(indices, 4), dev(indptr, 0)
+    px, py, pa = dev(x, 8), dev(y, 8), dev(a, 0)
+    pkg._lib.check(lib.cgamd_spmv(ctx.handle, 1, n, len(indices), ctypes.c_void_p(pv), ctypes.c_void_p(pp), ctypes.c_void_p(pc),
+                                  ctypes.c_void_p(px), ctypes.c_void_p(py), nrhs))
+    got = np.empty(n * nrhs, dtype=dtype)
+    pkg._lib.check(lib.cgamd_memcpy_d2h(ctx.handle, pkg._lib.ptr(got), ctypes.c_void_p(py), got.nbytes))
+    want = cg_oracle.spmv(indptr, indices, data, x, nrhs=nrhs, mode=cg_oracle.MODE_SEQUENTIAL)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    # axpy / vdot on misaligned vectors with an odd leading dimension
+    py2 = dev(y, 8)
+    pkg._lib.check(lib.cgamd_axpy(ctx.handle, 1, n, ctypes.c_void_p(px), ctypes.c_void_p(py2), ctypes.c_void_p(pa), 1, nrhs))
+    pkg._lib.check(lib.cgamd_memcpy_d2h(ctx.handle, pkg._lib.ptr(got), ctypes.c_void_p(py2), got.nbytes))
+    assert np.allclose(got, cg_oracle.axpy(x, y, a, 1, nrhs=nrhs), rtol=1e-13)
+    res = pkg.DeviceBuffer(ctx, hostbuf=np.zeros(nrhs, dtype=dtype))
+    pkg._lib.check(lib.cgamd_vdot(ctx.handle, 1, n, ctypes.c_void_p(px), ctypes.c_void_p(py2), ctypes.c_void_p(res.ptr), nrhs))
+    wd = [np.dot(x[r * n:(r + 1) * n], got[r * n:(r + 1) * n]) for r in range(nrhs)]
+    assert np.allclose(res.get(), wd, rtol=1e-12)
+    # a solver on a borrowed, misaligned device matrix falls back to the generic kernel and stays correct
+    s = pkg.Solver(ctx, n, len(indices), pv, pp, pc, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=dtype)
+    b = rand_vec(rng, n, dtype)
+    A_ok = None
+    xs, h = s.solve(b, None, 5)
+    s.close()
+    xo, ho = cg_oracle.cg(indptr, indices, data, b, n_iterations=5, mode=cg_oracle.MODE_SEQUENTIAL)
+    # (random non-symmetric matrix: the recurrence diverges and amplifies rounding, compare the first steps)
+    assert np.allclose(h[:4, 0], ho[:4, 0], rtol=1e-9)
+
+
+def test_error_reporting_on_gpu(pkg, gpu):
+    ctx, queue, kernels = gpu
+    ip = np.array([0, 2, 1], dtype=np.int32)        # not monotone
+    with pytest.raises(pkg.CgAmdError) as e:
+        pkg.Solver(ctx, 2, 1, np.ones(1), ip, np.zeros(1, dtype=np.int32), 1)
+    assert e.value.status == 1 and "monotone" in str(e.value)
+    ip = np.array([0, 1, 2], dtype=np.int32)
+    with pytest.raises(pkg.CgAmdError) as e:
+        pkg.Solver(ctx, 2, 2, np.ones(2), ip, np.array([0, 5], dtype=np.int32), 1)     # column out of range
+    assert "out of range" in str(e.value)
+    s = pkg.Solver(ctx, 2, 2, np.ones(2), ip, np.array([0, 1], dtype=np.int32), 1)
+    with pytest.raises(pkg.CgAmdError) as e:
+        s.iterate(1)                                                                   # before set_rhs
+    assert e.value.status == 7
+    with pytest.raises(pkg.CgAmdError):
+        s.spmm_rowmajor(s.vector("x"), s.vector("r"), 8)                               # nRHS must be 16 or 32
+    s.close()
