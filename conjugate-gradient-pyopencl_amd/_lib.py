@@ -17,7 +17,7 @@ DTYPE_CODE = {np.dtype(np.float32): F32, np.dtype(np.float64): F64,
               np.dtype(np.complex64): C64, np.dtype(np.complex128): C128}
 CODE_DTYPE = {v: k for k, v in DTYPE_CODE.items()}
 
-MATRIX_ON_DEVICE, NO_GRAPH, UNFUSED, DIST_GRAPH, DIST_NO_OVERLAP = 1, 2, 4, 8, 32
+MATRIX_ON_DEVICE, NO_GRAPH, UNFUSED, DIST_GRAPH, DIST_NO_OVERLAP, DIST_P2P = 1, 2, 4, 8, 32, 64
 
 
 class CgAmdError(RuntimeError):
@@ -103,6 +103,10 @@ def load():
         "cgamd_dist_get_x": (ci, [vp, vp]),
         "cgamd_dist_history": (ci, [vp, vp, ci]),
         "cgamd_dist_synchronize": (ci, [vp]),
+        "cgamd_p2p_mailbox_alloc": (ci, [vp, ll, ci, pvp, vp]),
+        "cgamd_p2p_mailbox_free": (ci, [vp, vp]),
+        "cgamd_dist_attach_p2p": (ci, [vp, vp, vp, vp]),
+        "cgamd_dist_p2p_error": (ci, [vp]),
         # legacy entry, reference clcg.h:3-5
         "cg": (vp, [ci, ci, vp, vp, vp, vp, vp, ci, ci, ci]),
     }

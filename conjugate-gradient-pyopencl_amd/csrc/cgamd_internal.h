@@ -109,6 +109,21 @@ int launch_spmm_mfma(int dtype, const SpmvPlan &plan, int n, long long nnz, cons
                      const int *cols, const void *x, void *y, int nrhs, hipStream_t st);
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);
 
+// ---- peer-to-peer backend (kernels.hip "Peer-to-peer communication over xGMI") ----------------------------
+constexpr size_t kMailboxHeader = 8192;   // slots + flags + error word; halo entries follow
+struct P2pExchange {
+    char *const *mailbox = nullptr;   // device array [nranks] of mapped mailbox bases
+    int rank = 0, n_peers = 0, n_local = 0;
+    const int *peer_rank = nullptr, *send_off = nullptr, *send_count = nullptr, *dst_off = nullptr, *recv_off = nullptr,
+              *recv_count = nullptr;  // device arrays [n_peers]
+    const int *send_index = nullptr;
+    unsigned long long *epoch = nullptr;
+};
+int launch_p2p_exchange(int dtype, const P2pExchange &e, void *v_ext, hipStream_t st);
+// out = sum over ranks (in rank order) of the local sum of `partials`; which in {0,1} selects the slot set
+int launch_p2p_allreduce(int dtype, const void *partials, int grid, char *const *mailbox, int rank, int nranks, int which,
+                         unsigned long long *epoch, void *out, hipStream_t st);
+
 // synthetic generators (device)
 int launch_gen_laplace3d(int dtype, int nx, int ny, int nz, long long row_begin, long long row_end, void *vals,
                          int *ptr, int *cols, hipStream_t st);

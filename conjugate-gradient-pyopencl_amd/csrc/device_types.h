@@ -73,6 +73,13 @@ template <> CG_DEV double from_acc<double>(double a) { return a; }
 template <> CG_DEV float2 from_acc<float2>(double2 a) { return make_float2((float)a.x, (float)a.y); }
 template <> CG_DEV double2 from_acc<double2>(double2 a) { return a; }
 
+// accumulator <-> (x, y) pair, for type-agnostic transport of real and complex sums
+CG_DEV double2 to_acc2(double a) { return make_double2(a, 0.); }
+CG_DEV double2 to_acc2(double2 a) { return a; }
+template <typename A> CG_DEV A from_acc2(double2 a);
+template <> CG_DEV double from_acc2<double>(double2 a) { return a.x; }
+template <> CG_DEV double2 from_acc2<double2>(double2 a) { return a; }
+
 // scalar division used for alpha = delta/dq and beta = delta_new/delta_old
 // (reference clcg.c:326-327,389-391).  Complex: Smith's algorithm, as C99 / numpy do.
 CG_DEV double acc_div(double a, double b) { return a / b; }

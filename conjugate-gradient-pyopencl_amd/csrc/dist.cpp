@@ -100,6 +100,14 @@ struct cgamd_dist {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     bool graph_failed = false;
+    // peer-to-peer backend (no RCCL): uncached IPC mailboxes written directly by the peers over xGMI
+    bool p2p = false, p2p_attached = false;
+    char *my_mailbox = nullptr;
+    std::vector<void *> opened;            // mappings to close
+    char **mailbox_dev = nullptr;          // device array [nranks]
+    int *plan_dev = nullptr;               // device: peer_rank, send_off, send_count, dst_off, recv_off, recv_count
+    unsigned long long *epochs = nullptr;  // device: [0] exchange, [1] reduce slot 0, [2] reduce slot 1
+    P2pExchange xch;
     // overlap of the boundary exchange with the SpMV of the interior row blocks
     bool overlap = false;
     int *interior_list = nullptr, *boundary_list = nullptr;   // device
@@ -120,6 +128,10 @@ static size_t elem_mult(int dtype) { return (dtype == CGAMD_C64 || dtype == CGAM
 // boundary exchange of `v_ext[0:n_local]` into `v_ext[n_local:]` of the neighbours
 static int exchange(cgamd_dist *d, void *v_ext, hipStream_t st) {
     if (d->peer.empty()) return CGAMD_OK;
+    if (d->p2p) {
+        if (!d->p2p_attached) return fail(CGAMD_ERR_STATE, "p2p backend: call cgamd_dist_attach_p2p first");
+        return launch_p2p_exchange(d->dtype, d->xch, v_ext, st);
+    }
     const size_t vs = dtype_size(d->dtype), em = elem_mult(d->dtype);
     if (int rc = launch_pack(d->dtype, d->total_send, d->send_index, v_ext, d->sendbuf, st)) return rc;
     CG_NCCL(g_rccl.GroupStart());
@@ -139,6 +151,16 @@ static int allreduce_scalar(cgamd_dist *d, void *acc, hipStream_t st) {
     if (!d->comm) return CGAMD_OK;
     CG_NCCL(g_rccl.AllReduce(acc, acc, acc_size(d->dtype) / 8, ncclDouble, ncclSum, d->comm, st));
     return CGAMD_OK;
+}
+
+// partials -> global sum in accumulator precision at `out` (device): RCCL all-reduce or the mailbox protocol
+static int reduce_all(cgamd_dist *d, const void *partials, int count, int which, void *out, hipStream_t st) {
+    if (d->p2p) {
+        if (!d->p2p_attached) return fail(CGAMD_ERR_STATE, "p2p backend: call cgamd_dist_attach_p2p first");
+        return launch_p2p_allreduce(d->dtype, partials, count, d->mailbox_dev, d->rank, d->nranks, which, d->epochs + 1 + which, out, st);
+    }
+    if (int rc = launch_reduce_to_acc(d->dtype, partials, count, 1, out, st)) return rc;
+    return allreduce_scalar(d, out, st);
 }
 
 static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
@@ -163,12 +185,10 @@ static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
         if ((rc = exchange(d, d->d_ext, st))) return rc;
         if ((rc = launch_spmv(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, ldx, d->q, n, 1, d->d_ext, d->part_dq, st))) return rc;
     }
-    if ((rc = launch_reduce_to_acc(dt, d->part_dq, d->plan.n_partials, 1, red, st))) return rc;
-    if ((rc = allreduce_scalar(d, red, st))) return rc;
+    if ((rc = reduce_all(d, d->part_dq, d->plan.n_partials, 0, red, st))) return rc;
     if ((rc = launch_cg_alpha(dt, red, 1, 1, d->sc, st))) return rc;
     if ((rc = launch_axpy2_dot(dt, n, d->d_ext, d->x, d->q, d->r, n, d->sc.alpha, 1, d->part_rr, d->vgrid, st))) return rc;
-    if ((rc = launch_reduce_to_acc(dt, d->part_rr, d->vgrid, 1, red + 16, st))) return rc;
-    if ((rc = allreduce_scalar(d, red + 16, st))) return rc;
+    if ((rc = reduce_all(d, d->part_rr, d->vgrid, 1, red + 16, st))) return rc;
     if ((rc = launch_cg_beta(dt, red + 16, 1, 1, d->sc, st))) return rc;
     return launch_aypx(dt, n, d->r, d->d_ext, n, d->sc.beta, 1, st);
 }
@@ -246,12 +266,14 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
         return fail(CGAMD_ERR_INVALID, "dist_create: local problem exceeds int32 indexing");
     if (!aValues || !aPointers || !aCols) return fail(CGAMD_ERR_INVALID, "dist_create: null matrix pointer");
     if (n_peers > 0 && (!peer_rank || !send_count || !recv_count)) return fail(CGAMD_ERR_INVALID, "dist_create: null plan arrays");
-    if ((nranks > 1 || n_peers > 0) && !id128) return fail(CGAMD_ERR_INVALID, "dist_create: a communicator id is required when there are peers");
+    if ((nranks > 1 || n_peers > 0) && !id128 && !(flags & CGAMD_DIST_P2P))
+        return fail(CGAMD_ERR_INVALID, "dist_create: a communicator id (or CGAMD_DIST_P2P) is required when there are peers");
     CG_HIP(hipSetDevice(ctx->device));
 
     cgamd_dist *d = new cgamd_dist();
     d->ctx = ctx; d->dtype = dtype; d->rank = rank; d->nranks = nranks; d->n_local = n_local; d->n_halo = n_halo;
     d->nnz = nnz_local; d->vals = aValues; d->ptr = aPointers; d->cols = aCols; d->flags = flags;
+    d->p2p = (flags & CGAMD_DIST_P2P) != 0;
     d->plan = make_spmv_plan(n_local);
     d->vgrid = vec_grid(n_local, dtype);
     long long so = 0, ro = 0;
@@ -291,7 +313,7 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     if (!rc) rc = ensure_history(d, 1024);
     if (!rc) rc = compute_spmv_plan(d->ptr, d->cols, n_local, d->sc.iter, ctx->stream, &d->plan);
     if (!rc) finalize_spmv_plan(&d->plan, dtype, 1, d->vals, d->cols);
-    if (!rc && id128) {
+    if (!rc && id128 && !d->p2p) {
         rc = need_rccl();
         if (!rc) {
             ncclUniqueId id;
@@ -302,7 +324,7 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     }
     // hipGraph capture of the two-stream fork/join around RCCL send/recv crashed in the runtime (ROCm 7.0/7.2,
     // RCCL 2.26): the graph mode therefore runs the exchange in line, the plain-launch mode overlaps it.
-    if (!rc && !(flags & (CGAMD_DIST_NO_OVERLAP | CGAMD_DIST_GRAPH)) && d->comm) rc = build_overlap_lists(d);
+    if (!rc && !(flags & (CGAMD_DIST_NO_OVERLAP | CGAMD_DIST_GRAPH)) && (d->comm || d->p2p)) rc = build_overlap_lists(d);
     if (rc) {
         std::string keep = cgamd_last_error();
         cgamd_dist_destroy(d);
@@ -320,6 +342,10 @@ int cgamd_dist_destroy(cgamd_dist *d) {
     if (d->gexec) (void)hipGraphExecDestroy(d->gexec);
     if (d->graph) (void)hipGraphDestroy(d->graph);
     if (d->comm) (void)g_rccl.CommDestroy(d->comm);
+    for (void *m : d->opened) (void)hipIpcCloseMemHandle(m);
+    if (d->mailbox_dev) (void)hipFree(d->mailbox_dev);
+    if (d->plan_dev) (void)hipFree(d->plan_dev);
+    if (d->epochs) (void)hipFree(d->epochs);
     if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
     if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
     if (d->ev_join) (void)hipEventDestroy(d->ev_join);
@@ -351,8 +377,7 @@ int cgamd_dist_set_rhs(cgamd_dist *d, const void *b_local, const void *x0_local)
     if ((rc = launch_sub(d->dtype, d->n_local, d->b, d->q, d->r, d->n_local, 1, st))) return rc;
     CG_HIP(hipMemcpyAsync(d->d_ext, d->r, vb, hipMemcpyDeviceToDevice, st));
     if ((rc = launch_dot_partials(d->dtype, d->n_local, d->r, d->r, d->n_local, 1, d->part_rr, d->vgrid, st))) return rc;
-    if ((rc = launch_reduce_to_acc(d->dtype, d->part_rr, d->vgrid, 1, (char *)d->red + 16, st))) return rc;
-    if ((rc = allreduce_scalar(d, (char *)d->red + 16, st))) return rc;
+    if ((rc = reduce_all(d, d->part_rr, d->vgrid, 1, (char *)d->red + 16, st))) return rc;
     if ((rc = launch_cg_delta0(d->dtype, (char *)d->red + 16, 1, 1, d->sc, st))) return rc;
     d->rhs_set = true;
     d->iters = 0;
@@ -410,6 +435,84 @@ int cgamd_dist_synchronize(cgamd_dist *d) {
     CG_HIP(hipSetDevice(d->ctx->device));
     CG_HIP(hipStreamSynchronize(d->ctx->stream));
     return CGAMD_OK;
+}
+
+// ---- peer-to-peer backend: mailbox allocation and attachment -------------------------------------------
+int cgamd_p2p_mailbox_alloc(cgamd_ctx *ctx, long long halo_values, int dtype, void **mailbox, void *handle64) {
+    if (!ctx || !mailbox || !handle64 || halo_values < 0 || dtype < 0 || dtype > 3) return fail(CGAMD_ERR_INVALID, "p2p_mailbox_alloc: bad argument");
+    CG_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = kMailboxHeader + (size_t)halo_values * dtype_size(dtype) + 256;
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) return fail(CGAMD_ERR_ALLOC, std::string("hipExtMallocWithFlags(uncached mailbox): ") + hipGetErrorString(e));
+    CG_HIP(hipMemset(p, 0, bytes));
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) { (void)hipFree(p); return fail(CGAMD_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e)); }
+    static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
+    memcpy(handle64, &h, 64);
+    *mailbox = p;
+    return CGAMD_OK;
+}
+
+int cgamd_p2p_mailbox_free(cgamd_ctx *ctx, void *mailbox) {
+    if (!ctx) return fail(CGAMD_ERR_INVALID, "p2p_mailbox_free: ctx is NULL");
+    CG_HIP(hipSetDevice(ctx->device));
+    if (mailbox) CG_HIP(hipFree(mailbox));
+    return CGAMD_OK;
+}
+
+int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, const int *dst_offset) {
+    if (!d || !my_mailbox || !handles) return fail(CGAMD_ERR_INVALID, "dist_attach_p2p: null argument");
+    if (!d->p2p) return fail(CGAMD_ERR_STATE, "dist_attach_p2p: the handle was not created with CGAMD_DIST_P2P");
+    if (d->nranks > 64) return fail(CGAMD_ERR_INVALID, "dist_attach_p2p: at most 64 ranks");
+    const int np = (int)d->peer.size();
+    if (np > 0 && !dst_offset) return fail(CGAMD_ERR_INVALID, "dist_attach_p2p: dst_offset is NULL");
+    CG_HIP(hipSetDevice(d->ctx->device));
+    d->my_mailbox = static_cast<char *>(my_mailbox);
+    std::vector<char *> base((size_t)d->nranks, nullptr);
+    for (int r = 0; r < d->nranks; ++r) {
+        if (r == d->rank) { base[(size_t)r] = d->my_mailbox; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, static_cast<const char *>(handles) + (size_t)r * 64, 64);
+        void *m = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(CGAMD_ERR_COMM, "hipIpcOpenMemHandle(rank " + std::to_string(r) + "): " + hipGetErrorString(e));
+        d->opened.push_back(m);
+        base[(size_t)r] = static_cast<char *>(m);
+    }
+    int rc;
+    if ((rc = dalloc((void **)&d->mailbox_dev, sizeof(char *) * (size_t)d->nranks, "mailbox table"))) return rc;
+    CG_HIP(hipMemcpy(d->mailbox_dev, base.data(), sizeof(char *) * (size_t)d->nranks, hipMemcpyHostToDevice));
+    if ((rc = dalloc((void **)&d->epochs, 64, "epochs"))) return rc;
+    CG_HIP(hipMemset(d->epochs, 0, 64));
+    std::vector<int> plan((size_t)np * 6 + 1, 0);
+    for (int p = 0; p < np; ++p) {
+        plan[(size_t)p] = d->peer[(size_t)p];
+        plan[(size_t)np + p] = d->send_off[(size_t)p];
+        plan[(size_t)2 * np + p] = d->send_count[(size_t)p];
+        plan[(size_t)3 * np + p] = dst_offset[p];
+        plan[(size_t)4 * np + p] = d->recv_off[(size_t)p];
+        plan[(size_t)5 * np + p] = d->recv_count[(size_t)p];
+    }
+    if ((rc = dalloc((void **)&d->plan_dev, sizeof(int) * plan.size(), "p2p plan"))) return rc;
+    CG_HIP(hipMemcpy(d->plan_dev, plan.data(), sizeof(int) * plan.size(), hipMemcpyHostToDevice));
+    P2pExchange &x = d->xch;
+    x.mailbox = d->mailbox_dev; x.rank = d->rank; x.n_peers = np; x.n_local = d->n_local;
+    x.peer_rank = d->plan_dev; x.send_off = d->plan_dev + np; x.send_count = d->plan_dev + 2 * np;
+    x.dst_off = d->plan_dev + 3 * np; x.recv_off = d->plan_dev + 4 * np; x.recv_count = d->plan_dev + 5 * np;
+    x.send_index = d->send_index; x.epoch = d->epochs;
+    d->p2p_attached = true;
+    return CGAMD_OK;
+}
+
+// 0 = fine; != 0: a bounded spin of the peer-to-peer protocol timed out (1 boundary exchange, 2 all-reduce)
+int cgamd_dist_p2p_error(cgamd_dist *d) {
+    if (!d || !d->p2p || !d->my_mailbox) return 0;
+    unsigned long long w = 0;
+    if (hipSetDevice(d->ctx->device) != hipSuccess) return -1;
+    if (hipMemcpy(&w, d->my_mailbox + 6144, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)w;
 }
 
 }  // extern "C"

@@ -799,6 +799,124 @@ __global__ __launch_bounds__(256) void pack_kernel(int count, const int *__restr
 }
 
 // =================================================================================================
+// Peer-to-peer communication over xGMI without RCCL (optional backend of the row-partitioned loop).
+// RCCL's latency (10-20 us per small collective) bounds strong scaling of a 40 us iteration; here each rank owns
+// an UNCACHED, IPC-shared "mailbox" that its peers write directly:
+//     [0,4096)      reduction slots  slot[which in 0..1][source rank] = {value.x, value.y, epoch, pad} (32 B)
+//     [4096,6144)   halo flags       flag[source rank] = epoch of the last complete boundary push
+//     [6144,8192)   error word
+//     [8192,...)    halo entries     laid out exactly like the halo part of d_ext
+// Hand-off protocol (system scope, placement independent): payload stores -> every thread's
+// __threadfence_system() -> work-group barrier -> ONE release store of the epoch; the consumer polls that one word
+// relaxed, then one acquire fence, then reads the payload with system-scope loads.  Epochs come from device
+// counters advanced by the consuming kernel, so a hipGraph replays the protocol unchanged.  Slot reuse is safe
+// because two full all-reduces separate consecutive uses of any slot or of the halo area.  Spins are bounded;
+// a timeout sets the error word and the kernels fall through.
+// =================================================================================================
+constexpr int kMbSlots = 0, kMbHaloFlags = 4096, kMbError = 6144, kMbHalo = 8192;
+constexpr long long kSpinLimit = 1LL << 21;   // polls of ~1-2 us each: a few seconds, then the error word is set
+
+CG_DEV void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+CG_DEV unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+CG_DEV void st_sys_val(float *p, float v) { __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+CG_DEV void st_sys_val(double *p, double v) { st_sys(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v)); }
+CG_DEV void st_sys_val(float2 *p, float2 v) {
+    unsigned long long w = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+    st_sys(reinterpret_cast<unsigned long long *>(p), w);
+}
+CG_DEV void st_sys_val(double2 *p, double2 v) { st_sys_val(reinterpret_cast<double *>(p), v.x); st_sys_val(reinterpret_cast<double *>(p) + 1, v.y); }
+CG_DEV float ld_sys_val(const float *p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)); }
+CG_DEV double ld_sys_val(const double *p) { return __longlong_as_double((long long)ld_sys(reinterpret_cast<const unsigned long long *>(p))); }
+CG_DEV float2 ld_sys_val(const float2 *p) {
+    const unsigned long long w = ld_sys(reinterpret_cast<const unsigned long long *>(p));
+    return make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+}
+CG_DEV double2 ld_sys_val(const double2 *p) { return make_double2(ld_sys_val(reinterpret_cast<const double *>(p)), ld_sys_val(reinterpret_cast<const double *>(p) + 1)); }
+
+// spin (one lane) until *word == want; false on timeout
+CG_DEV bool spin_until(const unsigned long long *word, unsigned long long want) {
+    for (long long i = 0; i < kSpinLimit; ++i) {
+        if (ld_sys(word) == want) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+struct P2pExchangeArgs {
+    char *const *mailbox;       // [nranks] device array: mailbox base of every rank, mapped in this process
+    int rank, n_peers, n_local;
+    const int *peer_rank, *send_off, *send_count, *dst_off, *recv_off, *recv_count;   // device arrays [n_peers]
+    const int *send_index;
+    unsigned long long *epoch;  // device counter of boundary exchanges
+};
+
+// one work-group per peer: gather my boundary entries straight into the peer's mailbox, then publish the epoch
+template <typename T> __global__ __launch_bounds__(1024) void p2p_push_kernel(P2pExchangeArgs a, const T *v) {
+    const int p = blockIdx.x;
+    const unsigned long long ep = *a.epoch + 1;
+    char *mb = a.mailbox[a.peer_rank[p]];
+    T *dst = reinterpret_cast<T *>(mb + kMbHalo) + a.dst_off[p];
+    const int *idx = a.send_index + a.send_off[p];
+    for (int k = threadIdx.x; k < a.send_count[p]; k += blockDim.x) st_sys_val(dst + k, v[idx[k]]);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mb + kMbHaloFlags) + a.rank, ep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// one work-group: wait for every peer's epoch, copy the landed entries into the halo part of v_ext, advance the epoch
+template <typename T> __global__ __launch_bounds__(1024) void p2p_wait_unpack_kernel(P2pExchangeArgs a, T *v_ext) {
+    __shared__ int ok;
+    const unsigned long long ep = *a.epoch + 1;
+    char *mb = a.mailbox[a.rank];
+    for (int p = 0; p < a.n_peers; ++p) {
+        if (a.recv_count[p] == 0) continue;
+        if (threadIdx.x == 0) {
+            ok = spin_until(reinterpret_cast<unsigned long long *>(mb + kMbHaloFlags) + a.peer_rank[p], ep) ? 1 : 0;
+            if (!ok) st_sys(reinterpret_cast<unsigned long long *>(mb + kMbError), 1ULL);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        }
+        __syncthreads();
+        const T *src = reinterpret_cast<const T *>(mb + kMbHalo) + a.recv_off[p];
+        T *dst = v_ext + a.n_local + a.recv_off[p];
+        for (int k = threadIdx.x; k < a.recv_count[p]; k += blockDim.x) dst[k] = ld_sys_val(src + k);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *a.epoch = ep;
+}
+
+// local partials -> sum over all ranks, in rank order on every rank (bitwise identical everywhere):
+// one work-group; thread s < nranks writes my value into rank s's slot, then waits for rank s's value in mine.
+template <typename A>
+__global__ __launch_bounds__(kScalarBlock) void p2p_allreduce_kernel(const A *partials, int grid, char *const *mailbox, int rank,
+                                                                     int nranks, int which, unsigned long long *epoch, A *out) {
+    __shared__ A smem[kScalarBlock / kWave];
+    __shared__ double vx[64], vy[64];
+    const A loc = sum_partials_block(partials, grid, smem);   // broadcast to every thread
+    const unsigned long long ep = *epoch + 1;
+    const int s = threadIdx.x;
+    if (s < nranks) {
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(mailbox[s] + kMbSlots) + ((long long)which * 64 + rank) * 4;
+        const double2 v2 = to_acc2(loc);
+        st_sys(slot, (unsigned long long)__double_as_longlong(v2.x));
+        st_sys(slot + 1, (unsigned long long)__double_as_longlong(v2.y));
+        __hip_atomic_store(slot + 2, ep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long *in = reinterpret_cast<const unsigned long long *>(mailbox[rank] + kMbSlots) + ((long long)which * 64 + s) * 4;
+        if (!spin_until(in + 2, ep)) st_sys(reinterpret_cast<unsigned long long *>(mailbox[rank] + kMbError), 2ULL);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        vx[s] = __longlong_as_double((long long)ld_sys(in));
+        vy[s] = __longlong_as_double((long long)ld_sys(in + 1));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double2 tot = make_double2(0., 0.);
+        for (int k = 0; k < nranks; ++k) { tot.x += vx[k]; tot.y += vy[k]; }
+        *out = from_acc2<A>(tot);
+        *epoch = ep;
+    }
+}
+
+// =================================================================================================
 // Synthetic generators (device side, so multi-GB systems never cross PCIe)
 // =================================================================================================
 __host__ __device__ inline long long lap3d_ptr(long long i, long long nx, long long ny, long long nz) {
@@ -1219,6 +1337,30 @@ int launch_aypx_beta(int dtype, int n, const void *x, void *y, long long ld, con
     if (n <= 0) return CGAMD_OK;
     const bool v = vec_ok(dtype, ld, nrhs, {x, y});
     CG_DISPATCH(dtype, aypx_beta_impl, n, x, y, ld, partials, P, nrhs, sc, v, st);
+}
+
+// ---- peer-to-peer backend launchers ---------------------------------------------------------------
+template <typename T> static int p2p_exchange_impl(const P2pExchange &e, void *v_ext, hipStream_t st) {
+    P2pExchangeArgs a;
+    a.mailbox = e.mailbox; a.rank = e.rank; a.n_peers = e.n_peers; a.n_local = e.n_local;
+    a.peer_rank = e.peer_rank; a.send_off = e.send_off; a.send_count = e.send_count; a.dst_off = e.dst_off;
+    a.recv_off = e.recv_off; a.recv_count = e.recv_count; a.send_index = e.send_index; a.epoch = e.epoch;
+    hipLaunchKernelGGL((p2p_push_kernel<T>), dim3(e.n_peers), dim3(1024), 0, st, a, (const T *)v_ext);
+    hipLaunchKernelGGL((p2p_wait_unpack_kernel<T>), dim3(1), dim3(1024), 0, st, a, (T *)v_ext);
+    return check_launch("p2p_exchange");
+}
+int launch_p2p_exchange(int dtype, const P2pExchange &e, void *v_ext, hipStream_t st) {
+    if (e.n_peers <= 0) return CGAMD_OK;
+    CG_DISPATCH(dtype, p2p_exchange_impl, e, v_ext, st);
+}
+int launch_p2p_allreduce(int dtype, const void *partials, int grid, char *const *mailbox, int rank, int nranks, int which,
+                         unsigned long long *epoch, void *out, hipStream_t st) {
+    if (nranks > 64) return fail(CGAMD_ERR_INVALID, "p2p all-reduce: at most 64 ranks");
+    if (dtype == CGAMD_F32 || dtype == CGAMD_F64)
+        hipLaunchKernelGGL((p2p_allreduce_kernel<double>), dim3(1), dim3(kScalarBlock), 0, st, (const double *)partials, grid, mailbox, rank, nranks, which, epoch, (double *)out);
+    else
+        hipLaunchKernelGGL((p2p_allreduce_kernel<double2>), dim3(1), dim3(kScalarBlock), 0, st, (const double2 *)partials, grid, mailbox, rank, nranks, which, epoch, (double2 *)out);
+    return check_launch("p2p_allreduce");
 }
 
 }  // namespace cgamd

@@ -179,17 +179,25 @@ def broadcast_unique_id(rank, group=None, device=None):
 
 class DistSolver:
     """Row-partitioned CG on this rank's GPU (csrc/dist.cpp).  All arrays are torch CUDA tensors that
-    must outlive the solver; columns are plan.cols_local."""
+    must outlive the solver; columns are plan.cols_local.
 
-    def __init__(self, ctx, plan, indptr_local, values, dtype, unique_id=None, flags=0):
+    comm="rccl": grouped ncclSend/ncclRecv + ncclAllReduce (needs `unique_id` from broadcast_unique_id).
+    comm="p2p" : no RCCL -- every rank owns an uncached IPC mailbox its peers write over xGMI (collective over
+                 `group` at construction: the 64-byte IPC handles and the landing offsets are all-gathered)."""
+
+    def __init__(self, ctx, plan, indptr_local, values, dtype, unique_id=None, flags=0, comm="rccl", group=None):
         import torch
         self.ctx, self.plan, self.dtype = ctx, plan, np.dtype(dtype)
         self._lib = _lib.load()
+        self.mailbox = None
         peers = np.asarray(plan.peers, dtype=np.int32)
         sc = np.asarray(plan.send_counts, dtype=np.int32)
         rc = np.asarray(plan.recv_counts, dtype=np.int32)
         self._keep = (indptr_local, values, plan.cols_local, plan.send_index, peers, sc, rc)
-        if (plan.world > 1 or plan.peers) and unique_id is None:
+        if comm == "p2p":
+            flags |= _lib.DIST_P2P
+            unique_id = None
+        elif (plan.world > 1 or plan.peers) and unique_id is None:
             raise ValueError("unique_id is required when there are peers")
         idbuf = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)
         torch.cuda.synchronize()
@@ -201,6 +209,34 @@ class DistSolver:
             ptr(plan.send_index) if plan.send_index.numel() else None, int(flags), ctypes.byref(h)))
         self.handle = h
         self.iterations = 0
+        if comm == "p2p":
+            self._attach_p2p(group)
+
+    def _attach_p2p(self, group):
+        import torch.distributed as dist
+        plan = self.plan
+        mb = ctypes.c_void_p()
+        handle = np.zeros(64, dtype=np.uint8)
+        check(self._lib.cgamd_p2p_mailbox_alloc(self.ctx.handle, plan.n_halo, _lib.DTYPE_CODE[self.dtype], ctypes.byref(mb), ptr(handle)))
+        self.mailbox = mb
+        recv_off, off = {}, 0
+        for peer, cnt in zip(plan.peers, plan.recv_counts):      # where each peer's entries land in MY halo area
+            recv_off[int(peer)] = off
+            off += int(cnt)
+        mine = (handle.tobytes(), recv_off)
+        if plan.world > 1:
+            everyone = [None] * plan.world
+            dist.all_gather_object(everyone, mine, group=group)
+        else:
+            everyone = [mine]
+        handles = np.frombuffer(b"".join(e[0] for e in everyone), dtype=np.uint8).copy()
+        dst = np.asarray([everyone[int(p)][1][plan.rank] for p in plan.peers], dtype=np.int32)
+        check(self._lib.cgamd_dist_attach_p2p(self.handle, mb, ptr(handles), ptr(dst) if len(dst) else None))
+        if plan.world > 1:
+            dist.barrier(group=group)        # every mailbox is mapped before anyone pushes
+
+    def p2p_error(self):
+        return self._lib.cgamd_dist_p2p_error(self.handle)
 
     def set_rhs(self, b_local, x0_local=None):
         check(self._lib.cgamd_dist_set_rhs(self.handle, ptr(b_local), ptr(x0_local)))
@@ -228,6 +264,9 @@ class DistSolver:
     def close(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self._lib.cgamd_dist_destroy(self.handle)
+            if getattr(self, "mailbox", None):
+                self._lib.cgamd_p2p_mailbox_free(self.ctx.handle, self.mailbox)
+                self.mailbox = None
         self.handle = None
 
     def __del__(self):

@@ -98,6 +98,7 @@ int cgamd_sub(cgamd_ctx *ctx, int dtype, int size, const void *a, const void *b,
 #define CGAMD_NO_GRAPH 2           /* plain stream launches instead of hipGraph replay */
 #define CGAMD_UNFUSED 4            /* reference op structure: spmv, vdot, axpy, axpy, vdot, aypx (6 kernels) */
 #define CGAMD_DIST_NO_OVERLAP 32    /* cgamd_dist_create: exchange first, then one SpMV (no interior/boundary overlap) */
+#define CGAMD_DIST_P2P 64            /* cgamd_dist_create: no RCCL; peers write each other's IPC mailboxes (attach_p2p) */
 #define CGAMD_DIST_GRAPH 8         /* cgamd_dist_create: replay each iteration (incl. RCCL ops) from a hipGraph */
 
 int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, const void *aValues,
@@ -172,6 +173,15 @@ int cgamd_dist_iterate(cgamd_dist *d, int nIterations);
 int cgamd_dist_get_x(cgamd_dist *d, void *x_local);                                  /* device pointer */
 int cgamd_dist_history(cgamd_dist *d, void *history, int max_entries);
 int cgamd_dist_synchronize(cgamd_dist *d);
+/* Peer-to-peer backend (CGAMD_DIST_P2P): instead of RCCL, every rank owns an uncached IPC-shared mailbox
+ * (8 KiB header + n_halo values) that its peers write over xGMI; all-reduces are sums in rank order of values
+ * deposited in per-rank slots (bitwise identical on all ranks).  Sequence: mailbox_alloc on every rank -> gather
+ * the 64-byte handles of all ranks (torch.distributed) -> dist_create(..., id128 = NULL, flags | CGAMD_DIST_P2P)
+ * -> attach_p2p(handles[nranks*64], dst_offset[n_peers] = where my entries land in each peer's halo area). */
+int cgamd_p2p_mailbox_alloc(cgamd_ctx *ctx, long long halo_values, int dtype, void **mailbox, void *handle64);
+int cgamd_p2p_mailbox_free(cgamd_ctx *ctx, void *mailbox);
+int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, const int *dst_offset);
+int cgamd_dist_p2p_error(cgamd_dist *d);
 
 #ifdef __cplusplus
 }

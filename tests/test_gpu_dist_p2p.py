@@ -1,0 +1,93 @@
+"""GPU tests of the row-partitioned C loop with MORE THAN ONE RANK on the one-GPU test box.  RCCL refuses two
+ranks on one device, the peer-to-peer backend does not care: the ranks are separate processes that share
+cuda:0, exchange halos and reduce scalars through each other's IPC mailboxes (csrc/kernels.hip "Peer-to-peer
+communication").  Same plan, same loop, same kernels as the RCCL path; results against the serial oracle."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG_NAME, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _system(kind):
+    import cg_numpy
+    if kind == "lap3d":
+        ip, ix, da = cg_numpy.laplace3d(24, 20, 36)          # 17280 rows: overlap lists are built (>= 16 row blocks/rank)
+        b = np.linspace(1.0, 2.0, len(ip) - 1)
+    else:
+        N = 60
+        ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+        b = cg_numpy.rhsA(N, 12.0).flatten()
+    return ip, ix, da, b
+
+
+def _worker(rank, world, port, kind, iters, flags, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module(PKG_NAME)
+    dmod = importlib.import_module(PKG_NAME + ".dist")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        ctx = pkg.Context(0)
+        ip, ix, da, b = _system(kind)
+        n = len(ip) - 1
+        ranges = dmod.row_ranges(n, world)
+        rb, re = ranges[rank]
+        lo, hi = ip[rb], ip[re]
+        plan = dmod.build_halo_plan(torch.from_numpy(ix[lo:hi].astype(np.int64)), ranges, rank)
+        plan.cols_local = plan.cols_local.to(dev)
+        plan.send_index = plan.send_index.to(dev)
+        indptr = torch.from_numpy((ip[rb:re + 1] - lo).astype(np.int32)).to(dev)
+        vals = torch.from_numpy(da[lo:hi]).to(dev)
+        s = dmod.DistSolver(ctx, plan, indptr, vals, da.dtype, flags=flags, comm="p2p")
+        bl = torch.from_numpy(b[rb:re].astype(da.dtype)).to(dev)
+        s.set_rhs(bl, None)
+        for _ in range(3):
+            s.iterate(iters // 3)
+        x = s.x(torch.empty(plan.n_local, dtype=bl.dtype, device=dev)).cpu().numpy()
+        hist = s.history()
+        err = s.p2p_error()
+        s.close()
+        ctx.close()
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), x=x, hist=hist, err=err)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind,flags", [(2, "lap3d", 0), (3, "lap3d", 8), (2, "helm", 8), (3, "helm", 32)])
+def test_p2p_multirank_on_one_gpu(tmp_path, world, kind, flags):
+    import torch.multiprocessing as mp
+    import cg_oracle
+    iters = 30
+    mp.spawn(_worker, args=(world, _free_port(), kind, iters, flags, str(tmp_path)), nprocs=world, join=True)
+    ip, ix, da, b = _system(kind)
+    xo, ho = cg_oracle.cg(ip, ix, da, b.astype(da.dtype), n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
+    parts = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    assert all(int(p["err"]) == 0 for p in parts)
+    for p in parts[1:]:
+        assert np.array_equal(p["hist"], parts[0]["hist"])        # rank-ordered sums: bitwise identical on all ranks
+    keep = np.abs(ho[:, 0]) / np.abs(ho[0, 0]) > 1e-8
+    assert np.max(np.abs(parts[0]["hist"][keep] - ho[keep, 0]) / np.abs(ho[keep, 0])) < 1e-10
+    x = np.concatenate([p["x"] for p in parts])
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-9
