@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", type=str, default="250x200x200", help="global grid nx x ny x nz")
-    ap.add_argument("--no-dist-graph", action="store_true", help="N>1: plain stream launches instead of hipGraph replay of the RCCL loop")
+    ap.add_argument("--dist-skip", type=str, default="", help="N>1: comma list of loop candidates to skip (p2p+graph,p2p,rccl+graph,rccl)")
     ap.add_argument("--dtype", type=str, default="f64", choices=["f32", "f64", "c64", "c128"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="reference op structure (6 kernels/iteration)")
@@ -106,7 +106,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("CG_FORCE_DIST", "0") == "1":
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("CG_DIST_BACKEND", "nccl")     # "gloo": rehearsal of N ranks on one GPU (p2p loops only)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     pkg = importlib.import_module(PKG)
     lib = pkg._lib
