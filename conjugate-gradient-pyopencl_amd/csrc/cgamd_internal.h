@@ -120,9 +120,10 @@ struct P2pExchange {
     unsigned long long *epoch = nullptr;
 };
 int launch_p2p_exchange(int dtype, const P2pExchange &e, void *v_ext, hipStream_t st);
-// out = sum over ranks (in rank order) of the local sum of `partials`; which in {0,1} selects the slot set
-int launch_p2p_allreduce(int dtype, const void *partials, int grid, char *const *mailbox, int rank, int nranks, int which,
-                         unsigned long long *epoch, void *out, hipStream_t st);
+// global sum (rank order) of the local sum of `partials`, followed in the same launch by the scalar step that consumes
+// it: mode 1 = cg_delta0, 2 = cg_alpha, 3 = cg_beta; which in {0,1} selects the slot set
+int launch_p2p_allreduce(int dtype, int mode, const void *partials, int grid, char *const *mailbox, int rank, int nranks,
+                         int which, unsigned long long *epoch, const CgScalars &sc, hipStream_t st);
 
 // synthetic generators (device)
 int launch_gen_laplace3d(int dtype, int nx, int ny, int nz, long long row_begin, long long row_end, void *vals,

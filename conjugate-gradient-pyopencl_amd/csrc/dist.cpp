@@ -153,20 +153,25 @@ static int allreduce_scalar(cgamd_dist *d, void *acc, hipStream_t st) {
     return CGAMD_OK;
 }
 
-// partials -> global sum in accumulator precision at `out` (device): RCCL all-reduce or the mailbox protocol
-static int reduce_all(cgamd_dist *d, const void *partials, int count, int which, void *out, hipStream_t st) {
+// partials -> global sum -> the scalar step consuming it (mode 1 delta0, 2 alpha, 3 beta).  RCCL: local reduce,
+// ncclAllReduce, scalar kernel (3 launches); peer-to-peer: one launch does all three.
+static int reduce_all(cgamd_dist *d, const void *partials, int count, int which, int mode, hipStream_t st) {
     if (d->p2p) {
         if (!d->p2p_attached) return fail(CGAMD_ERR_STATE, "p2p backend: call cgamd_dist_attach_p2p first");
-        return launch_p2p_allreduce(d->dtype, partials, count, d->mailbox_dev, d->rank, d->nranks, which, d->epochs + 1 + which, out, st);
+        return launch_p2p_allreduce(d->dtype, mode, partials, count, d->mailbox_dev, d->rank, d->nranks, which,
+                                    d->epochs + 1 + which, d->sc, st);
     }
+    void *out = (char *)d->red + 16 * which;
     if (int rc = launch_reduce_to_acc(d->dtype, partials, count, 1, out, st)) return rc;
-    return allreduce_scalar(d, out, st);
+    if (int rc = allreduce_scalar(d, out, st)) return rc;
+    if (mode == 1) return launch_cg_delta0(d->dtype, out, 1, 1, d->sc, st);
+    if (mode == 2) return launch_cg_alpha(d->dtype, out, 1, 1, d->sc, st);
+    return launch_cg_beta(d->dtype, out, 1, 1, d->sc, st);
 }
 
 static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
     const int dt = d->dtype, n = d->n_local;
     const long long ldx = (long long)d->n_local + d->n_halo;
-    char *red = (char *)d->red;
     int rc;
     if (d->overlap) {
         // fork: the exchange runs on the comm stream while the row blocks that reference no halo column are
@@ -185,11 +190,9 @@ static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
         if ((rc = exchange(d, d->d_ext, st))) return rc;
         if ((rc = launch_spmv(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, ldx, d->q, n, 1, d->d_ext, d->part_dq, st))) return rc;
     }
-    if ((rc = reduce_all(d, d->part_dq, d->plan.n_partials, 0, red, st))) return rc;
-    if ((rc = launch_cg_alpha(dt, red, 1, 1, d->sc, st))) return rc;
+    if ((rc = reduce_all(d, d->part_dq, d->plan.n_partials, 0, 2, st))) return rc;
     if ((rc = launch_axpy2_dot(dt, n, d->d_ext, d->x, d->q, d->r, n, d->sc.alpha, 1, d->part_rr, d->vgrid, st))) return rc;
-    if ((rc = reduce_all(d, d->part_rr, d->vgrid, 1, red + 16, st))) return rc;
-    if ((rc = launch_cg_beta(dt, red + 16, 1, 1, d->sc, st))) return rc;
+    if ((rc = reduce_all(d, d->part_rr, d->vgrid, 1, 3, st))) return rc;
     return launch_aypx(dt, n, d->r, d->d_ext, n, d->sc.beta, 1, st);
 }
 
@@ -377,8 +380,7 @@ int cgamd_dist_set_rhs(cgamd_dist *d, const void *b_local, const void *x0_local)
     if ((rc = launch_sub(d->dtype, d->n_local, d->b, d->q, d->r, d->n_local, 1, st))) return rc;
     CG_HIP(hipMemcpyAsync(d->d_ext, d->r, vb, hipMemcpyDeviceToDevice, st));
     if ((rc = launch_dot_partials(d->dtype, d->n_local, d->r, d->r, d->n_local, 1, d->part_rr, d->vgrid, st))) return rc;
-    if ((rc = reduce_all(d, d->part_rr, d->vgrid, 1, (char *)d->red + 16, st))) return rc;
-    if ((rc = launch_cg_delta0(d->dtype, (char *)d->red + 16, 1, 1, d->sc, st))) return rc;
+    if ((rc = reduce_all(d, d->part_rr, d->vgrid, 1, 1, st))) return rc;
     d->rhs_set = true;
     d->iters = 0;
     return CGAMD_OK;

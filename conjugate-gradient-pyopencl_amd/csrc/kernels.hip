@@ -887,9 +887,13 @@ template <typename T> __global__ __launch_bounds__(1024) void p2p_wait_unpack_ke
 
 // local partials -> sum over all ranks, in rank order on every rank (bitwise identical everywhere):
 // one work-group; thread s < nranks writes my value into rank s's slot, then waits for rank s's value in mine.
-template <typename A>
-__global__ __launch_bounds__(kScalarBlock) void p2p_allreduce_kernel(const A *partials, int grid, char *const *mailbox, int rank,
-                                                                     int nranks, int which, unsigned long long *epoch, A *out) {
+// The scalar step that consumes the sum rides in the same launch (MODE): 1 = cg_delta0, 2 = cg_alpha, 3 = cg_beta.
+template <typename T, int MODE>
+__global__ __launch_bounds__(kScalarBlock) void p2p_allreduce_kernel(const typename VT<T>::acc *partials, int grid,
+                                                                     char *const *mailbox, int rank, int nranks, int which,
+                                                                     unsigned long long *epoch, T *delta, T *alpha, T *beta,
+                                                                     T *history, int history_cap, int *iter) {
+    using A = typename VT<T>::acc;
     __shared__ A smem[kScalarBlock / kWave];
     __shared__ double vx[64], vy[64];
     const A loc = sum_partials_block(partials, grid, smem);   // broadcast to every thread
@@ -909,10 +913,25 @@ __global__ __launch_bounds__(kScalarBlock) void p2p_allreduce_kernel(const A *pa
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double2 tot = make_double2(0., 0.);
-        for (int k = 0; k < nranks; ++k) { tot.x += vx[k]; tot.y += vy[k]; }
-        *out = from_acc2<A>(tot);
+        double2 tot2 = make_double2(0., 0.);
+        for (int k = 0; k < nranks; ++k) { tot2.x += vx[k]; tot2.y += vy[k]; }
+        const A tot = from_acc2<A>(tot2);
         *epoch = ep;
+        if (MODE == 1) {                       // cg_delta0 (clcg.c:274-292)
+            delta[0] = from_acc<T>(tot);
+            history[0] = from_acc<T>(tot);
+            *iter = 0;
+        } else if (MODE == 2) {                // cg_alpha (clcg.c:317-327)
+            const T dqT = from_acc<T>(tot);
+            alpha[0] = from_acc<T>(acc_div(to_acc(delta[0]), to_acc(dqT)));
+            *iter = *iter + 1;
+        } else {                               // cg_beta (clcg.c:376-391)
+            const int it = *iter;
+            const T dnT = from_acc<T>(tot);
+            beta[0] = from_acc<T>(acc_div(to_acc(dnT), to_acc(delta[0])));
+            delta[0] = dnT;
+            if (it < history_cap) history[it] = dnT;
+        }
     }
 }
 
@@ -1353,14 +1372,21 @@ int launch_p2p_exchange(int dtype, const P2pExchange &e, void *v_ext, hipStream_
     if (e.n_peers <= 0) return CGAMD_OK;
     CG_DISPATCH(dtype, p2p_exchange_impl, e, v_ext, st);
 }
-int launch_p2p_allreduce(int dtype, const void *partials, int grid, char *const *mailbox, int rank, int nranks, int which,
-                         unsigned long long *epoch, void *out, hipStream_t st) {
-    if (nranks > 64) return fail(CGAMD_ERR_INVALID, "p2p all-reduce: at most 64 ranks");
-    if (dtype == CGAMD_F32 || dtype == CGAMD_F64)
-        hipLaunchKernelGGL((p2p_allreduce_kernel<double>), dim3(1), dim3(kScalarBlock), 0, st, (const double *)partials, grid, mailbox, rank, nranks, which, epoch, (double *)out);
-    else
-        hipLaunchKernelGGL((p2p_allreduce_kernel<double2>), dim3(1), dim3(kScalarBlock), 0, st, (const double2 *)partials, grid, mailbox, rank, nranks, which, epoch, (double2 *)out);
+template <typename T>
+static int p2p_ar_impl(int mode, const void *partials, int grid, char *const *mailbox, int rank, int nranks, int which,
+                       unsigned long long *epoch, const CgScalars &sc, hipStream_t st) {
+    auto *pp = static_cast<const typename VT<T>::acc *>(partials);
+#define CG_AR(M)                                                                                                            \
+    hipLaunchKernelGGL((p2p_allreduce_kernel<T, M>), dim3(1), dim3(kScalarBlock), 0, st, pp, grid, mailbox, rank, nranks, which, \
+                       epoch, (T *)sc.delta, (T *)sc.alpha, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter)
+    if (mode == 1) CG_AR(1); else if (mode == 2) CG_AR(2); else CG_AR(3);
+#undef CG_AR
     return check_launch("p2p_allreduce");
+}
+int launch_p2p_allreduce(int dtype, int mode, const void *partials, int grid, char *const *mailbox, int rank, int nranks,
+                         int which, unsigned long long *epoch, const CgScalars &sc, hipStream_t st) {
+    if (nranks > 64) return fail(CGAMD_ERR_INVALID, "p2p all-reduce: at most 64 ranks");
+    CG_DISPATCH(dtype, p2p_ar_impl, mode, partials, grid, mailbox, rank, nranks, which, epoch, sc, st);
 }
 
 }  // namespace cgamd
