@@ -326,8 +326,9 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
         }
     }
     // hipGraph capture of the two-stream fork/join around RCCL send/recv crashed in the runtime (ROCm 7.0/7.2,
-    // RCCL 2.26): the graph mode therefore runs the exchange in line, the plain-launch mode overlaps it.
-    if (!rc && !(flags & (CGAMD_DIST_NO_OVERLAP | CGAMD_DIST_GRAPH)) && (d->comm || d->p2p)) rc = build_overlap_lists(d);
+    // RCCL 2.26): with RCCL the graph mode therefore runs the exchange in line and the plain-launch mode overlaps
+    // it; the peer-to-peer backend is pure kernels and overlaps in both modes.
+    if (!rc && !(flags & CGAMD_DIST_NO_OVERLAP) && ((d->comm && !(flags & CGAMD_DIST_GRAPH)) || d->p2p)) rc = build_overlap_lists(d);
     if (rc) {
         std::string keep = cgamd_last_error();
         cgamd_dist_destroy(d);
