@@ -241,6 +241,12 @@ class Solver:
     def iterate(self, n_iterations):
         check(self._lib.cgamd_solver_iterate(self.handle, int(n_iterations)))
 
+    def iterate_timed(self, n_iterations):
+        """n_iterations plain-launch iterations with HIP events around every SpMV: (avg SpMV ms, avg iteration ms)"""
+        a, b = ctypes.c_float(), ctypes.c_float()
+        check(self._lib.cgamd_solver_iterate_timed(self.handle, int(n_iterations), ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def x(self, out=None):
         if out is None:
             out = np.empty(self.size * self.n_rhs, dtype=self.dtype)

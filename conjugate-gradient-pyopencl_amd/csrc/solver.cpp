@@ -247,6 +247,46 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
     return CGAMD_OK;
 }
 
+// nIterations plain-launch iterations with a HIP event pair around every SpMV launch, on the solver's stream:
+// the in-loop duration of the dominant kernel (bench.py's roofline).  Synchronises.
+int cgamd_solver_iterate_timed(cgamd_solver *s, int nIterations, float *spmv_ms_avg, float *iter_ms_avg) {
+    if (!s || !spmv_ms_avg) return fail(CGAMD_ERR_INVALID, "iterate_timed: null argument");
+    if (!s->rhs_set) return fail(CGAMD_ERR_STATE, "iterate_timed: call set_rhs first");
+    if (nIterations < 1 || (s->flags & CGAMD_UNFUSED)) return fail(CGAMD_ERR_INVALID, "iterate_timed: needs >= 1 iteration of the fused loop");
+    CG_HIP(hipSetDevice(s->ctx->device));
+    if (int rc = ensure_history(s, s->iters + nIterations + 1)) return rc;
+    hipStream_t st = s->ctx->stream;
+    const int dt = s->dtype, n = s->n, nr = s->nrhs;
+    std::vector<hipEvent_t> ev((size_t)2 * nIterations + 2, nullptr);
+    for (auto &e : ev) CG_HIP(hipEventCreate(&e));
+    int rc = CGAMD_OK;
+    CG_HIP(hipEventRecord(ev[(size_t)2 * nIterations], st));
+    for (int i = 0; i < nIterations && !rc; ++i) {
+        CG_HIP(hipEventRecord(ev[(size_t)2 * i], st));
+        rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st);
+        CG_HIP(hipEventRecord(ev[(size_t)2 * i + 1], st));
+        if (!rc) rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st);
+        if (!rc) rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st);
+        if (!rc) rc = launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
+    }
+    CG_HIP(hipEventRecord(ev[(size_t)2 * nIterations + 1], st));
+    CG_HIP(hipStreamSynchronize(st));
+    double sum = 0.0;
+    for (int i = 0; i < nIterations && !rc; ++i) {
+        float ms = 0.f;
+        CG_HIP(hipEventElapsedTime(&ms, ev[(size_t)2 * i], ev[(size_t)2 * i + 1]));
+        sum += ms;
+    }
+    float total = 0.f;
+    CG_HIP(hipEventElapsedTime(&total, ev[(size_t)2 * nIterations], ev[(size_t)2 * nIterations + 1]));
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (rc) return rc;
+    s->iters += nIterations;
+    *spmv_ms_avg = (float)(sum / nIterations);
+    if (iter_ms_avg) *iter_ms_avg = total / nIterations;
+    return CGAMD_OK;
+}
+
 int cgamd_solver_get_x(cgamd_solver *s, void *x, int on_device) {
     if (!s || !x) return fail(CGAMD_ERR_INVALID, "get_x: null argument");
     CG_HIP(hipSetDevice(s->ctx->device));

@@ -109,6 +109,9 @@ int cgamd_solver_destroy(cgamd_solver *s);
 int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_device);
 /* enqueue exactly nIterations iterations (reference clcg.c:297-419); asynchronous, no host sync */
 int cgamd_solver_iterate(cgamd_solver *s, int nIterations);
+/* nIterations iterations with plain launches and a HIP event pair around every SpMV launch on the solver's stream;
+ * returns the average in-loop SpMV duration (and optionally the average iteration time), in ms.  Synchronises. */
+int cgamd_solver_iterate_timed(cgamd_solver *s, int nIterations, float *spmv_ms_avg, float *iter_ms_avg);
 /* copy the current iterate; synchronises the stream when on_device == 0 */
 int cgamd_solver_get_x(cgamd_solver *s, void *x, int on_device);
 /* residual history: entry k (k = 0..iterations done) holds delta_k[r] for r < nRHS, value type = dtype.
