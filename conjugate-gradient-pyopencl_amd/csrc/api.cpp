@@ -34,6 +34,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmv_far") g_tune.spmv_far = value;
     else if (k == "spmv_unroll") g_tune.spmv_unroll = value;
     else if (k == "spmm_rb") g_tune.spmm_rb = value;
+    else if (k == "spmv_lds_pad") g_tune.spmv_lds_pad = value;
     else return fail(CGAMD_ERR_INVALID, "tune: unknown key " + k);
     return CGAMD_OK;
 }

@@ -50,6 +50,7 @@ struct Tuning {
     int spmv_nt = 1;        // non-temporal matrix loads
     int spmv_unroll = 0;    // row walk: LDS reads + gathers in flight per lane (4 or 8; 0 = 8, or 4 for 16-byte values)
     int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = all in one launch)
+    int spmv_lds_pad = 0;   // experiment: extra dynamic LDS bytes per work-group (lowers occupancy)
     int spmv_far = 1;       // row-block schedule interleave stride (1 = none)
     int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)
     int vec_grid = 0;       // vector kernels: 0 = auto

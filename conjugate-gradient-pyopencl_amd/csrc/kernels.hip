@@ -1066,7 +1066,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     if (variant == 5) {
         a.cap = (plan.max_span + 3) & ~3;
         a.far = g_tune.spmv_far > 0 ? g_tune.spmv_far : 1;
-        const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
+        const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + (size_t)g_tune.spmv_lds_pad;
         int per_xcd = 0;
         for (int x = 0; x < 8; ++x) {
             const int m = (int)((long long)(x + 1) * plan.row_blocks / 8) - (int)((long long)x * plan.row_blocks / 8);
