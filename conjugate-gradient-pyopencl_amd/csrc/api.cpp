@@ -35,6 +35,9 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmv_unroll") g_tune.spmv_unroll = value;
     else if (k == "spmm_rb") g_tune.spmm_rb = value;
     else if (k == "spmv_lds_pad") g_tune.spmv_lds_pad = value;
+    else if (k == "spmv_policy") g_tune.spmv_policy = value;
+    else if (k == "vec_nt") g_tune.vec_nt = value;
+    else if (k == "vec_skew") g_tune.vec_skew = value & ~15;
     else return fail(CGAMD_ERR_INVALID, "tune: unknown key " + k);
     return CGAMD_OK;
 }

@@ -50,6 +50,10 @@ struct Tuning {
     int spmv_nt = 1;        // non-temporal matrix loads
     int spmv_unroll = 0;    // row walk: LDS reads + gathers in flight per lane (4 or 8; 0 = 8, or 4 for 16-byte values)
     int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = all in one launch)
+    int vec_skew = 0;       // bytes added to the pitch between the solver's vectors (multiple of 16)
+    int vec_nt = 3;         // axpy2_dot: bit0 = x loaded/stored non-temporally (touched once per iteration), bit1 = q loaded
+                            // non-temporally (its last use): d and r, which are re-read, keep the caches; measured -10..-22 us/iteration
+    int spmv_policy = -1;   // experiment: >= 0 = matrix stream via buffer loads with this cache-policy aux field
     int spmv_lds_pad = 0;   // experiment: extra dynamic LDS bytes per work-group (lowers occupancy)
     int spmv_far = 1;       // row-block schedule interleave stride (1 = none)
     int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)

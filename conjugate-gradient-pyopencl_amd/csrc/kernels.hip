@@ -31,6 +31,18 @@ template <typename T> struct Pack {
 
 template <typename T> CG_DEV Pack<T> ld_pack(const T *p) { return *reinterpret_cast<const Pack<T> *>(p); }
 template <typename T> CG_DEV void st_pack(T *p, const Pack<T> &v) { *reinterpret_cast<Pack<T> *>(p) = v; }
+// non-temporal forms for data that is touched once per iteration (x) or for the last time (q): keeps the
+// vectors that are re-read (d, r) in L2 / Infinity Cache
+template <typename T> CG_DEV Pack<T> ld_pack_nt(const T *p) {
+    union { u32x4 raw; Pack<T> v; } u;
+    u.raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return u.v;
+}
+template <typename T> CG_DEV void st_pack_nt(T *p, const Pack<T> &v) {
+    union { u32x4 raw; Pack<T> v; } u;
+    u.v = v;
+    __builtin_nontemporal_store(u.raw, reinterpret_cast<u32x4 *>(p));
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -219,20 +231,45 @@ template <typename T, bool NT, bool FULL> CG_DEV void load_quad(const T *__restr
     }
 }
 
+// Same 4 entries through raw buffer loads with an explicit cache-policy field AUX (bit0 sc0, bit1 nt, bit4 sc1):
+// experiment knob "spmv_policy" -- which policy keeps the CG vectors resident in L2 / Infinity Cache while the
+// matrix streams through.  Offsets are relative to the slice start (the descriptor's base), so they fit 32 bits.
+template <typename T, int AUX> CG_DEV void load_quad_buf(__amdgpu_buffer_rsrc_t rv, __amdgpu_buffer_rsrc_t rc, int entry,
+                                                         T (&v)[4], int (&c)[4]) {
+    constexpr int NV = sizeof(T) * 4 / 16;
+    union { u32x4 raw[NV]; T w[4]; } uu;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) uu.raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, entry * (int)sizeof(T) + 16 * k, 0, AUX);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = uu.w[k];
+    const u32x4 cc = __builtin_amdgcn_raw_buffer_load_b128(rc, entry * 4, 0, AUX);
+    c[0] = (int)cc.x; c[1] = (int)cc.y; c[2] = (int)cc.z; c[3] = (int)cc.w;
+}
+
 // Park the slice [cfirst, p1) of aValues/aCols raw in LDS.  Every lane issues the loads of TWO quads before it
 // waits for either (a plain loop made hipcc wait for quad 1 before issuing quad 2: one more dependent HBM
 // round trip per work-group, and the work-group's lifetime is a chain of such round trips).
-template <typename T, int BLOCK, bool NT, bool FULL>
+template <typename T, int BLOCK, bool NT, bool FULL, int POL = -1>
 CG_DEV void stage_slice_impl(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
                              T *sv, int *sc) {
     const int t = threadIdx.x;
+    __amdgpu_buffer_rsrc_t rv, rc;
+    if (POL >= 0) {
+        rv = __builtin_amdgcn_make_buffer_rsrc((void *)(vals + cfirst), 0, 0x7fffffff, 0x00020000);
+        rc = __builtin_amdgcn_make_buffer_rsrc((void *)(cols + cfirst), 0, 0x7fffffff, 0x00020000);
+    }
     for (long long base = cfirst; base < p1; base += 8 * BLOCK) {
         const long long q0 = base + 4 * t, q1 = q0 + 4 * BLOCK;
         const bool h0 = q0 < p1, h1 = q1 < p1;
         T v0[4], v1[4];
         int c0[4], c1[4];
-        if (h0) load_quad<T, NT, FULL>(vals, cols, nnz, q0, v0, c0);
-        if (h1) load_quad<T, NT, FULL>(vals, cols, nnz, q1, v1, c1);
+        if (POL >= 0 && FULL) {
+            if (h0) load_quad_buf<T, POL < 0 ? 0 : POL>(rv, rc, (int)(q0 - cfirst), v0, c0);
+            if (h1) load_quad_buf<T, POL < 0 ? 0 : POL>(rv, rc, (int)(q1 - cfirst), v1, c1);
+        } else {
+            if (h0) load_quad<T, NT, FULL>(vals, cols, nnz, q0, v0, c0);
+            if (h1) load_quad<T, NT, FULL>(vals, cols, nnz, q1, v1, c1);
+        }
         if (h0) {
             const int o = (int)(q0 - cfirst);
 #pragma unroll
@@ -245,12 +282,12 @@ CG_DEV void stage_slice_impl(const T *__restrict__ vals, const int *__restrict__
         }
     }
 }
-template <typename T, int BLOCK, bool NT>
+template <typename T, int BLOCK, bool NT, int POL = -1>
 CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1, T *sv,
                         int *sc) {
     // only the work-group that owns the very end of the matrix can meet a partial quad: block-uniform branch,
     // so the common path carries no per-lane tail handling (whose control flow made hipcc serialise the loads)
-    if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_impl<T, BLOCK, NT, true>(vals, cols, nnz, cfirst, p1, sv, sc);
+    if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_impl<T, BLOCK, NT, true, POL>(vals, cols, nnz, cfirst, p1, sv, sc);
     else stage_slice_impl<T, BLOCK, NT, false>(vals, cols, nnz, cfirst, p1, sv, sc);
 }
 
@@ -275,7 +312,7 @@ CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols
 //     not pay at N=10M (x already stays in L2/Infinity Cache) and is kept only as a tuning knob.
 // LDS is sized at launch from the plan's largest slice (values + columns).
 // -------------------------------------------------------------------------------------------------
-template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL>
+template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL, int POL = -1>
 __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     using A = typename VT<T>::acc;
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
@@ -308,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
-    stage_slice<T, BLOCK, NT>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+    stage_slice<T, BLOCK, NT, POL>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
     const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
     __syncthreads();
     // Row walk, branch-free inside a batch: out-of-range slots re-read the row's LAST entry (a valid LDS slot
@@ -554,7 +591,7 @@ template <int BLOCK> __global__ void spmv_span_kernel(int n, const int *__restri
 // Streaming vector kernels.  grid = (G, nRHS); RHS r lives at base + r*ld.
 // =================================================================================================
 // x += alpha d ; r -= alpha q ; partial(r.r)
-template <typename T, int BLOCK, bool VEC>
+template <typename T, int BLOCK, bool VEC, int VNT = 0>
 __global__ __launch_bounds__(BLOCK) void axpy2_dot_kernel(int n, const T *__restrict__ d, T *__restrict__ x,
                                                           const T *__restrict__ q, T *__restrict__ rv, long long ld,
                                                           const T *__restrict__ alpha,
@@ -572,15 +609,15 @@ __global__ __launch_bounds__(BLOCK) void axpy2_dot_kernel(int n, const T *__rest
     if (VEC) {
         const long long npack = n / E;
         for (long long i = i0; i < npack; i += stride) {
-            const Pack<T> pd = ld_pack(d + i * E), pq = ld_pack(q + i * E);
-            Pack<T> px = ld_pack(x + i * E), pr = ld_pack(rv + i * E);
+            const Pack<T> pd = ld_pack(d + i * E), pq = (VNT & 2) ? ld_pack_nt(q + i * E) : ld_pack(q + i * E);
+            Pack<T> px = (VNT & 1) ? ld_pack_nt(x + i * E) : ld_pack(x + i * E), pr = ld_pack(rv + i * E);
 #pragma unroll
             for (int k = 0; k < E; ++k) {
                 px.v[k] = vadd(px.v[k], vmul(al, pd.v[k]));
                 pr.v[k] = vsub(pr.v[k], vmul(al, pq.v[k]));
                 acc = vadd(acc, to_acc(vmul(pr.v[k], pr.v[k])));
             }
-            st_pack(x + i * E, px);
+            if (VNT & 1) st_pack_nt(x + i * E, px); else st_pack(x + i * E, px);
             st_pack(rv + i * E, pr);
         }
         i0 += npack * E;  // scalar tail
@@ -1081,6 +1118,16 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, UNR>), g5, block, lds, st, a);       \
     } while (0)
         // 8 gathers in flight per lane for 4/8-byte values; 4 for complex128 (8 would cost 3 waves/SIMD of occupancy)
+        if (g_tune.spmv_policy >= 0 && sizeof(T) == 8 && !VT<T>::cplx && fuse) {
+            // experiment: matrix stream through buffer loads with an explicit cache policy (f64, fused dot only)
+#define CG_POL(P) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, true, true, 8, P>), g5, block, lds, st, a)
+            switch (g_tune.spmv_policy) {
+            case 0: CG_POL(0); break;   case 1: CG_POL(1); break;   case 2: CG_POL(2); break;   case 3: CG_POL(3); break;
+            case 16: CG_POL(16); break; case 17: CG_POL(17); break; case 18: CG_POL(18); break; default: CG_POL(19); break;
+            }
+#undef CG_POL
+            return check_launch("spmv_rowblock(policy)");
+        }
         const int unroll = g_tune.spmv_unroll ? g_tune.spmv_unroll : (sizeof(T) > 8 ? 4 : 8);
         if (unroll == 4) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
         else { if (nt) CG_RB(true, 8); else CG_RB(false, 8); }
@@ -1233,7 +1280,10 @@ static int axpy2_impl(int n, const void *d, void *x, const void *q, void *r, lon
                       void *partials, int grid, bool vec, hipStream_t st) {
     dim3 g(grid, nrhs), blk(kBlock);
     auto *pp = static_cast<typename VT<T>::acc *>(partials);
-    if (vec) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    if (vec && g_tune.vec_nt == 1) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true, 1>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    else if (vec && g_tune.vec_nt == 2) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true, 2>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    else if (vec && g_tune.vec_nt == 3) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true, 3>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    else if (vec) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
     else hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
     return check_launch("axpy2_dot");
 }

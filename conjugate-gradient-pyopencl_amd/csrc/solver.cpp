@@ -26,6 +26,7 @@ struct cgamd_solver {
     SpmvPlan plan;
     int vgrid = 1;
     void *x = nullptr, *r = nullptr, *d = nullptr, *q = nullptr, *b = nullptr;
+    void *slab = nullptr;   // backing store of x, r, d, q, b
     void *part_dq = nullptr, *part_rr = nullptr;
     CgScalars sc;
     bool rhs_set = false;
@@ -151,11 +152,17 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
         }
     }
     const size_t vbytes = (size_t)size * nRHS * vs;
-    if (!rc) rc = dmalloc(&s->x, vbytes, "x");
-    if (!rc) rc = dmalloc(&s->r, vbytes, "r");
-    if (!rc) rc = dmalloc(&s->d, vbytes, "d");
-    if (!rc) rc = dmalloc(&s->q, vbytes, "q");
-    if (!rc) rc = dmalloc(&s->b, vbytes, "b");
+    {
+        // the five vectors live in one slab, each at a 4 KiB-aligned offset plus a per-vector skew: the update kernels
+        // stream up to four of them in lock-step, and equal strides between them alias onto the same HBM channels
+        const size_t skew = (size_t)(g_tune.vec_skew >= 0 ? g_tune.vec_skew : 0);
+        const size_t pitch = ((vbytes + 4095) & ~(size_t)4095) + skew;
+        if (!rc) rc = dmalloc(&s->slab, pitch * 5 + 4096, "vectors");
+        if (!rc) {
+            char *base = static_cast<char *>(s->slab);
+            s->x = base; s->r = base + pitch; s->d = base + 2 * pitch; s->q = base + 3 * pitch; s->b = base + 4 * pitch;
+        }
+    }
     if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * (size_t)std::max(s->plan.grid, s->plan.row_blocks) * nRHS, "partials_dq");
     if (!rc) rc = dmalloc(&s->part_rr, acc_size(dtype) * (size_t)s->vgrid * nRHS, "partials_rr");
     if (!rc) rc = dmalloc(&s->sc.alpha, vs * nRHS, "alpha");
@@ -189,7 +196,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
         if (s->ptr) (void)hipFree(s->ptr);
         if (s->cols) (void)hipFree(s->cols);
     }
-    void *bufs[] = {s->x, s->r, s->d, s->q, s->b, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
+    void *bufs[] = {s->slab, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
                     s->sc.history, s->sc.iter};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
