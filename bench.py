@@ -194,7 +194,7 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"3D 7-pt Laplacian {nx}x{ny}x{nz} CSR, N={n}, nnz={nnz}, {args.dtype}, 1 RHS, "
-                               f"b=5, x0=0, fixed-iteration CG ({'reference 6-op' if args.unfused else 'fused 5-launch'} loop)",
+                               f"b=5, x0=0, fixed-iteration CG ({'reference 6-op' if args.unfused else 'fused 4-launch'} loop)",
                    "rows": n, "nnz": nnz, "parallelism": "1 GPU"},
         "spmv_gbs": spmv_gbs, "spmv_pct_of_8tbs": 100.0 * spmv_gbs / HBM_PEAK_GBS,
         "spmv_back_to_back_gbs": spmv_bytes / (spmv_alone_ms * 1e-3) / 1e9,

@@ -104,8 +104,32 @@ template <typename T> struct SpmvArgs {
     const int *rb_list;             // row-block kernel: optional explicit list of row blocks (multi-GPU interior / boundary split)
     int rb_count;
     int cap;   // row-block kernel: LDS slice capacity in entries (multiple of 4)
-    int far;   // row-block kernel: schedule interleave stride in row blocks (1 = none)
+    int cycle; // row-block kernel: block-cyclic schedule over the XCDs, cycle length in row blocks (1 = one contiguous eighth per XCD)
 };
+
+// Row-block schedule shared by the row-block kernels: work-group b runs on XCD b%8 as that XCD's (b/8)-th block.
+// cycle > 1: block-cyclic -- cycles of `cycle` row blocks, XCD j takes the j-th run of ceil(cycle/8) blocks of each;
+// cycle <= 1: XCD j owns the j-th contiguous eighth.  Returns -1 for the padding work-groups of the grid.
+CG_DEV int rowblock_of(int b, int row_blocks, int cycle) {
+    const int xcd = b & 7, i = b >> 3;
+    if (cycle > 1) {
+        const int chunk = (cycle + 7) >> 3;
+        const int k = i / chunk, lo = xcd * chunk + (i - k * chunk);
+        const int rb = k * cycle + lo;
+        return (lo < cycle && rb < row_blocks) ? rb : -1;
+    }
+    const int xb = (int)((long long)xcd * row_blocks / 8), xe = (int)((long long)(xcd + 1) * row_blocks / 8);
+    return i < xe - xb ? xb + i : -1;
+}
+static int rowblock_grid(int row_blocks, int cycle) {
+    if (cycle > 1) return 8 * ((cycle + 7) / 8) * ((row_blocks + cycle - 1) / cycle);
+    int per_xcd = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int m = (int)((long long)(x + 1) * row_blocks / 8) - (int)((long long)x * row_blocks / 8);
+        per_xcd = m > per_xcd ? m : per_xcd;
+    }
+    return per_xcd * 8;
+}
 
 template <typename T, int BLOCK, int QPT, bool VEC, bool FUSE_DOT>
 __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs<T> a) {
@@ -301,15 +325,17 @@ CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols
 //     step k is issued by 64 lanes sitting in 64 consecutive rows: for banded matrices their k-th columns are
 //     consecutive, so one wave-level gather touches ~4 cache lines (a nnz-per-lane mapping touches ~24).
 //   * y is written coalesced; the fused d.q partial is one value per row block (fixed order later).
-//   * Schedule: work-group b runs on XCD b%8 (round-robin dispatch) as the (b/8)-th block of that XCD; each
-//     XCD owns one contiguous eighth of the row blocks, so the x window it gathers from stays in its own
-//     L2.  Measured on the N=10M 7-point system: HBM reads 982 MB against 957 MB algorithmic (x fetched
-//     ~once), whereas persistent work-groups re-fetched x once per far diagonal (1128 MB) and ran
+//   * Schedule: work-group b runs on XCD b%8 (round-robin dispatch) as the (b/8)-th block of that XCD.  The row
+//     blocks are dealt BLOCK-CYCLICALLY: cycles of `cycle` row blocks (cgamd_tune "spmv_cycle", default 64), and in
+//     every cycle XCD j takes the j-th run of cycle/8 consecutive blocks.  All 8 XCDs therefore sweep the matrix
+//     together (the whole chip streams one ~1 MB region at a time and finishes together) while every XCD still
+//     gathers x through runs of consecutive row blocks that share cache lines in its private L2.  Against one
+//     contiguous eighth of the matrix per XCD (cycle = 1): SpMV 180.6 -> 174.2 us, CG 3208 -> 3366 it/s on the
+//     N=10M 7-point system, 3448 -> 3722 it/s on the 9M-row Helmholtz FE matrix; cycles of 8/16 (runs of 1-2 blocks)
+//     lose 4-10 %, 32...800 are within 1 % of each other (profiles/r1_experiments/ab_cyc_*.log).
+//     Persistent work-groups re-fetched x once per far diagonal (1128 MB against 957 MB algorithmic) and ran
 //     12-15 % slower; software-pipelined persistent variants were no faster either
 //     (profiles/r1_experiments/ab*.log, pmc_*_summary.txt).
-//   * Optional interleave stride `far` (cgamd_tune "spmv_far", default 1 = off): consecutive dispatches of
-//     an XCD take blocks y, y+far, y+2far, ... (z-neighbours of a 3-D stencil resident together).  It did
-//     not pay at N=10M (x already stays in L2/Infinity Cache) and is kept only as a tuning knob.
 // LDS is sized at launch from the plan's largest slice (values + columns).
 // -------------------------------------------------------------------------------------------------
 template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL, int POL = -1>
@@ -326,15 +352,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
         if ((int)blockIdx.x >= a.rb_count) return;
         rb = a.rb_list[blockIdx.x];
     } else {
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        const int xb = (int)((long long)xcd * a.row_blocks / 8), xe = (int)((long long)(xcd + 1) * a.row_blocks / 8);
-        const int m = xe - xb;
-        if (i >= m) return;
-        const int S = min(max(a.far, 1), m), q = m / S, rem = m % S;
-        int y, z;
-        if (i < rem * (q + 1)) { y = i / (q + 1); z = i % (q + 1); }
-        else { const int j = i - rem * (q + 1); y = rem + j / q; z = j % q; }
-        rb = xb + y + z * S;
+        rb = rowblock_of(blockIdx.x, a.row_blocks, a.cycle);
+        if (rb < 0) return;
     }
     const int r0 = rb * BLOCK;
     const int row = r0 + t;
@@ -401,10 +420,8 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowblock_kernel(SpmvArgs<T> a) {
     A *wavedot = reinterpret_cast<A *>(dyn_smem + (size_t)a.cap * (sizeof(T) + 4));   // [nrhs][BLOCK/64]
 
     const int t = threadIdx.x;
-    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-    const int xb = (int)((long long)xcd * a.row_blocks / 8), xe = (int)((long long)(xcd + 1) * a.row_blocks / 8);
-    if (i >= xe - xb) return;
-    const int rb = xb + i;
+    const int rb = rowblock_of(blockIdx.x, a.row_blocks, a.cycle);
+    if (rb < 0) return;
     const int r0 = rb * BLOCK;
     const int row = r0 + t;
     // The work-group's lifetime is a chain of dependent memory round trips; keep it at three: {row pointers}
@@ -487,7 +504,7 @@ template <> struct Mfma<double> { using acc = f64x4; static CG_DEV int row(int l
 template <> struct Mfma<float> { using acc = f32x4; static CG_DEV int row(int lane, int reg) { return 4 * (lane >> 4) + reg; } };
 
 template <typename T> struct SpmmMfmaArgs {
-    int n, nrhs, row_blocks, cap;
+    int n, nrhs, row_blocks, cap, cycle;
     long long nnz;
     const T *vals;
     const int *ptr, *cols;
@@ -502,10 +519,9 @@ __global__ __launch_bounds__(BLOCK) void spmm_mfma_kernel(SpmmMfmaArgs<T> a) {
     T *sv = reinterpret_cast<T *>(dyn_smem);
     int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
-    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-    const int xb = (int)((long long)xcd * a.row_blocks / 8), xe = (int)((long long)(xcd + 1) * a.row_blocks / 8);
-    if (i >= xe - xb) return;
-    const int r0 = (xb + i) * BLOCK;
+    const int rbm = rowblock_of(blockIdx.x, a.row_blocks, a.cycle);
+    if (rbm < 0) return;
+    const int r0 = rbm * BLOCK;
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
     stage_slice<T, BLOCK, true>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
@@ -1102,14 +1118,9 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     const int variant = (vec && nrhs == 1 && plan.kind == 5) ? 5 : 0;
     if (variant == 5) {
         a.cap = (plan.max_span + 3) & ~3;
-        a.far = g_tune.spmv_far > 0 ? g_tune.spmv_far : 1;
+        a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
         const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + (size_t)g_tune.spmv_lds_pad;
-        int per_xcd = 0;
-        for (int x = 0; x < 8; ++x) {
-            const int m = (int)((long long)(x + 1) * plan.row_blocks / 8) - (int)((long long)x * plan.row_blocks / 8);
-            per_xcd = m > per_xcd ? m : per_xcd;
-        }
-        dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : per_xcd * 8);
+        dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : rowblock_grid(plan.row_blocks, a.cycle));
         if (rb_list && rb_count <= 0) return CGAMD_OK;
         const bool nt = g_tune.spmv_nt != 0;
 #define CG_RB(NT, UNR)                                                                                           \
@@ -1136,14 +1147,9 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     }
     if (vec && nrhs > 1 && plan.kind == 6) {
         a.cap = (plan.max_span + 3) & ~3;
-        a.far = 1;
+        a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
         const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave);
-        int per_xcd = 0;
-        for (int x = 0; x < 8; ++x) {
-            const int m = (int)((long long)(x + 1) * plan.row_blocks / 8) - (int)((long long)x * plan.row_blocks / 8);
-            per_xcd = m > per_xcd ? m : per_xcd;
-        }
-        dim3 g6(per_xcd * 8);
+        dim3 g6(rowblock_grid(plan.row_blocks, a.cycle));
         constexpr int RB = sizeof(T) <= 8 ? 8 : 4;
         // One launch covers all right-hand sides (groups of RB inside the kernel).  Splitting into one launch per
         // group (cgamd_tune "spmm_rb") re-reads the matrix per group and shrinks the x window per XCD; measured
@@ -1365,12 +1371,8 @@ static int spmm_mfma_impl(const SpmvPlan &plan, int n, long long nnz, const void
     a.n = n; a.nrhs = nrhs; a.row_blocks = plan.row_blocks; a.cap = (plan.max_span + 3) & ~3; a.nnz = nnz;
     a.vals = (const T *)vals; a.ptr = ptr; a.cols = cols; a.x = (const T *)x; a.y = (T *)y;
     const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
-    int per_xcd = 0;
-    for (int xx = 0; xx < 8; ++xx) {
-        const int m = (int)((long long)(xx + 1) * plan.row_blocks / 8) - (int)((long long)xx * plan.row_blocks / 8);
-        per_xcd = m > per_xcd ? m : per_xcd;
-    }
-    dim3 g(per_xcd * 8), b(kBlock);
+    a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
+    dim3 g(rowblock_grid(plan.row_blocks, a.cycle)), b(kBlock);
     if (nrhs == 16) hipLaunchKernelGGL((spmm_mfma_kernel<T, kBlock, 1>), g, b, lds, st, a);
     else hipLaunchKernelGGL((spmm_mfma_kernel<T, kBlock, 2>), g, b, lds, st, a);
     return check_launch("spmm_mfma");

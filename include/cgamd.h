@@ -51,9 +51,9 @@ int cgamd_version(void);
 size_t cgamd_dtype_size(int dtype);
 
 /* run-time tuning knobs (A/B experiments and profiling): "spmv_variant" (5 = row-block kernel, default;
- * 0 = generic chunked kernel), "spmv_nt" (non-temporal matrix loads, default 1), "spmv_far" (row-block
- * schedule interleave stride, default 1), "spmv_grid" / "vec_grid" (0 = auto).  Read when a solver is created
- * (variant, grids) or at launch (nt, far). */
+ * 0 = generic chunked kernel), "spmv_nt" (non-temporal matrix loads, default 1), "spmv_cycle" (row-block
+ * schedule: block-cyclic over the 8 XCDs with this cycle length in row blocks, default 64; 1 = contiguous eighths), "spmv_grid" / "vec_grid" (0 = auto).  Read when a solver is created
+ * (variant, grids) or at launch (nt, cycle). */
 int cgamd_tune(const char *key, int value);
 
 /* ---- devices / context (reference cl.py:16-31) -------------------------- */
