@@ -17,7 +17,7 @@ DTYPE_CODE = {np.dtype(np.float32): F32, np.dtype(np.float64): F64,
               np.dtype(np.complex64): C64, np.dtype(np.complex128): C128}
 CODE_DTYPE = {v: k for k, v in DTYPE_CODE.items()}
 
-MATRIX_ON_DEVICE, NO_GRAPH, UNFUSED, DIST_GRAPH, DIST_NO_OVERLAP, DIST_P2P = 1, 2, 4, 8, 32, 64
+MATRIX_ON_DEVICE, NO_GRAPH, UNFUSED, DIST_GRAPH, DIST_NO_OVERLAP, DIST_P2P, DIST_P2P_STAGED = 1, 2, 4, 8, 32, 64, 128
 
 
 class CgAmdError(RuntimeError):

@@ -37,21 +37,24 @@ struct SpmvPlan {
     int max_span = 0;    // largest 4-aligned nnz span of a kBlock-row slice (0 = unknown -> generic kernel)
     int kind = 0;        // kernel chosen by finalize_spmv_plan (0 generic ... 5 row-block)
     int n_partials = 0;  // fused-dot partials per RHS written by that kernel
+    int nt = 1;          // matrix stream loaded non-temporally (finalize_spmv_plan: off when the matrix fits the Infinity Cache)
+    int vec_nt = 3;      // axpy2_dot streaming hints (see Tuning::vec_nt), resolved by finalize_spmv_plan
 };
 SpmvPlan make_spmv_plan(int n);
 // fills plan->max_span from the matrix structure; synchronises `st`; scratch_dev: >= 4 bytes
 int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan);
-void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, const void *vals, const int *cols);
+void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols);
 constexpr int kMaxSliceBytes = 64 * 1024;   // variant 5: largest LDS slice accepted (else the generic chunked kernel runs)
 
 // run-time tuning knobs (cgamd_tune); defaults are the shipped configuration
 struct Tuning {
     int spmv_variant = 5;   // 5 = row-block kernel (matrix through LDS, one row block per work-group), 0 = generic chunked
-    int spmv_nt = 1;        // non-temporal matrix loads
+    int spmv_nt = -1;       // non-temporal matrix loads: 1 on, 0 off, -1 auto = on unless the matrix fits the 256 MB Infinity
+                            // Cache (<= 384 MB measured break-even: below it the re-used matrix is served from the cache)
     int spmv_unroll = 0;    // row walk: LDS reads + gathers in flight per lane (4 or 8; 0 = 8, or 4 for 16-byte values)
     int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = all in one launch)
     int vec_skew = 0;       // bytes added to the pitch between the solver's vectors (multiple of 16)
-    int vec_nt = 3;         // axpy2_dot: bit0 = x loaded/stored non-temporally (touched once per iteration), bit1 = q loaded
+    int vec_nt = -1;        // -1 auto (3, or 0 when matrix + vectors stay cache resident); axpy2_dot: bit0 = x loaded/stored non-temporally (touched once per iteration), bit1 = q loaded
                             // non-temporally (its last use): d and r, which are re-read, keep the caches; measured -10..-22 us/iteration
     int spmv_policy = -1;   // experiment: >= 0 = matrix stream via buffer loads with this cache-policy aux field
     int spmv_lds_pad = 0;   // experiment: extra dynamic LDS bytes per work-group (lowers occupancy)
@@ -81,7 +84,7 @@ int launch_aypx(int dtype, int n, const void *x, void *y, long long ld, const vo
 int launch_sub(int dtype, int n, const void *a, const void *b, void *res, long long ld, int nrhs, hipStream_t st);
 // fused x += alpha d ; r -= alpha q ; partials(r.r)
 int launch_axpy2_dot(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld,
-                     const void *alpha, int nrhs, void *partials, int grid, hipStream_t st);
+                     const void *alpha, int nrhs, void *partials, int grid, hipStream_t st, int vec_nt = 3);
 
 // device-resident scalar state of one CG run
 struct CgScalars {
@@ -123,12 +126,25 @@ struct P2pExchange {
               *recv_count = nullptr;  // device arrays [n_peers]
     const int *send_index = nullptr;
     unsigned long long *epoch = nullptr;
+    unsigned *counters = nullptr;     // device, zero-initialised: [0] unpack, [1 + p] push of peer p
+    int max_count = 0;                // largest send/recv count over the peers
+    const void *my_halo = nullptr;    // halo area of MY mailbox (entry h = column n_local + h)
 };
+int p2p_push_chunks(const P2pExchange &e);
+// four-launch peer-to-peer iteration (see kernels.hip): SpMV with the push and the wait inside, aypx with the beta all-reduce.
+// halo_flag: device int per row block (1 = references a halo column); rotate: first row block of the visiting order
+int launch_spmv_p2p(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
+                    const void *d_ext, void *q, void *partials, const int *halo_flag, int rotate, const P2pExchange &e,
+                    hipStream_t st);
+int spmv_p2p_grid(const SpmvPlan &plan);
+int launch_aypx_beta_p2p(int dtype, int n, const void *x, void *y, const void *partials, int P, char *const *mailbox, int rank,
+                         int nranks, int which, const unsigned long long *epoch, const CgScalars &sc, hipStream_t st);
 int launch_p2p_exchange(int dtype, const P2pExchange &e, void *v_ext, hipStream_t st);
 // global sum (rank order) of the local sum of `partials`, followed in the same launch by the scalar step that consumes
 // it: mode 1 = cg_delta0, 2 = cg_alpha, 3 = cg_beta; which in {0,1} selects the slot set
 int launch_p2p_allreduce(int dtype, int mode, const void *partials, int grid, char *const *mailbox, int rank, int nranks,
-                         int which, unsigned long long *epoch, const CgScalars &sc, hipStream_t st);
+                         int which, unsigned long long *epoch, const CgScalars &sc, hipStream_t st,
+                         unsigned long long *bump0 = nullptr, unsigned long long *bump1 = nullptr);
 
 // synthetic generators (device)
 int launch_gen_laplace3d(int dtype, int nx, int ny, int nz, long long row_begin, long long row_end, void *vals,

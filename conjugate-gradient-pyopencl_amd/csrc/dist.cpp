@@ -114,6 +114,11 @@ struct cgamd_dist {
     int n_interior = 0, n_boundary = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // four-launch peer-to-peer iteration: per-row-block flag "references a halo column" and the row block the SpMV
+    // launch starts from (the leading boundary blocks of a slab partition are visited last)
+    bool direct = false;
+    int *halo_flag = nullptr;
+    int rotate = 0;
 };
 
 static int dalloc(void **p, size_t bytes, const char *what) {
@@ -173,6 +178,16 @@ static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
     const int dt = d->dtype, n = d->n_local;
     const long long ldx = (long long)d->n_local + d->n_halo;
     int rc;
+    if (d->direct && d->p2p_attached) {
+        // peer-to-peer, four launches: [push | wait | SpMV | d.q], [all-reduce d.q, alpha], [axpy x2 + r.r], [all-reduce r.r, beta, aypx]
+        if ((rc = launch_spmv_p2p(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, d->q, d->part_dq, d->halo_flag,
+                                  d->rotate, d->xch, st))) return rc;
+        if ((rc = launch_p2p_allreduce(dt, 2, d->part_dq, d->plan.n_partials, d->mailbox_dev, d->rank, d->nranks, 0, d->epochs + 1,
+                                       d->sc, st, d->epochs, d->epochs + 2))) return rc;
+        if ((rc = launch_axpy2_dot(dt, n, d->d_ext, d->x, d->q, d->r, n, d->sc.alpha, 1, d->part_rr, d->vgrid, st, d->plan.vec_nt))) return rc;
+        return launch_aypx_beta_p2p(dt, n, d->r, d->d_ext, d->part_rr, d->vgrid, d->mailbox_dev, d->rank, d->nranks, 1,
+                                    d->epochs + 2, d->sc, st);
+    }
     if (d->overlap) {
         // fork: the exchange runs on the comm stream while the row blocks that reference no halo column are
         // multiplied; the boundary blocks follow once the halo has landed.  Both launches write disjoint
@@ -191,15 +206,14 @@ static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
         if ((rc = launch_spmv(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, ldx, d->q, n, 1, d->d_ext, d->part_dq, st))) return rc;
     }
     if ((rc = reduce_all(d, d->part_dq, d->plan.n_partials, 0, 2, st))) return rc;
-    if ((rc = launch_axpy2_dot(dt, n, d->d_ext, d->x, d->q, d->r, n, d->sc.alpha, 1, d->part_rr, d->vgrid, st))) return rc;
+    if ((rc = launch_axpy2_dot(dt, n, d->d_ext, d->x, d->q, d->r, n, d->sc.alpha, 1, d->part_rr, d->vgrid, st, d->plan.vec_nt))) return rc;
     if ((rc = reduce_all(d, d->part_rr, d->vgrid, 1, 3, st))) return rc;
     return launch_aypx(dt, n, d->r, d->d_ext, n, d->sc.beta, 1, st);
 }
 
 // classify the row blocks once: boundary = references a halo column
-static int build_overlap_lists(cgamd_dist *d) {
+static int classify_row_blocks(cgamd_dist *d, std::vector<int> *interior, std::vector<int> *boundary) {
     const int nb = d->plan.row_blocks;
-    if (d->n_halo == 0 || d->plan.kind != 5 || nb < 16) return CGAMD_OK;
     int *flags_dev = nullptr;
     if (int rc = dalloc((void **)&flags_dev, sizeof(int) * (size_t)nb, "halo flags")) return rc;
     int rc = launch_halo_flags(d->n_local, d->ptr, d->cols, d->n_local, nb, flags_dev, d->ctx->stream);
@@ -209,19 +223,41 @@ static int build_overlap_lists(cgamd_dist *d) {
     (void)hipFree(flags_dev);
     if (rc) return rc;
     if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("halo flags: ") + hipGetErrorString(e));
-    std::vector<int> interior, boundary;
-    for (int rb = 0; rb < nb; ++rb) (flags[(size_t)rb] ? boundary : interior).push_back(rb);
-    if (boundary.empty() || boundary.size() * 2 > (size_t)nb) return CGAMD_OK;   // nothing to hide it behind
-    if ((rc = dalloc((void **)&d->interior_list, sizeof(int) * interior.size(), "interior list"))) return rc;
-    if ((rc = dalloc((void **)&d->boundary_list, sizeof(int) * boundary.size(), "boundary list"))) return rc;
-    CG_HIP(hipMemcpy(d->interior_list, interior.data(), sizeof(int) * interior.size(), hipMemcpyHostToDevice));
-    CG_HIP(hipMemcpy(d->boundary_list, boundary.data(), sizeof(int) * boundary.size(), hipMemcpyHostToDevice));
+    for (int rb = 0; rb < nb; ++rb) (flags[(size_t)rb] ? boundary : interior)->push_back(rb);
+    return CGAMD_OK;
+}
+
+static int upload_ints(int **dev, const std::vector<int> &v, const char *what) {
+    if (int rc = dalloc((void **)dev, sizeof(int) * v.size(), what)) return rc;
+    if (!v.empty()) CG_HIP(hipMemcpy(*dev, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+    return CGAMD_OK;
+}
+
+static int build_overlap_lists(cgamd_dist *d, const std::vector<int> &interior, const std::vector<int> &boundary) {
+    const int nb = d->plan.row_blocks;
+    if (nb < 16 || boundary.empty() || boundary.size() * 2 > (size_t)nb) return CGAMD_OK;   // nothing to hide it behind
+    int rc;
+    if ((rc = upload_ints(&d->interior_list, interior, "interior list"))) return rc;
+    if ((rc = upload_ints(&d->boundary_list, boundary, "boundary list"))) return rc;
     d->n_interior = (int)interior.size();
     d->n_boundary = (int)boundary.size();
     CG_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
     CG_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
     CG_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
     d->overlap = true;
+    return CGAMD_OK;
+}
+
+// four-launch peer-to-peer SpMV: flags per row block, visiting order rotated past the leading boundary blocks
+static int build_direct_schedule(cgamd_dist *d, const std::vector<int> &boundary) {
+    const int nb = d->plan.row_blocks;
+    std::vector<int> flag((size_t)nb, 0);
+    for (int rb : boundary) flag[(size_t)rb] = 1;
+    int lead = 0;
+    while (lead < nb && flag[(size_t)lead]) ++lead;
+    d->rotate = lead < nb ? lead : 0;
+    if (int rc = upload_ints(&d->halo_flag, flag, "halo flags")) return rc;
+    d->direct = true;
     return CGAMD_OK;
 }
 
@@ -315,7 +351,7 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     if (!rc) rc = dalloc((void **)&d->sc.iter, 16, "iter");
     if (!rc) rc = ensure_history(d, 1024);
     if (!rc) rc = compute_spmv_plan(d->ptr, d->cols, n_local, d->sc.iter, ctx->stream, &d->plan);
-    if (!rc) finalize_spmv_plan(&d->plan, dtype, 1, d->vals, d->cols);
+    if (!rc) finalize_spmv_plan(&d->plan, dtype, 1, n_local, nnz_local, d->vals, d->cols);
     if (!rc && id128 && !d->p2p) {
         rc = need_rccl();
         if (!rc) {
@@ -328,7 +364,14 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     // hipGraph capture of the two-stream fork/join around RCCL send/recv crashed in the runtime (ROCm 7.0/7.2,
     // RCCL 2.26): with RCCL the graph mode therefore runs the exchange in line and the plain-launch mode overlaps
     // it; the peer-to-peer backend is pure kernels and overlaps in both modes.
-    if (!rc && !(flags & CGAMD_DIST_NO_OVERLAP) && ((d->comm && !(flags & CGAMD_DIST_GRAPH)) || d->p2p)) rc = build_overlap_lists(d);
+    if (!rc && d->n_halo > 0 && d->plan.kind == 5) {
+        std::vector<int> interior, boundary;
+        rc = classify_row_blocks(d, &interior, &boundary);
+        const bool staged = (flags & CGAMD_DIST_P2P_STAGED) != 0;
+        if (!rc && d->p2p && !staged) rc = build_direct_schedule(d, boundary);
+        if (!rc && !d->direct && !(flags & CGAMD_DIST_NO_OVERLAP) && ((d->comm && !(flags & CGAMD_DIST_GRAPH)) || d->p2p))
+            rc = build_overlap_lists(d, interior, boundary);
+    }
     if (rc) {
         std::string keep = cgamd_last_error();
         cgamd_dist_destroy(d);
@@ -355,6 +398,7 @@ int cgamd_dist_destroy(cgamd_dist *d) {
     if (d->ev_join) (void)hipEventDestroy(d->ev_join);
     if (d->interior_list) (void)hipFree(d->interior_list);
     if (d->boundary_list) (void)hipFree(d->boundary_list);
+    if (d->halo_flag) (void)hipFree(d->halo_flag);
     void *bufs[] = {d->x, d->r, d->q, d->b, d->d_ext, d->sendbuf, d->part_dq, d->part_rr, d->red, d->sc.alpha,
                     d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter};
     for (void *p : bufs)
@@ -487,8 +531,9 @@ int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, 
     int rc;
     if ((rc = dalloc((void **)&d->mailbox_dev, sizeof(char *) * (size_t)d->nranks, "mailbox table"))) return rc;
     CG_HIP(hipMemcpy(d->mailbox_dev, base.data(), sizeof(char *) * (size_t)d->nranks, hipMemcpyHostToDevice));
-    if ((rc = dalloc((void **)&d->epochs, 64, "epochs"))) return rc;
-    CG_HIP(hipMemset(d->epochs, 0, 64));
+    const size_t epoch_bytes = 64 + sizeof(unsigned) * (size_t)(1 + np);   // 3 epochs, then the work-group counters
+    if ((rc = dalloc((void **)&d->epochs, epoch_bytes, "epochs"))) return rc;
+    CG_HIP(hipMemset(d->epochs, 0, epoch_bytes));
     std::vector<int> plan((size_t)np * 6 + 1, 0);
     for (int p = 0; p < np; ++p) {
         plan[(size_t)p] = d->peer[(size_t)p];
@@ -505,6 +550,11 @@ int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, 
     x.peer_rank = d->plan_dev; x.send_off = d->plan_dev + np; x.send_count = d->plan_dev + 2 * np;
     x.dst_off = d->plan_dev + 3 * np; x.recv_off = d->plan_dev + 4 * np; x.recv_count = d->plan_dev + 5 * np;
     x.send_index = d->send_index; x.epoch = d->epochs;
+    x.counters = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(d->epochs) + 64);
+    x.my_halo = d->my_mailbox + kMailboxHeader;
+    x.max_count = 0;
+    for (int p = 0; p < np; ++p) x.max_count = std::max(x.max_count, std::max(d->send_count[(size_t)p], d->recv_count[(size_t)p]));
+    if (d->direct && spmv_p2p_grid(d->plan) < np * p2p_push_chunks(x)) d->direct = false;   // too few work-groups to carry the push
     d->p2p_attached = true;
     return CGAMD_OK;
 }

@@ -110,7 +110,7 @@ template <typename T> struct SpmvArgs {
 // Row-block schedule shared by the row-block kernels: work-group b runs on XCD b%8 as that XCD's (b/8)-th block.
 // cycle > 1: block-cyclic -- cycles of `cycle` row blocks, XCD j takes the j-th run of ceil(cycle/8) blocks of each;
 // cycle <= 1: XCD j owns the j-th contiguous eighth.  Returns -1 for the padding work-groups of the grid.
-CG_DEV int rowblock_of(int b, int row_blocks, int cycle) {
+__host__ __device__ __forceinline__ int rowblock_of(int b, int row_blocks, int cycle) {
     const int xcd = b & 7, i = b >> 3;
     if (cycle > 1) {
         const int chunk = (cycle + 7) >> 3;
@@ -859,16 +859,26 @@ __global__ __launch_bounds__(256) void pack_kernel(int count, const int *__restr
 //     [4096,6144)   halo flags       flag[source rank] = epoch of the last complete boundary push
 //     [6144,8192)   error word
 //     [8192,...)    halo entries     laid out exactly like the halo part of d_ext
-// Hand-off protocol (system scope, placement independent): payload stores -> every thread's
-// __threadfence_system() -> work-group barrier -> ONE release store of the epoch; the consumer polls that one word
-// relaxed, then one acquire fence, then reads the payload with system-scope loads.  Epochs come from device
-// counters advanced by the consuming kernel, so a hipGraph replays the protocol unchanged.  Slot reuse is safe
-// because two full all-reduces separate consecutive uses of any slot or of the halo area.  Spins are bounded;
-// a timeout sets the error word and the kernels fall through.
+// Hand-off protocol (placement independent).  Every mailbox access is a system-scope relaxed atomic load/store, i.e. a
+// write-through / cache-bypassing access (sc0 sc1) to memory that is mapped uncached anyway.  Producer: payload stores ->
+// every thread waits until its stores are acknowledged (p2p_stores_done: s_waitcnt vmcnt(0), NO cache maintenance) ->
+// work-group barrier -> one store of the epoch.  Consumer: polls that word, then reads the payload with the same
+// cache-bypassing loads.  Deliberately NOT system-scope release/acquire fences: on gfx950 those write back / invalidate
+// the whole L2 of the XCD (buffer_wbl2 / buffer_inv sc0 sc1), and inside the SpMV and aypx launches that threw the
+// vectors out of L2 once per pushing or waiting work-group (SpMV 21 -> 36 us on a 1.25M-row slab).
+// Epochs come from device counters advanced by a later single-work-group kernel, so a hipGraph replays the protocol
+// unchanged.  Slot reuse is safe because two full all-reduces separate consecutive uses of any slot or of the halo area.
+// Spins are bounded; a timeout sets the error word and the kernels fall through.
 // =================================================================================================
 constexpr int kMbSlots = 0, kMbHaloFlags = 4096, kMbError = 6144, kMbHalo = 8192;
 constexpr long long kSpinLimit = 1LL << 21;   // polls of ~1-2 us each: a few seconds, then the error word is set
 
+// all of this lane's earlier stores are acknowledged by the memory system; compiler-level ordering included
+CG_DEV void p2p_stores_done() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
 CG_DEV void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 CG_DEV unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 CG_DEV void st_sys_val(float *p, float v) { __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -901,41 +911,255 @@ struct P2pExchangeArgs {
     const int *peer_rank, *send_off, *send_count, *dst_off, *recv_off, *recv_count;   // device arrays [n_peers]
     const int *send_index;
     unsigned long long *epoch;  // device counter of boundary exchanges
+    unsigned *counters;         // device: [0] unpack work-groups done, [1 + p] push work-groups done for peer p (all 0 between launches)
+    int max_count;              // largest send/recv count over the peers (grid sizing)
 };
 
-// one work-group per peer: gather my boundary entries straight into the peer's mailbox, then publish the epoch
-template <typename T> __global__ __launch_bounds__(1024) void p2p_push_kernel(P2pExchangeArgs a, const T *v) {
-    const int p = blockIdx.x;
-    const unsigned long long ep = *a.epoch + 1;
+// Push: blockIdx.y = peer, blockIdx.x = chunk of kP2pChunk entries.  Every work-group gathers its chunk of my boundary
+// entries straight into the peer's mailbox (one 8/16-byte system-scope store per lane, all in flight together); the
+// LAST work-group of a peer to finish (device counter) publishes the epoch flag with release semantics.
+constexpr int kP2pBlock = 256, kP2pChunk = 1024;
+// chunk c (of `chunks`) of my boundary entries for peer p; called by a whole kP2pBlock-thread work-group
+template <typename T> CG_DEV void p2p_push_chunk(const P2pExchangeArgs &a, const T *v, int p, int c, int chunks, unsigned long long ep) {
     char *mb = a.mailbox[a.peer_rank[p]];
     T *dst = reinterpret_cast<T *>(mb + kMbHalo) + a.dst_off[p];
     const int *idx = a.send_index + a.send_off[p];
-    for (int k = threadIdx.x; k < a.send_count[p]; k += blockDim.x) st_sys_val(dst + k, v[idx[k]]);
-    __threadfence_system();
+    const int cnt = a.send_count[p], k0 = c * kP2pChunk + threadIdx.x;
+    if (c * kP2pChunk < cnt) {
+        T val[kP2pChunk / kP2pBlock];
+#pragma unroll
+        for (int u = 0; u < kP2pChunk / kP2pBlock; ++u) val[u] = v[idx[min(k0 + u * kP2pBlock, cnt - 1)]];
+#pragma unroll
+        for (int u = 0; u < kP2pChunk / kP2pBlock; ++u) {
+            const int k = k0 + u * kP2pBlock;
+            if (k < cnt) st_sys_val(dst + k, val[u]);
+        }
+    }
+    p2p_stores_done();
     __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mb + kMbHaloFlags) + a.rank, ep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        unsigned *done = a.counters + 1 + p;
+        const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)prev + 1 == chunks) {      // every chunk's stores were acknowledged before its increment
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st_sys(reinterpret_cast<unsigned long long *>(mb + kMbHaloFlags) + a.rank, ep);
+        }
+    }
+}
+template <typename T> __global__ __launch_bounds__(kP2pBlock) void p2p_push_kernel(P2pExchangeArgs a, const T *v) {
+    p2p_push_chunk<T>(a, v, blockIdx.y, blockIdx.x, gridDim.x, *a.epoch + 1);
 }
 
-// one work-group: wait for every peer's epoch, copy the landed entries into the halo part of v_ext, advance the epoch
-template <typename T> __global__ __launch_bounds__(1024) void p2p_wait_unpack_kernel(P2pExchangeArgs a, T *v_ext) {
-    __shared__ int ok;
+// Unpack: same grid shape.  Every work-group waits for its peer's epoch (one polling lane), then copies its chunk of the
+// landed entries into the halo part of v_ext; the last work-group overall advances the exchange epoch.
+template <typename T> __global__ __launch_bounds__(kP2pBlock) void p2p_wait_unpack_kernel(P2pExchangeArgs a, T *v_ext) {
+    const int p = blockIdx.y;
     const unsigned long long ep = *a.epoch + 1;
     char *mb = a.mailbox[a.rank];
-    for (int p = 0; p < a.n_peers; ++p) {
-        if (a.recv_count[p] == 0) continue;
+    const int cnt = a.recv_count[p], k0 = blockIdx.x * kP2pChunk + threadIdx.x;
+    if ((int)blockIdx.x * kP2pChunk < cnt) {
         if (threadIdx.x == 0) {
-            ok = spin_until(reinterpret_cast<unsigned long long *>(mb + kMbHaloFlags) + a.peer_rank[p], ep) ? 1 : 0;
-            if (!ok) st_sys(reinterpret_cast<unsigned long long *>(mb + kMbError), 1ULL);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            if (!spin_until(reinterpret_cast<unsigned long long *>(mb + kMbHaloFlags) + a.peer_rank[p], ep))
+                st_sys(reinterpret_cast<unsigned long long *>(mb + kMbError), 1ULL);
         }
         __syncthreads();
         const T *src = reinterpret_cast<const T *>(mb + kMbHalo) + a.recv_off[p];
         T *dst = v_ext + a.n_local + a.recv_off[p];
-        for (int k = threadIdx.x; k < a.recv_count[p]; k += blockDim.x) dst[k] = ld_sys_val(src + k);
+        T val[kP2pChunk / kP2pBlock];
+#pragma unroll
+        for (int u = 0; u < kP2pChunk / kP2pBlock; ++u) val[u] = ld_sys_val(src + min(k0 + u * kP2pBlock, cnt - 1));
+#pragma unroll
+        for (int u = 0; u < kP2pChunk / kP2pBlock; ++u) {
+            const int k = k0 + u * kP2pBlock;
+            if (k < cnt) dst[k] = val[u];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(a.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1 == gridDim.x * gridDim.y) {       // everybody has read *a.epoch
+            __hip_atomic_store(a.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *a.epoch = ep;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Peer-to-peer CG iteration in four launches (same count as the single-GPU loop):
+//   spmv_rowblock_p2p_kernel : push + wait + SpMV + d.q partials     p2p_allreduce_kernel<2>: alpha (bumps the epochs)
+//   axpy2_dot_kernel         : unchanged                              aypx_beta_p2p_kernel  : all-reduce of r.r + beta + aypx
+// spmv_rowblock_p2p_kernel = spmv_rowblock_kernel (same block-cyclic XCD schedule, rotated so that the leading boundary
+// row blocks of a slab partition are visited last) plus a per-row-block flag "references a halo column", where
+//   * the first n_peers * push_chunks work-groups first ship one chunk of my boundary entries of d into the peers'
+//     mailboxes (p2p_push_chunk), so the halo is on the wire before any SpMV work starts;
+//   * the boundary row blocks wait for the peers' epoch flags after issuing their matrix slice loads and gather halo
+//     columns (col >= n_local) straight from the mailbox; there is no unpack pass;
+//   * interior row blocks never look at a flag: the xGMI latency hides behind them.
+// Nobody writes the exchange epoch here; the alpha kernel that follows in stream order advances it.
+// -------------------------------------------------------------------------------------------------
+template <typename T> struct SpmvP2pArgs {
+    SpmvArgs<T> s;          // rb_list = per-row-block flag (1 = references a halo column), cycle = block-cyclic schedule
+    P2pExchangeArgs x;
+    const T *halo;          // my mailbox's halo area: entry h is column n_local + h
+    int n_local, rotate, push_chunks;   // rotate: row blocks are visited from this one on, so leading boundary blocks come last
+};
+
+template <typename T, int BLOCK, bool NT, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T> g) {
+    using A = typename VT<T>::acc;
+    const SpmvArgs<T> &a = g.s;
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    T *sv = reinterpret_cast<T *>(dyn_smem);
+    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));
+    __shared__ A red[BLOCK / kWave];
+    const int t = threadIdx.x, b = blockIdx.x;
+    // the epoch is loaded only where it is needed: a load here would sit in front of every work-group's first wait
+    if (b < g.x.n_peers * g.push_chunks)
+        p2p_push_chunk<T>(g.x, a.x, b / g.push_chunks, b % g.push_chunks, g.push_chunks, *g.x.epoch + 1);
+    // the schedule is arithmetic (a list lookup here would put one more memory round trip in front of every work-group)
+    int rb = rowblock_of(b, a.row_blocks, a.cycle);
+    if (rb < 0) return;
+    rb += g.rotate;
+    if (rb >= a.row_blocks) rb -= a.row_blocks;
+    const int bflag = a.rb_list[rb];          // consumed after the slice loads are in flight
+    const int r0 = rb * BLOCK, row = r0 + t;
+    const int rclamp = min(row, a.n - 1);
+    const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
+    const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
+    const int cfirst = p0 & ~3;
+    stage_slice<T, BLOCK, NT, -1>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+    const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
+    const bool boundary = bflag != 0;
+    if (boundary && t == 0) {
+        const char *mb = g.x.mailbox[g.x.rank];
+        const unsigned long long ep = *g.x.epoch + 1;
+        for (int p = 0; p < g.x.n_peers; ++p) {
+            if (g.x.recv_count[p] == 0) continue;
+            if (!spin_until(reinterpret_cast<const unsigned long long *>(mb + kMbHaloFlags) + g.x.peer_rank[p], ep))
+                st_sys(reinterpret_cast<unsigned long long *>(const_cast<char *>(mb) + kMbError), 1ULL);
+        }
+    }
+    __syncthreads();
+    T sum = vzero<T>();
+    if (boundary) {
+        for (int k = s; k < e; k += UNROLL) {
+            T xv[UNROLL], av[UNROLL];
+            int cj[UNROLL];
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const int idx = min(k + j, e - 1);
+                cj[j] = sc[idx];
+                av[j] = sv[idx];
+            }
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const bool far = cj[j] >= g.n_local;
+                xv[j] = a.x[far ? rclamp : cj[j]];
+                if (far) xv[j] = ld_sys_val(g.halo + (cj[j] - g.n_local));     // in place from the mailbox, cache-bypassing
+            }
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const T nxt = vfma(av[j], xv[j], sum);
+                sum = vsel(k + j < e, nxt, sum);
+            }
+        }
+    } else {
+        for (int k = s; k < e; k += UNROLL) {
+            T xv[UNROLL], av[UNROLL];
+            int cj[UNROLL];
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const int idx = min(k + j, e - 1);
+                cj[j] = sc[idx];
+                av[j] = sv[idx];
+            }
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) xv[j] = a.x[cj[j]];
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const T nxt = vfma(av[j], xv[j], sum);
+                sum = vsel(k + j < e, nxt, sum);
+            }
+        }
+    }
+    A dot1 = vzero<A>();
+    if (row < a.n) {
+        a.y[row] = sum;
+        dot1 = to_acc(vmul(a.dvec[row], sum));
+    }
+    const A tot = block_sum<BLOCK>(dot1, red);
+    if (t == 0) a.partials[rb] = tot;
+}
+
+// d = beta d + r with the all-reduce of r.r and the beta step in the prologue.  Work-group 0 sums the local partials and
+// writes the result into slot set `which` of every rank's mailbox; EVERY work-group then waits for all ranks' slots in
+// its own mailbox and adds them in rank order (bitwise the same beta everywhere).  The epoch was advanced by the alpha
+// kernel of this iteration, so it is read-only here; slots are safe to reuse because a peer can only publish its next
+// value after it has seen my next d.q, which I publish after this launch has completed.
+template <typename T, int BLOCK, bool VEC>
+__global__ __launch_bounds__(BLOCK) void aypx_beta_p2p_kernel(int n, const T *x, T *y, const typename VT<T>::acc *partials, int P,
+                                                              char *const *mailbox, int rank, int nranks, int which,
+                                                              const unsigned long long *epoch, T *delta, T *beta, T *history,
+                                                              int history_cap, const int *iter) {
+    using A = typename VT<T>::acc;
+    __shared__ A red[BLOCK / kWave];
+    __shared__ double vx[64], vy[64];
+    __shared__ T beta_s;
+    const unsigned long long ep = *epoch;
+    const int s = threadIdx.x;
+    if (blockIdx.x == 0) {
+        A acc = vzero<A>();
+        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, partials[i]);
+        const A tot = block_sum<BLOCK>(acc, red);
+        if (threadIdx.x == 0) { const double2 v2 = to_acc2(tot); vx[0] = v2.x; vy[0] = v2.y; }
+        __syncthreads();
+        if (s < nranks) {
+            unsigned long long *slot = reinterpret_cast<unsigned long long *>(mailbox[s] + kMbSlots) + ((long long)which * 64 + rank) * 4;
+            st_sys(slot, (unsigned long long)__double_as_longlong(vx[0]));
+            st_sys(slot + 1, (unsigned long long)__double_as_longlong(vy[0]));
+            p2p_stores_done();
+            st_sys(slot + 2, ep);
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *a.epoch = ep;
+    if (s < nranks) {
+        const unsigned long long *in = reinterpret_cast<const unsigned long long *>(mailbox[rank] + kMbSlots) + ((long long)which * 64 + s) * 4;
+        if (!spin_until(in + 2, ep)) st_sys(reinterpret_cast<unsigned long long *>(mailbox[rank] + kMbError), 2ULL);
+        vx[s] = __longlong_as_double((long long)ld_sys(in));
+        vy[s] = __longlong_as_double((long long)ld_sys(in + 1));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double2 tot2 = make_double2(0., 0.);
+        for (int k = 0; k < nranks; ++k) { tot2.x += vx[k]; tot2.y += vy[k]; }
+        const int it = *iter;
+        const T dnT = from_acc<T>(from_acc2<A>(tot2));
+        const T dold = history[it - 1];
+        const T bt = from_acc<T>(acc_div(to_acc(dnT), to_acc(dold)));
+        beta_s = bt;
+        if (blockIdx.x == 0) {
+            beta[0] = bt;
+            delta[0] = dnT;
+            if (it < history_cap) history[it] = dnT;
+        }
+    }
+    __syncthreads();
+    const T al = beta_s;
+    constexpr int E = Pack<T>::N;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (VEC) {
+        const long long npack = n / E;
+        for (long long i = i0; i < npack; i += stride) {
+            const Pack<T> px = ld_pack(x + i * E);
+            Pack<T> py = ld_pack(y + i * E);
+#pragma unroll
+            for (int k = 0; k < E; ++k) py.v[k] = vadd(vmul(al, py.v[k]), px.v[k]);
+            st_pack(y + i * E, py);
+        }
+        i0 += npack * E;
+    }
+    for (long long i = i0; i < n; i += stride) y[i] = vadd(vmul(al, y[i]), x[i]);
 }
 
 // local partials -> sum over all ranks, in rank order on every rank (bitwise identical everywhere):
@@ -945,7 +1169,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kScalarBlock) void p2p_allreduce_kernel(const typename VT<T>::acc *partials, int grid,
                                                                      char *const *mailbox, int rank, int nranks, int which,
                                                                      unsigned long long *epoch, T *delta, T *alpha, T *beta,
-                                                                     T *history, int history_cap, int *iter) {
+                                                                     T *history, int history_cap, int *iter,
+                                                                     unsigned long long *bump0, unsigned long long *bump1) {
     using A = typename VT<T>::acc;
     __shared__ A smem[kScalarBlock / kWave];
     __shared__ double vx[64], vy[64];
@@ -957,10 +1182,10 @@ __global__ __launch_bounds__(kScalarBlock) void p2p_allreduce_kernel(const typen
         const double2 v2 = to_acc2(loc);
         st_sys(slot, (unsigned long long)__double_as_longlong(v2.x));
         st_sys(slot + 1, (unsigned long long)__double_as_longlong(v2.y));
-        __hip_atomic_store(slot + 2, ep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        p2p_stores_done();
+        st_sys(slot + 2, ep);
         const unsigned long long *in = reinterpret_cast<const unsigned long long *>(mailbox[rank] + kMbSlots) + ((long long)which * 64 + s) * 4;
         if (!spin_until(in + 2, ep)) st_sys(reinterpret_cast<unsigned long long *>(mailbox[rank] + kMbError), 2ULL);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         vx[s] = __longlong_as_double((long long)ld_sys(in));
         vy[s] = __longlong_as_double((long long)ld_sys(in + 1));
     }
@@ -970,6 +1195,8 @@ __global__ __launch_bounds__(kScalarBlock) void p2p_allreduce_kernel(const typen
         for (int k = 0; k < nranks; ++k) { tot2.x += vx[k]; tot2.y += vy[k]; }
         const A tot = from_acc2<A>(tot2);
         *epoch = ep;
+        if (bump0) *bump0 = *bump0 + 1;     // four-launch loop: the exchange epoch the SpMV launch just used ...
+        if (bump1) *bump1 = *bump1 + 1;     // ... and the epoch aypx_beta_p2p_kernel will read
         if (MODE == 1) {                       // cg_delta0 (clcg.c:274-292)
             delta[0] = from_acc<T>(tot);
             history[0] = from_acc<T>(tot);
@@ -1122,7 +1349,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + (size_t)g_tune.spmv_lds_pad;
         dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : rowblock_grid(plan.row_blocks, a.cycle));
         if (rb_list && rb_count <= 0) return CGAMD_OK;
-        const bool nt = g_tune.spmv_nt != 0;
+        const bool nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
 #define CG_RB(NT, UNR)                                                                                           \
     do {                                                                                                         \
         if (fuse) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, true, UNR>), g5, block, lds, st, a);   \
@@ -1155,6 +1382,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         // group (cgamd_tune "spmm_rb") re-reads the matrix per group and shrinks the x window per XCD; measured
         // slower at nRHS = 32 (253 vs 220 us) and at nRHS = 9 -- kept as an experiment knob only.
         const int chunk = (g_tune.spmm_rb > 0 && g_tune.spmm_rb < nrhs) ? g_tune.spmm_rb : nrhs;
+        const bool nt6 = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
         for (int g0 = 0; g0 < nrhs; g0 += chunk) {
             SpmvArgs<T> b = a;
             b.nrhs = (nrhs - g0 < chunk) ? nrhs - g0 : chunk;
@@ -1163,9 +1391,11 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
             if (fuse) {
                 b.dvec = a.dvec + (long long)g0 * ldx;
                 b.partials = a.partials + (long long)g0 * plan.row_blocks;
-                hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, true, true, RB>), g6, block, lds, st, b);
+                if (nt6) hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, true, true, RB>), g6, block, lds, st, b);
+                else hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, false, true, RB>), g6, block, lds, st, b);
             } else {
-                hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, true, false, RB>), g6, block, lds, st, b);
+                if (nt6) hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, true, false, RB>), g6, block, lds, st, b);
+                else hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, false, false, RB>), g6, block, lds, st, b);
             }
         }
         return check_launch("spmm_rowblock");
@@ -1195,7 +1425,15 @@ int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scrat
 }
 
 // decides once which SpMV kernel a solver uses (and therefore how many dot partials it produces)
-void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, const void *vals, const int *cols) {
+void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols) {
+    // Cache policy.  The 256 MB Infinity Cache keeps a matrix of up to ~384 MB mostly resident from one iteration to the
+    // next; streaming it non-temporally then only throws that away (N=1.25M rows, f64: SpMV 25.7 -> 21.4 us, iteration
+    // 49.3 -> 42.5 us; break-even between 313 and 418 MB, profiles/r1_experiments/ab_nt_sizes.log).  Larger matrices are
+    // streamed non-temporally so that the vectors, which ARE re-used within the iteration, keep the cache.
+    const size_t matrix_bytes = (size_t)nnz * (dtype_size(dtype) + 4) + ((size_t)n + 1) * 4;
+    const size_t vector_bytes = (size_t)n * dtype_size(dtype) * (size_t)nrhs;
+    plan->nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (matrix_bytes > ((size_t)384 << 20));
+    plan->vec_nt = g_tune.vec_nt >= 0 ? g_tune.vec_nt : ((matrix_bytes + 5 * vector_bytes <= ((size_t)200 << 20)) ? 0 : 3);
     int kind = g_tune.spmv_variant;
     const bool vec = aligned16(vals) && aligned16(cols);
     if (!vec || plan->max_span <= 0) kind = 0;
@@ -1283,20 +1521,21 @@ int launch_sub(int dtype, int n, const void *a, const void *b, void *res, long l
 
 template <typename T>
 static int axpy2_impl(int n, const void *d, void *x, const void *q, void *r, long long ld, const void *alpha, int nrhs,
-                      void *partials, int grid, bool vec, hipStream_t st) {
+                      void *partials, int grid, bool vec, int vnt, hipStream_t st) {
     dim3 g(grid, nrhs), blk(kBlock);
     auto *pp = static_cast<typename VT<T>::acc *>(partials);
-    if (vec && g_tune.vec_nt == 1) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true, 1>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
-    else if (vec && g_tune.vec_nt == 2) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true, 2>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
-    else if (vec && g_tune.vec_nt == 3) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true, 3>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    if (vec && vnt == 1) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true, 1>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    else if (vec && vnt == 2) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true, 2>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    else if (vec && vnt == 3) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true, 3>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
     else if (vec) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
     else hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
     return check_launch("axpy2_dot");
 }
 int launch_axpy2_dot(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *alpha,
-                     int nrhs, void *partials, int grid, hipStream_t st) {
+                     int nrhs, void *partials, int grid, hipStream_t st, int vec_nt) {
     const bool vec = vec_ok(dtype, ld, nrhs, {d, x, q, r});
-    CG_DISPATCH(dtype, axpy2_impl, n, d, x, q, r, ld, alpha, nrhs, partials, grid, vec, st);
+    const int vnt = g_tune.vec_nt >= 0 ? g_tune.vec_nt : vec_nt;
+    CG_DISPATCH(dtype, axpy2_impl, n, d, x, q, r, ld, alpha, nrhs, partials, grid, vec, vnt, st);
 }
 
 template <typename T> static int delta0_impl(const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
@@ -1411,13 +1650,74 @@ int launch_aypx_beta(int dtype, int n, const void *x, void *y, long long ld, con
 }
 
 // ---- peer-to-peer backend launchers ---------------------------------------------------------------
-template <typename T> static int p2p_exchange_impl(const P2pExchange &e, void *v_ext, hipStream_t st) {
+static P2pExchangeArgs p2p_args(const P2pExchange &e) {
     P2pExchangeArgs a;
     a.mailbox = e.mailbox; a.rank = e.rank; a.n_peers = e.n_peers; a.n_local = e.n_local;
     a.peer_rank = e.peer_rank; a.send_off = e.send_off; a.send_count = e.send_count; a.dst_off = e.dst_off;
     a.recv_off = e.recv_off; a.recv_count = e.recv_count; a.send_index = e.send_index; a.epoch = e.epoch;
-    hipLaunchKernelGGL((p2p_push_kernel<T>), dim3(e.n_peers), dim3(1024), 0, st, a, (const T *)v_ext);
-    hipLaunchKernelGGL((p2p_wait_unpack_kernel<T>), dim3(1), dim3(1024), 0, st, a, (T *)v_ext);
+    a.counters = e.counters; a.max_count = e.max_count;
+    return a;
+}
+int p2p_push_chunks(const P2pExchange &e) { return e.max_count > 0 ? (e.max_count + kP2pChunk - 1) / kP2pChunk : 1; }
+template <typename T>
+static int spmv_p2p_impl(const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
+                         const void *d_ext, void *q, void *partials, const int *halo_flag, int rotate, const P2pExchange &e,
+                         hipStream_t st) {
+    SpmvP2pArgs<T> g;
+    SpmvArgs<T> &a = g.s;
+    a.n = n; a.nrhs = 1; a.nnz = nnz;
+    a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
+    a.x = static_cast<const T *>(d_ext); a.ldx = 0;
+    a.y = static_cast<T *>(q); a.ldy = 0;
+    a.dvec = static_cast<const T *>(d_ext);
+    a.partials = static_cast<typename VT<T>::acc *>(partials);
+    a.row_blocks = plan.row_blocks; a.rb_list = halo_flag; a.rb_count = plan.row_blocks;
+    a.cap = (plan.max_span + 3) & ~3;
+    a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
+    g.x = p2p_args(e);
+    g.halo = static_cast<const T *>(e.my_halo);
+    g.n_local = e.n_local; g.rotate = rotate; g.push_chunks = p2p_push_chunks(e);
+    const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
+    const int grid = rowblock_grid(plan.row_blocks, a.cycle);
+    if (grid < e.n_peers * g.push_chunks) return fail(CGAMD_ERR_STATE, "spmv_p2p: fewer work-groups than push chunks");
+    const dim3 gd(grid), block(kBlock);
+    const bool nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
+    constexpr int U = sizeof(T) > 8 ? 4 : 8;
+    if (nt) hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, true, U>), gd, block, lds, st, g);
+    else hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, false, U>), gd, block, lds, st, g);
+    return check_launch("spmv_rowblock_p2p");
+}
+int launch_spmv_p2p(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
+                    const void *d_ext, void *q, void *partials, const int *halo_flag, int rotate, const P2pExchange &e,
+                    hipStream_t st) {
+    if (plan.kind != 5 || !aligned16(vals) || !aligned16(cols)) return fail(CGAMD_ERR_STATE, "spmv_p2p: needs the row-block kernel");
+    CG_DISPATCH(dtype, spmv_p2p_impl, plan, n, nnz, vals, ptr, cols, d_ext, q, partials, halo_flag, rotate, e, st);
+}
+// work-groups the four-launch SpMV runs (they carry the push chunks)
+int spmv_p2p_grid(const SpmvPlan &plan) { return rowblock_grid(plan.row_blocks, g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1); }
+
+template <typename T>
+static int aypx_beta_p2p_impl(int n, const void *x, void *y, const void *partials, int P, char *const *mailbox, int rank,
+                              int nranks, int which, const unsigned long long *epoch, const CgScalars &sc, bool vec, hipStream_t st) {
+    dim3 g(vec_grid(n, VT<T>::dtype)), blk(kBlock);
+    auto *pp = static_cast<const typename VT<T>::acc *>(partials);
+    if (vec) hipLaunchKernelGGL((aypx_beta_p2p_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)x, (T *)y, pp, P, mailbox, rank, nranks, which, epoch, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (const int *)sc.iter);
+    else hipLaunchKernelGGL((aypx_beta_p2p_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)x, (T *)y, pp, P, mailbox, rank, nranks, which, epoch, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (const int *)sc.iter);
+    return check_launch("aypx_beta_p2p");
+}
+int launch_aypx_beta_p2p(int dtype, int n, const void *x, void *y, const void *partials, int P, char *const *mailbox, int rank,
+                         int nranks, int which, const unsigned long long *epoch, const CgScalars &sc, hipStream_t st) {
+    if (n <= 0) return CGAMD_OK;
+    if (nranks > 64) return fail(CGAMD_ERR_INVALID, "p2p all-reduce: at most 64 ranks");
+    const bool v = vec_ok(dtype, n, 1, {x, y});
+    CG_DISPATCH(dtype, aypx_beta_p2p_impl, n, x, y, partials, P, mailbox, rank, nranks, which, epoch, sc, v, st);
+}
+
+template <typename T> static int p2p_exchange_impl(const P2pExchange &e, void *v_ext, hipStream_t st) {
+    P2pExchangeArgs a = p2p_args(e);
+    const dim3 g(p2p_push_chunks(e), e.n_peers);
+    hipLaunchKernelGGL((p2p_push_kernel<T>), g, dim3(kP2pBlock), 0, st, a, (const T *)v_ext);
+    hipLaunchKernelGGL((p2p_wait_unpack_kernel<T>), g, dim3(kP2pBlock), 0, st, a, (T *)v_ext);
     return check_launch("p2p_exchange");
 }
 int launch_p2p_exchange(int dtype, const P2pExchange &e, void *v_ext, hipStream_t st) {
@@ -1426,19 +1726,21 @@ int launch_p2p_exchange(int dtype, const P2pExchange &e, void *v_ext, hipStream_
 }
 template <typename T>
 static int p2p_ar_impl(int mode, const void *partials, int grid, char *const *mailbox, int rank, int nranks, int which,
-                       unsigned long long *epoch, const CgScalars &sc, hipStream_t st) {
+                       unsigned long long *epoch, const CgScalars &sc, unsigned long long *bump0, unsigned long long *bump1,
+                       hipStream_t st) {
     auto *pp = static_cast<const typename VT<T>::acc *>(partials);
 #define CG_AR(M)                                                                                                            \
     hipLaunchKernelGGL((p2p_allreduce_kernel<T, M>), dim3(1), dim3(kScalarBlock), 0, st, pp, grid, mailbox, rank, nranks, which, \
-                       epoch, (T *)sc.delta, (T *)sc.alpha, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter)
+                       epoch, (T *)sc.delta, (T *)sc.alpha, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter, bump0, bump1)
     if (mode == 1) CG_AR(1); else if (mode == 2) CG_AR(2); else CG_AR(3);
 #undef CG_AR
     return check_launch("p2p_allreduce");
 }
 int launch_p2p_allreduce(int dtype, int mode, const void *partials, int grid, char *const *mailbox, int rank, int nranks,
-                         int which, unsigned long long *epoch, const CgScalars &sc, hipStream_t st) {
+                         int which, unsigned long long *epoch, const CgScalars &sc, hipStream_t st, unsigned long long *bump0,
+                         unsigned long long *bump1) {
     if (nranks > 64) return fail(CGAMD_ERR_INVALID, "p2p all-reduce: at most 64 ranks");
-    CG_DISPATCH(dtype, p2p_ar_impl, mode, partials, grid, mailbox, rank, nranks, which, epoch, sc, st);
+    CG_DISPATCH(dtype, p2p_ar_impl, mode, partials, grid, mailbox, rank, nranks, which, epoch, sc, bump0, bump1, st);
 }
 
 }  // namespace cgamd

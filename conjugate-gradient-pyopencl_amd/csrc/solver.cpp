@@ -69,7 +69,7 @@ static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
     if (!(s->flags & CGAMD_UNFUSED)) {
         if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
         if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
-        if ((rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st))) return rc;
+        if ((rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt))) return rc;
         return launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
     }
     if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, nullptr, nullptr, st))) return rc;
@@ -171,7 +171,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) rc = dmalloc((void **)&s->sc.iter, 16, "iter");
     if (!rc) rc = ensure_history(s, 1024);
     if (!rc) rc = compute_spmv_plan(s->ptr, s->cols, size, s->sc.iter, ctx->stream, &s->plan);
-    if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, s->vals, s->cols);
+    if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, size, nnz, s->vals, s->cols);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(ctx->stream);  // host matrix arrays may go away after return
         if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("solver_create sync: ") + hipGetErrorString(e));
@@ -273,7 +273,7 @@ int cgamd_solver_iterate_timed(cgamd_solver *s, int nIterations, float *spmv_ms_
         rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st);
         CG_HIP(hipEventRecord(ev[(size_t)2 * i + 1], st));
         if (!rc) rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st);
-        if (!rc) rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st);
+        if (!rc) rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
         if (!rc) rc = launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
     }
     CG_HIP(hipEventRecord(ev[(size_t)2 * nIterations + 1], st));

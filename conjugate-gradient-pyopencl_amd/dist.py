@@ -340,10 +340,13 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
     """bench.py --gpus N (N > 1): the SAME N=10M system, rows partitioned into N contiguous z-slabs.
 
     Candidate loops, each validated on a short run against the plain RCCL loop before it may be timed:
-      p2p+graph   peer-to-peer mailboxes over xGMI, whole iteration replayed from a hipGraph
-      p2p         peer-to-peer, plain launches, halo exchange overlapped with the interior SpMV
+      p2p4        peer-to-peer mailboxes over xGMI, FOUR launches per iteration: the halo push and the wait ride inside
+                  the SpMV launch (halo read in place), the r.r all-reduce inside the aypx launch; plain launches
+      p2p4+graph  the same, replayed from a hipGraph
+      p2p         peer-to-peer with separate push / unpack / all-reduce launches (seven per iteration)
+      p2p+graph   the same from a hipGraph
       rccl+graph  RCCL send/recv + all-reduce captured in a hipGraph
-      rccl        RCCL, plain launches, exchange overlapped
+      rccl        RCCL, plain launches, exchange overlapped with the interior SpMV
     The fastest valid candidate (short trial, max over ranks) runs the timed region.  If the C loop is
     unavailable altogether the Python loop over torch.distributed drives the same HIP kernels."""
     import time
@@ -357,12 +360,14 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
     b = torch.full((plan.n_local,), 5.0, dtype=tdt, device=dev)          # main.c:44: b = (r+1)*5, x0 = 0
     torch.cuda.synchronize()
     notes, trials = [], {}
-    want = [m for m in ("p2p+graph", "p2p", "rccl+graph", "rccl") if m not in getattr(args, "dist_skip", "").split(",")
+    want = [m for m in ("p2p4", "p2p4+graph", "p2p", "p2p+graph", "rccl+graph", "rccl") if m not in getattr(args, "dist_skip", "").split(",")
             and (dist.get_backend() == "nccl" or m.startswith("p2p"))]
 
     def make(mode):
         flags = _lib.DIST_GRAPH if mode.endswith("+graph") else 0
         if mode.startswith("p2p"):
+            if not mode.startswith("p2p4"):
+                flags |= _lib.DIST_P2P_STAGED | _lib.DIST_NO_OVERLAP
             return DistSolver(ctx, plan, indptr, data, dtype, flags=flags, comm="p2p")
         return DistSolver(ctx, plan, indptr, data, dtype, unique_id=broadcast_unique_id(rank, device=dev), flags=flags)
 
@@ -440,7 +445,8 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
     V = np.dtype(dtype).itemsize
     iter_bytes = nnz_total * (V + 4) + (n + 1) * 4 + 14 * n * V
     it_s = args.steps / dt
-    comm_desc = ("peer-to-peer mailboxes over xGMI (direct halo writes + rank-ordered scalar sums)" if mode.startswith("p2p")
+    comm_desc = ("peer-to-peer mailboxes over xGMI (direct halo writes + rank-ordered scalar sums)"
+                 + (", 4 launches/iteration" if mode.startswith("p2p4") else "") if mode.startswith("p2p")
                  else "RCCL send/recv + 2 scalar all-reduces per iteration")
     return {
         "metric": "CG iterations/sec + SpMV effective HBM GB/s (% of 8 TB/s peak), N=10M CSR",

@@ -100,6 +100,9 @@ int cgamd_sub(cgamd_ctx *ctx, int dtype, int size, const void *a, const void *b,
 #define CGAMD_DIST_NO_OVERLAP 32    /* cgamd_dist_create: exchange first, then one SpMV (no interior/boundary overlap) */
 #define CGAMD_DIST_P2P 64            /* cgamd_dist_create: no RCCL; peers write each other's IPC mailboxes (attach_p2p) */
 #define CGAMD_DIST_GRAPH 8         /* cgamd_dist_create: replay each iteration (incl. RCCL ops) from a hipGraph */
+#define CGAMD_DIST_P2P_STAGED 128   /* with CGAMD_DIST_P2P: separate push / wait+unpack launches and all-reduce launches (7 per
+                                     * iteration) instead of the default four-launch iteration (push and wait inside the SpMV
+                                     * launch, halo read in place from the mailbox, beta all-reduce inside the aypx launch) */
 
 int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, const void *aValues,
                         const int *aPointers, const int *aCols, int nRHS, int flags, cgamd_solver **out);

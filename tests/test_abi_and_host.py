@@ -107,7 +107,7 @@ def test_argument_validation_without_gpu(pkg):
     assert lib.cgamd_cg(1, -1, 0, None, None, None, None, None, 1, 1, None, 0) == 1     # CGAMD_ERR_INVALID
     assert lib.cgamd_cg(1, 4, 4, None, None, None, None, None, 1, 1, None, 0) == 1
     assert lib.cgamd_tune(b"no_such_key", 1) == 1
-    assert lib.cgamd_tune(b"spmv_nt", 1) == 0
+    assert lib.cgamd_tune(b"spmv_nt", -1) == 0
     out = ctypes.c_longlong()
     assert lib.cgamd_gen_laplace3d(None, 1, 250, 200, 200, 0, 10_000_000, None, None, None, ctypes.byref(out)) == 0
     assert out.value == 69_720_000

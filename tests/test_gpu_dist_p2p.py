@@ -75,7 +75,10 @@ def _worker(rank, world, port, kind, iters, flags, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind,flags", [(2, "lap3d", 0), (3, "lap3d", 8), (2, "helm", 8), (3, "helm", 32)])
+# flags: 0 = four-launch iteration (push + wait inside the SpMV launch, halo read in place, beta all-reduce inside aypx),
+# 8 = the same from a hipGraph, 128 = staged push / unpack / all-reduce launches (+8 graph, +32 no interior/boundary overlap)
+@pytest.mark.parametrize("world,kind,flags", [(2, "lap3d", 0), (3, "lap3d", 8), (2, "helm", 8), (3, "helm", 0), (4, "lap3d", 0),
+                                              (2, "lap3d", 128), (3, "lap3d", 128 | 8), (3, "helm", 128 | 32)])
 def test_p2p_multirank_on_one_gpu(tmp_path, world, kind, flags):
     import torch.multiprocessing as mp
     import cg_oracle
