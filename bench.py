@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--dtype", type=str, default="f64", choices=["f32", "f64", "c64", "c128"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="reference op structure (6 kernels/iteration)")
+    ap.add_argument("--no-graph", action="store_true", help="plain stream launches instead of hipGraph replay (A/B)")
     ap.add_argument("--spmv-reps", type=int, default=20)
     return ap.parse_args()
 
@@ -143,7 +144,7 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
     n = nx * ny * nz
     indptr, indices, data = pkg.generators.laplace3d(ctx, nx, ny, nz, dtype=dtype)
     nnz = int(indices.numel())
-    flags = lib.MATRIX_ON_DEVICE | (lib.UNFUSED if args.unfused else 0)
+    flags = lib.MATRIX_ON_DEVICE | (lib.UNFUSED if args.unfused else 0) | (lib.NO_GRAPH if args.no_graph else 0)
     solver = pkg.Solver(ctx, n, nnz, data, indptr, indices, 1, flags=flags, dtype=dtype)
     tdt = pkg.generators.torch_dtype(dtype)
     b = torch.full((n,), 5.0, dtype=tdt, device=dev)       # main.c:44: b = (r+1)*5, x0 = 0

@@ -77,6 +77,7 @@ def load():
         "cgamd_solver_create": (ci, [vp, ci, ci, ll, vp, vp, vp, ci, ci, pvp]),
         "cgamd_solver_destroy": (ci, [vp]),
         "cgamd_solver_set_rhs": (ci, [vp, vp, vp, ci]),
+        "cgamd_solver_set_preconditioner": (ci, [vp, vp, ci]),
         "cgamd_solver_iterate": (ci, [vp, ci]),
         "cgamd_solver_iterate_timed": (ci, [vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
         "cgamd_solver_get_x": (ci, [vp, vp, ci]),

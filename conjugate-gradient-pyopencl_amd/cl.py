@@ -238,6 +238,25 @@ class Solver:
                 x0 = np.ascontiguousarray(np.asarray(x0).reshape(-1), dtype=self.dtype)
         check(self._lib.cgamd_solver_set_rhs(self.handle, ptr(b), ptr(x0), int(on_device)))
 
+    def set_preconditioner(self, m):
+        """z = m * r between residual and search direction: the reference's PCG with a diagonal `M`
+        (helmFE_var.py:546-586, `z = M.dot(r)` branch).  m: the diagonal as a 1-D array (1/diag(A) for Jacobi), a scipy
+        sparse diagonal matrix as the reference passes it, a device buffer, or None to go back to plain CG.  Takes effect at
+        the next set_rhs; history() keeps returning r.r."""
+        if m is None:
+            check(self._lib.cgamd_solver_set_preconditioner(self.handle, None, 0))
+            return
+        if hasattr(m, "diagonal") and hasattr(m, "nnz"):          # scipy sparse: must be diagonal, as in the reference
+            if m.nnz > m.shape[0]:
+                raise ValueError("only a diagonal M is supported (the reference's spsolve branch is out of scope)")
+            m = m.diagonal()
+        on_device = not isinstance(m, np.ndarray) and not isinstance(m, (list, tuple))
+        if not on_device:
+            m = np.ascontiguousarray(np.asarray(m).reshape(-1), dtype=self.dtype)
+            if m.size != self.size:
+                raise ValueError("preconditioner diagonal must have `size` entries")
+        check(self._lib.cgamd_solver_set_preconditioner(self.handle, ptr(m), int(on_device)))
+
     def iterate(self, n_iterations):
         check(self._lib.cgamd_solver_iterate(self.handle, int(n_iterations)))
 
@@ -255,6 +274,9 @@ class Solver:
         if on_device:
             self.ctx.synchronize()      # the copy ran on the solver's stream; make it visible to the caller's
         return out
+
+    def iterations_done(self):
+        return int(self._lib.cgamd_solver_iterations_done(self.handle))
 
     def history(self):
         """delta_k = r_k . r_k (unconjugated) for k = 0..iterations; shape (iterations+1, n_rhs)."""
@@ -317,6 +339,35 @@ class Solver:
             if below.size or not np.all(np.isfinite(h[-1])):
                 break
         return self.x(), done, self.history()
+
+    def pcg(self, b, M=None, x0=None, tol=1e-6, maxit=1000, check_every=8):
+        """`PCG(A, b, M, x, tol, maxit)` of the reference (helmFE_var.py:546-586) for M = None or a diagonal M: stops when
+        sqrt(|r.r|) < tol, returns (x, i) with i the 0-based index of the last iteration run, like the reference.  The
+        residual history stays on the device and is read back every `check_every` iterations; x is taken at the first
+        iteration that met the tolerance by re-running exactly that many iterations when the check overshot it."""
+        if self.n_rhs != 1:
+            raise ValueError("pcg handles one right-hand side")
+        self.set_preconditioner(M)
+        try:
+            def run(limit, stop_early):
+                self.set_rhs(b, x0)
+                done = 0
+                while done < limit:
+                    step = min(check_every, limit - done)
+                    self.iterate(step)
+                    done += step
+                    if stop_early:
+                        h = self.history()
+                        hit = np.nonzero(~(np.sqrt(np.abs(h[1:, 0])) >= tol))[0]        # below tol, or NaN
+                        if hit.size:
+                            return int(hit[0]) + 1
+                return limit
+            its = run(int(maxit), True)
+            if self.iterations_done() != its:
+                run(its, False)
+            return self.x(), its - 1
+        finally:
+            self.set_preconditioner(None)
 
 
 def solve_subdomains(ctx, P0, residuals, n_iterations, dtype=np.csingle, solver=None):

@@ -131,6 +131,12 @@ struct P2pExchange {
     const void *my_halo = nullptr;    // halo area of MY mailbox (entry h = column n_local + h)
 };
 int p2p_push_chunks(const P2pExchange &e);
+// diagonally preconditioned CG (helmFE_var.py:546-586 with a diagonal M): see kernels.hip
+int launch_pcg_axpy2_dot2(int dtype, bool init, int n, const void *d, void *x, const void *q, void *r, const void *m,
+                          long long ld, const void *alpha, int nrhs, void *part_rz, void *part_rr, int grid, hipStream_t st);
+int launch_pcg_aypx_beta(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *part_rz,
+                         const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st);
+int launch_pcg_delta0(int dtype, const void *part_rz, const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st);
 // four-launch peer-to-peer iteration (see kernels.hip): SpMV with the push and the wait inside, aypx with the beta all-reduce.
 // halo_flag: device int per row block (1 = references a halo column); rotate: first row block of the visiting order
 int launch_spmv_p2p(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,

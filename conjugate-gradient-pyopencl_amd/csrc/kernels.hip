@@ -760,6 +760,138 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_kernel(int n, const T *__rest
 }
 
 // =================================================================================================
+// Diagonally (Jacobi) preconditioned CG -- the reference's PCG with a diagonal CSR `M`, z = M.dot(r)
+// (helmFE_var.py:546-586): rho = r.z, p = z + (rho/rho_old) p, q = A p, alpha = rho / p.q, x += alpha p, r -= alpha q,
+// stop on sqrt|r.r|.  Same four launches as the plain loop: the SpMV (+p.q) and cg_alpha are shared (delta holds rho);
+//   pcg_axpy2_dot2_kernel : x += alpha p, r -= alpha q, partials of r.(m r) and of r.r      (7NV bytes)
+//   pcg_aypx_beta_kernel  : beta in the prologue, p = m r + beta p                           (4NV bytes)
+// m[i] is what multiplies r[i] (the inverse diagonal for Jacobi), shared by all right-hand sides.  rho of the previous
+// iteration is read from a two-entry parity buffer so that work-group 0 may publish the new one in the same launch.
+// =================================================================================================
+template <typename T, int BLOCK, bool VEC, bool INIT>
+__global__ __launch_bounds__(BLOCK) void pcg_axpy2_dot2_kernel(int n, const T *__restrict__ d, T *__restrict__ x,
+                                                               const T *__restrict__ q, T *__restrict__ rv,
+                                                               const T *__restrict__ m, long long ld,
+                                                               const T *__restrict__ alpha,
+                                                               typename VT<T>::acc *__restrict__ part_rz,
+                                                               typename VT<T>::acc *__restrict__ part_rr) {
+    // INIT: no update, d = m r instead (set_rhs: p0 = z0), same two dot products
+    using A = typename VT<T>::acc;
+    __shared__ A red[BLOCK / kWave];
+    const int r = blockIdx.y;
+    T *dw = const_cast<T *>(d) + (long long)r * ld;
+    d += (long long)r * ld; x += (long long)r * ld; q += (long long)r * ld; rv += (long long)r * ld;
+    const T al = INIT ? vzero<T>() : alpha[r];
+    A arz = vzero<A>(), arr = vzero<A>();
+    constexpr int E = Pack<T>::N;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (VEC) {
+        const long long npack = n / E;
+        for (long long i = i0; i < npack; i += stride) {
+            Pack<T> pr = ld_pack(rv + i * E);
+            const Pack<T> pm = ld_pack(m + i * E);
+            if (!INIT) {
+                const Pack<T> pd = ld_pack(d + i * E), pq = ld_pack(q + i * E);
+                Pack<T> px = ld_pack(x + i * E);
+#pragma unroll
+                for (int k = 0; k < E; ++k) {
+                    px.v[k] = vadd(px.v[k], vmul(al, pd.v[k]));
+                    pr.v[k] = vsub(pr.v[k], vmul(al, pq.v[k]));
+                }
+                st_pack(x + i * E, px);
+                st_pack(rv + i * E, pr);
+            }
+            Pack<T> pz;
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                pz.v[k] = vmul(pm.v[k], pr.v[k]);
+                arz = vadd(arz, to_acc(vmul(pr.v[k], pz.v[k])));
+                arr = vadd(arr, to_acc(vmul(pr.v[k], pr.v[k])));
+            }
+            if (INIT) st_pack(dw + i * E, pz);
+        }
+        i0 += npack * E;
+    }
+    for (long long i = i0; i < n; i += stride) {
+        T rn = rv[i];
+        if (!INIT) {
+            x[i] = vadd(x[i], vmul(al, d[i]));
+            rn = vsub(rn, vmul(al, q[i]));
+            rv[i] = rn;
+        }
+        const T z = vmul(m[i], rn);
+        if (INIT) dw[i] = z;
+        arz = vadd(arz, to_acc(vmul(rn, z)));
+        arr = vadd(arr, to_acc(vmul(rn, rn)));
+    }
+    const A trz = block_sum<BLOCK>(arz, red);
+    if (threadIdx.x == 0) part_rz[(long long)r * gridDim.x + blockIdx.x] = trz;
+    const A trr = block_sum<BLOCK>(arr, red);
+    if (threadIdx.x == 0) part_rr[(long long)r * gridDim.x + blockIdx.x] = trr;
+}
+
+template <typename T, int BLOCK, bool VEC>
+__global__ __launch_bounds__(BLOCK) void pcg_aypx_beta_kernel(int n, const T *__restrict__ rv, T *__restrict__ pv,
+                                                              const T *__restrict__ m, long long ld,
+                                                              const typename VT<T>::acc *__restrict__ part_rz,
+                                                              const typename VT<T>::acc *__restrict__ part_rr, int P, int nrhs,
+                                                              T *delta, T *beta, T *history, T *rho2, const int *iter) {
+    using A = typename VT<T>::acc;
+    __shared__ A red[BLOCK / kWave];
+    __shared__ T beta_s;
+    const int r = blockIdx.y;
+    {
+        A acc = vzero<A>();
+        const A *pz = part_rz + (long long)r * P;
+        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, pz[i]);
+        const A rho = block_sum<BLOCK>(acc, red);
+        A acc2 = vzero<A>();
+        if (blockIdx.x == 0) {
+            const A *pr = part_rr + (long long)r * P;
+            for (int i = threadIdx.x; i < P; i += BLOCK) acc2 = vadd(acc2, pr[i]);
+            acc2 = block_sum<BLOCK>(acc2, red);
+        }
+        if (threadIdx.x == 0) {
+            const int it = *iter;
+            const T rhoT = from_acc<T>(rho);
+            const T rold = rho2[(long long)((it - 1) & 1) * nrhs + r];
+            const T b = from_acc<T>(acc_div(to_acc(rhoT), to_acc(rold)));
+            beta_s = b;
+            if (blockIdx.x == 0) {
+                beta[r] = b;
+                delta[r] = rhoT;                                   // cg_alpha divides this by p.q
+                rho2[(long long)(it & 1) * nrhs + r] = rhoT;
+                history[(long long)it * nrhs + r] = from_acc<T>(acc2);   // r.r: what the stopping test looks at
+            }
+        }
+        __syncthreads();
+    }
+    const T bt = beta_s;
+    rv += (long long)r * ld; pv += (long long)r * ld;
+    constexpr int E = Pack<T>::N;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (VEC) {
+        const long long npack = n / E;
+        for (long long i = i0; i < npack; i += stride) {
+            const Pack<T> pr = ld_pack(rv + i * E), pm = ld_pack(m + i * E);
+            Pack<T> pp = ld_pack(pv + i * E);
+#pragma unroll
+            for (int k = 0; k < E; ++k) pp.v[k] = vadd(vmul(bt, pp.v[k]), vmul(pm.v[k], pr.v[k]));
+            st_pack(pv + i * E, pp);
+        }
+        i0 += npack * E;
+    }
+    for (long long i = i0; i < n; i += stride) pv[i] = vadd(vmul(bt, pv[i]), vmul(m[i], rv[i]));
+}
+
+// set_rhs: delta = rho0 = sum r.z partials, rho2[0] = rho0, history[0] = r.r, iter = 0
+template <typename T>
+__global__ __launch_bounds__(1024) void pcg_delta0_kernel(const typename VT<T>::acc *part_rz, const typename VT<T>::acc *part_rr, int P,
+                                                          int nrhs, T *delta, T *history, T *rho2, int *iter);
+
+// =================================================================================================
 // Scalar kernels: one 256-thread work-group per RHS; fixed summation order (thread-strided, wave
 // shuffle, then the 4 wave sums in order) => bitwise reproducible.
 // =================================================================================================
@@ -789,6 +921,22 @@ __global__ __launch_bounds__(kScalarBlock) void reduce_to_value_kernel(const typ
     const int r = blockIdx.x;
     const auto s = sum_partials_block(partials + (long long)r * grid, grid, smem);
     if (threadIdx.x == 0) result[r] = from_acc<T>(s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void pcg_delta0_kernel(const typename VT<T>::acc *part_rz, const typename VT<T>::acc *part_rr, int P,
+                                                          int nrhs, T *delta, T *history, T *rho2, int *iter) {
+    __shared__ typename VT<T>::acc smem[kScalarBlock / kWave];
+    const int r = blockIdx.x;
+    const auto rho = sum_partials_block(part_rz + (long long)r * P, P, smem);
+    __syncthreads();
+    const auto rr = sum_partials_block(part_rr + (long long)r * P, P, smem);
+    if (threadIdx.x == 0) {
+        delta[r] = from_acc<T>(rho);
+        rho2[r] = from_acc<T>(rho);
+        history[r] = from_acc<T>(rr);
+        if (r == 0) *iter = 0;
+    }
 }
 
 template <typename T>
@@ -1647,6 +1795,49 @@ int launch_aypx_beta(int dtype, int n, const void *x, void *y, long long ld, con
     if (n <= 0) return CGAMD_OK;
     const bool v = vec_ok(dtype, ld, nrhs, {x, y});
     CG_DISPATCH(dtype, aypx_beta_impl, n, x, y, ld, partials, P, nrhs, sc, v, st);
+}
+
+// ---- diagonally preconditioned CG -----------------------------------------------------------------
+template <typename T>
+static int pcg_axpy2_impl(bool init, int n, const void *d, void *x, const void *q, void *r, const void *m, long long ld,
+                          const void *alpha, int nrhs, void *part_rz, void *part_rr, int grid, bool vec, hipStream_t st) {
+    dim3 g(grid, nrhs), blk(kBlock);
+    using A = typename VT<T>::acc;
+#define CG_PCG(V, I) hipLaunchKernelGGL((pcg_axpy2_dot2_kernel<T, kBlock, V, I>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, \
+                                        (T *)r, (const T *)m, ld, (const T *)alpha, (A *)part_rz, (A *)part_rr)
+    if (init) { if (vec) CG_PCG(true, true); else CG_PCG(false, true); }
+    else { if (vec) CG_PCG(true, false); else CG_PCG(false, false); }
+#undef CG_PCG
+    return check_launch("pcg_axpy2_dot2");
+}
+int launch_pcg_axpy2_dot2(int dtype, bool init, int n, const void *d, void *x, const void *q, void *r, const void *m,
+                          long long ld, const void *alpha, int nrhs, void *part_rz, void *part_rr, int grid, hipStream_t st) {
+    const bool vec = vec_ok(dtype, ld, nrhs, {d, x, q, r, m});
+    CG_DISPATCH(dtype, pcg_axpy2_impl, init, n, d, x, q, r, m, ld, alpha, nrhs, part_rz, part_rr, grid, vec, st);
+}
+template <typename T>
+static int pcg_aypx_impl(int n, const void *r, void *p, const void *m, long long ld, const void *part_rz, const void *part_rr,
+                         int P, int nrhs, const CgScalars &sc, void *rho2, bool vec, hipStream_t st) {
+    dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
+    using A = typename VT<T>::acc;
+    if (vec) hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, (T *)rho2, (const int *)sc.iter);
+    else hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, (T *)rho2, (const int *)sc.iter);
+    return check_launch("pcg_aypx_beta");
+}
+int launch_pcg_aypx_beta(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *part_rz,
+                         const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st) {
+    const bool vec = vec_ok(dtype, ld, nrhs, {r, p, m});
+    CG_DISPATCH(dtype, pcg_aypx_impl, n, r, p, m, ld, part_rz, part_rr, P, nrhs, sc, rho2, vec, st);
+}
+template <typename T>
+static int pcg_delta0_impl(const void *part_rz, const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st) {
+    using A = typename VT<T>::acc;
+    hipLaunchKernelGGL((pcg_delta0_kernel<T>), dim3(nrhs), dim3(kScalarBlock), 0, st, (const A *)part_rz, (const A *)part_rr, P, nrhs,
+                       (T *)sc.delta, (T *)sc.history, (T *)rho2, sc.iter);
+    return check_launch("pcg_delta0");
+}
+int launch_pcg_delta0(int dtype, const void *part_rz, const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st) {
+    CG_DISPATCH(dtype, pcg_delta0_impl, part_rz, part_rr, P, nrhs, sc, rho2, st);
 }
 
 // ---- peer-to-peer backend launchers ---------------------------------------------------------------

@@ -28,6 +28,8 @@ struct cgamd_solver {
     void *x = nullptr, *r = nullptr, *d = nullptr, *q = nullptr, *b = nullptr;
     void *slab = nullptr;   // backing store of x, r, d, q, b
     void *part_dq = nullptr, *part_rr = nullptr;
+    // diagonal preconditioner (cgamd_solver_set_preconditioner): z = mdiag .* r; r.z partials; rho parity buffer
+    void *mdiag = nullptr, *part_rz = nullptr, *rho2 = nullptr;
     CgScalars sc;
     bool rhs_set = false;
     int iters = 0;  // iterations enqueued since set_rhs
@@ -66,6 +68,13 @@ static int validate_csr_host(int n, long long nnz, const int *ptr, const int *co
 static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
     const int dt = s->dtype, n = s->n, nr = s->nrhs;
     int rc;
+    if (s->mdiag) {   // preconditioned recurrence (helmFE_var.py:560-585); delta holds rho = r.z
+        if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
+        if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
+        if ((rc = launch_pcg_axpy2_dot2(dt, false, n, s->d, s->x, s->q, s->r, s->mdiag, n, s->sc.alpha, nr, s->part_rz, s->part_rr,
+                                        s->vgrid, st))) return rc;
+        return launch_pcg_aypx_beta(dt, n, s->r, s->d, s->mdiag, n, s->part_rz, s->part_rr, s->vgrid, nr, s->sc, s->rho2, st);
+    }
     if (!(s->flags & CGAMD_UNFUSED)) {
         if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
         if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
@@ -197,7 +206,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
         if (s->cols) (void)hipFree(s->cols);
     }
     void *bufs[] = {s->slab, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
-                    s->sc.history, s->sc.iter};
+                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;
@@ -218,12 +227,41 @@ int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_
     if ((rc = launch_spmv(s->dtype, s->plan, s->n, s->nnz, s->vals, s->ptr, s->cols, s->x, s->n, s->q, s->n, s->nrhs,
                           nullptr, nullptr, st))) return rc;
     if ((rc = launch_sub(s->dtype, s->n, s->b, s->q, s->r, s->n, s->nrhs, st))) return rc;
-    CG_HIP(hipMemcpyAsync(s->d, s->r, vbytes, hipMemcpyDeviceToDevice, st));
-    if ((rc = launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, s->nrhs, s->part_rr, s->vgrid, st))) return rc;
-    if ((rc = launch_cg_delta0(s->dtype, s->part_rr, s->vgrid, s->nrhs, s->sc, st))) return rc;
+    if (s->mdiag) {   // z0 = M r0, p0 = z0, rho0 = r0.z0 (helmFE_var.py:562-573)
+        if ((rc = launch_pcg_axpy2_dot2(s->dtype, true, s->n, s->d, s->x, s->q, s->r, s->mdiag, s->n, nullptr, s->nrhs, s->part_rz,
+                                        s->part_rr, s->vgrid, st))) return rc;
+        if ((rc = launch_pcg_delta0(s->dtype, s->part_rz, s->part_rr, s->vgrid, s->nrhs, s->sc, s->rho2, st))) return rc;
+    } else {
+        CG_HIP(hipMemcpyAsync(s->d, s->r, vbytes, hipMemcpyDeviceToDevice, st));
+        if ((rc = launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, s->nrhs, s->part_rr, s->vgrid, st))) return rc;
+        if ((rc = launch_cg_delta0(s->dtype, s->part_rr, s->vgrid, s->nrhs, s->sc, st))) return rc;
+    }
     if (!on_device) CG_HIP(hipStreamSynchronize(st));  // host buffers may be released by the caller
     s->rhs_set = true;
     s->iters = 0;
+    return CGAMD_OK;
+}
+
+// z = m .* r between residual and search direction: the reference's PCG with a diagonal CSR M (helmFE_var.py:546-586;
+// pass 1/diag(A) for Jacobi).  m: `size` values of the solver's type, shared by all right-hand sides; NULL removes the
+// preconditioner.  The next cgamd_solver_set_rhs starts the preconditioned recurrence; history then holds r.r as before.
+int cgamd_solver_set_preconditioner(cgamd_solver *s, const void *m, int on_device) {
+    if (!s) return fail(CGAMD_ERR_INVALID, "set_preconditioner: solver is NULL");
+    CG_HIP(hipSetDevice(s->ctx->device));
+    CG_HIP(hipStreamSynchronize(s->ctx->stream));
+    destroy_graphs(s);
+    s->rhs_set = false;
+    if (!m) {
+        if (s->mdiag) { (void)hipFree(s->mdiag); s->mdiag = nullptr; }
+        return CGAMD_OK;
+    }
+    const size_t vs = dtype_size(s->dtype);
+    int rc = CGAMD_OK;
+    if (!s->mdiag) rc = dmalloc(&s->mdiag, (size_t)s->n * vs, "preconditioner");
+    if (!rc && !s->part_rz) rc = dmalloc(&s->part_rz, acc_size(s->dtype) * (size_t)s->vgrid * s->nrhs, "partials_rz");
+    if (!rc && !s->rho2) rc = dmalloc(&s->rho2, 2 * vs * (size_t)s->nrhs, "rho");
+    if (rc) return rc;
+    CG_HIP(hipMemcpy(s->mdiag, m, (size_t)s->n * vs, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     return CGAMD_OK;
 }
 
@@ -259,7 +297,8 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
 int cgamd_solver_iterate_timed(cgamd_solver *s, int nIterations, float *spmv_ms_avg, float *iter_ms_avg) {
     if (!s || !spmv_ms_avg) return fail(CGAMD_ERR_INVALID, "iterate_timed: null argument");
     if (!s->rhs_set) return fail(CGAMD_ERR_STATE, "iterate_timed: call set_rhs first");
-    if (nIterations < 1 || (s->flags & CGAMD_UNFUSED)) return fail(CGAMD_ERR_INVALID, "iterate_timed: needs >= 1 iteration of the fused loop");
+    if (nIterations < 1 || (s->flags & CGAMD_UNFUSED) || s->mdiag)
+        return fail(CGAMD_ERR_INVALID, "iterate_timed: needs >= 1 iteration of the fused, unpreconditioned loop");
     CG_HIP(hipSetDevice(s->ctx->device));
     if (int rc = ensure_history(s, s->iters + nIterations + 1)) return rc;
     hipStream_t st = s->ctx->stream;

@@ -123,6 +123,11 @@ int cgamd_solver_history(cgamd_solver *s, void *history, int max_entries);
 int cgamd_solver_iterations_done(cgamd_solver *s);
 /* device pointers of the solver's resident state (for zero-copy inspection): which = 0:x 1:r 2:d 3:q */
 void *cgamd_solver_vector(cgamd_solver *s, int which);
+/* Diagonal (Jacobi) preconditioning -- the reference's PCG(A, b, M) with a diagonal CSR M, z = M.dot(r)
+ * (helmFE_var.py:546-586).  m: `size` values of the solver's type (1/diag(A) for Jacobi), host or
+ * device; NULL removes it.  Takes effect at the next cgamd_solver_set_rhs; history keeps holding r.r (the stopping
+ * test of the reference, helmFE_var.py:580-584), the recurrence uses rho = r.z. */
+int cgamd_solver_set_preconditioner(cgamd_solver *s, const void *m, int on_device);
 /* convenience: set_rhs + iterate + get_x (+ history if non-NULL, (nIterations+1)*nRHS values), host arrays */
 int cgamd_solver_solve(cgamd_solver *s, const void *b, void *x, int nIterations, void *history);
 /* the solver's SpMV (optionally fused with the d.q partial reduction) on caller vectors -- bench/profiling */

@@ -119,6 +119,37 @@ def cg_tol(indptr, indices, data, b, x0=None, tol=1e-5, maxit=1000):
     return x, it
 
 
+def pcg_diag(indptr, indices, data, b, m=None, x0=None, tol=1e-6, maxit=1000, history=False):
+    """Preconditioned CG with a diagonal M: helmFE_var.py:546-586, branch `z = M.dot(r)` (M a CSR matrix with
+    nnz <= n, i.e. diagonal) or `z = r` for M None.  m is that diagonal as a vector.  Unconjugated dots, stop on
+    sqrt(|r.r|) < tol AFTER the update, returns (x, i) with i the index of the last iteration run -- exactly the
+    reference's return value.  history=True additionally returns [r0.r0, r1.r1, ...] for the device parity tests."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix((data, indices, indptr), shape=(len(indptr) - 1,) * 2)
+    M = None if m is None else sp.csr_matrix(sp.diags(np.asarray(m)))   # the reference multiplies through a CSR matvec
+    x = np.zeros(b.size, dtype=complex) if x0 is None else x0
+    r = b - A.dot(x)
+    hist = [np.dot(r, r)]
+    i = -1
+    for i in range(maxit):
+        z = r if M is None else M.dot(r)
+        rho = np.dot(r, z)
+        if i == 0:
+            p = z
+        else:
+            beta = rho / rho_2
+            p = z + beta * p
+        q = A.dot(p)
+        alpha = rho / np.dot(p, q)
+        x = x + alpha * p
+        r = r - alpha * q
+        hist.append(np.dot(r, r))
+        if np.sqrt(abs(hist[-1])) < tol:
+            break
+        rho_2 = rho
+    return (x, i, np.asarray(hist)) if history else (x, i)
+
+
 # ----------------------------------------------------------------------------
 # Generators
 # ----------------------------------------------------------------------------

@@ -6,7 +6,7 @@ GPU box never sees /root/reference, so the vectors are committed as data.
 
 What is imported / executed from the reference (read-only, /root/reference):
   * helmFE_var.py as a module: helmFE_var (:9-331), rhsA/rhsL/rhs (:333-389),
-    CG (:507-544).  Needs only numpy/scipy.
+    CG (:507-544), PCG (:546-586).  Needs only numpy/scipy.
   * three pure functions of p_h-PY_C-CL.py extracted by `ast` and exec'd with
     numpy/scipy names (the file itself cannot be imported: it needs mpi4py and
     pyopencl and runs a whole solve at import): Poisson (:1642-1682),
@@ -142,6 +142,34 @@ def main():
     except Exception as e:  # pragma: no cover
         print("local_rect extraction failed:", e)
     np.savez_compressed(os.path.join(OUT, "driver_generators.npz"), **drv)
+
+    # ---- (5) diagonally preconditioned CG: the unmodified reference PCG (helmFE_var.py:546-586) ----------
+    pc = {}
+    N = 16
+    H = scipy.sparse.csr_matrix(hv.helmFE_var(N=N, omega=12.0, C=np.ones((N - 1, N - 1)), rho=0.15, Nhoriz=N, Nvert=N))
+    b = hv.rhsA(N, 12.0).flatten()
+    m = 1.0 / H.diagonal()
+    M = scipy.sparse.csr_matrix(scipy.sparse.diags(m))
+    for k, v in csr_parts(H).items():
+        pc[f"helm16_{k}"] = v
+    pc["helm16_b"], pc["helm16_m"] = b, m
+    K = 40     # tol = 0 never triggers the stopping test: exactly k iterations
+    pc["helm16_jacobi_X"] = np.stack([hv.PCG(H, b, M=M, tol=0.0, maxit=k)[0] for k in range(1, K + 1)])
+    x, i = hv.PCG(H, b, M=M, tol=1e-6, maxit=1000)
+    pc["helm16_jacobi_tol1e-6_x"], pc["helm16_jacobi_tol1e-6_i"] = x, np.array(i)
+    x, i = hv.PCG(H, b, M=None, tol=1e-6, maxit=1000)
+    pc["helm16_none_tol1e-6_x"], pc["helm16_none_tol1e-6_i"] = x, np.array(i)
+    # real SPD system with a non-constant diagonal, so that Jacobi changes the iteration
+    A2 = scipy.sparse.csr_matrix(fns["Poisson"](8) + scipy.sparse.diags(np.linspace(0.0, 3.0, 64)))
+    m2 = 1.0 / A2.diagonal()
+    M2 = scipy.sparse.csr_matrix(scipy.sparse.diags(m2))
+    for k, v in csr_parts(A2).items():
+        pc[f"shifted_poisson8_{k}"] = v
+    pc["shifted_poisson8_b"], pc["shifted_poisson8_m"] = bP, m2
+    pc["shifted_poisson8_jacobi_X"] = np.stack([hv.PCG(A2, bP, M=M2, tol=0.0, maxit=k)[0] for k in range(1, 21)])
+    x, i = hv.PCG(A2, bP, M=M2, tol=1e-10, maxit=1000)
+    pc["shifted_poisson8_jacobi_tol1e-10_x"], pc["shifted_poisson8_jacobi_tol1e-10_i"] = x, np.array(i)
+    np.savez_compressed(os.path.join(OUT, "pcg_iterates.npz"), **pc)
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -25,7 +25,7 @@ def pkg():
 @pytest.fixture(scope="session")
 def golden():
     return {name: np.load(os.path.join(GOLDEN, name + ".npz"))
-            for name in ("generators", "cg_iterates", "driver_generators")}
+            for name in ("generators", "cg_iterates", "driver_generators", "pcg_iterates")}
 
 
 @pytest.fixture(scope="session")

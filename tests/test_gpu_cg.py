@@ -193,3 +193,74 @@ def test_tolerance_stopping_mode(pkg, gpu, golden):
     assert 23 <= its <= 28
     assert np.linalg.norm(x - want) / np.linalg.norm(want) < 1e-8
     assert np.sqrt(abs(h[-1, 0])) < 1e-8
+
+
+def test_jacobi_pcg_against_reference_iterates(pkg, gpu, golden):
+    """diagonally preconditioned CG = the reference's PCG(A, b, M) with a diagonal CSR M
+    (helmFE_var.py:546-586).  x_k against the iterates of the unmodified reference (complex128 Helmholtz with M = 1/diag,
+    real shifted Poisson), r_k.r_k against the oracle restatement (bit-identical to the reference on CPU), the
+    tolerance-stopping entry against the reference's (x, i), and plain CG again once the preconditioner is removed."""
+    ctx, queue, kernels = gpu
+    g = golden["pcg_iterates"]
+    for name, dtype in (("helm16", np.complex128), ("shifted_poisson8", np.float64)):
+        ip, ix, da, b, m = (g[f"{name}_{k}"] for k in ("indptr", "indices", "data", "b", "m"))
+        X = g[f"{name}_jacobi_X"]
+        n = len(ip) - 1
+        s = pkg.Solver(ctx, n, len(ix), da.astype(dtype), ip, ix, 1)
+        s.set_preconditioner(m.astype(dtype))
+        for k in (1, 2, 3, 7, 12, X.shape[0]):
+            x, h = s.solve(b.astype(dtype), None, k)
+            rel = np.linalg.norm(x - X[k - 1]) / np.linalg.norm(X[k - 1])
+            assert rel < 1e-9, (name, k, rel)
+            _, _, ho = cg_numpy.pcg_diag(ip, ix, da, b, m, tol=0.0, maxit=k, history=True)
+            assert h.shape == (k + 1, 1)
+            keep = np.abs(ho) / np.abs(ho[0]) > 1e-8           # reduction-order noise only while not converged
+            assert np.max(np.abs(h[keep, 0] - ho[keep]) / np.abs(ho[keep])) < 1e-10, (name, k)
+        tol_key, tol = ("jacobi_tol1e-6", 1e-6) if name == "helm16" else ("jacobi_tol1e-10", 1e-10)
+        x, i = s.pcg(b.astype(dtype), M=m.astype(dtype), tol=tol, maxit=1000, check_every=5)
+        assert i == int(g[f"{name}_{tol_key}_i"])
+        want = g[f"{name}_{tol_key}_x"]
+        assert np.linalg.norm(x - want) / np.linalg.norm(want) < 1e-8
+        # pcg() leaves the handle unpreconditioned: the plain recurrence again
+        xo, ho = cg_oracle.cg(ip, ix, da.astype(dtype), b.astype(dtype), n_iterations=10, mode=cg_oracle.MODE_SEQUENTIAL)
+        x, h = s.solve(b.astype(dtype), None, 10)
+        assert np.max(np.abs(h[:, 0] - ho[:, 0]) / np.abs(ho[:, 0])) < 1e-10
+        s.close()
+    # M = None through the same entry: the reference's unpreconditioned branch (z = r)
+    ip, ix, da, b = (g[f"helm16_{k}"] for k in ("indptr", "indices", "data", "b"))
+    s = pkg.Solver(ctx, len(ip) - 1, len(ix), da, ip, ix, 1)
+    x, i = s.pcg(b, M=None, tol=1e-6, maxit=1000)
+    assert i == int(g["helm16_none_tol1e-6_i"])
+    assert np.linalg.norm(x - g["helm16_none_tol1e-6_x"]) / np.linalg.norm(x) < 1e-8
+    s.close()
+
+
+@pytest.mark.parametrize("dtype,rtol", [(np.float32, 1e-4), (np.complex64, 1e-4), (np.float64, 1e-10)])
+def test_jacobi_pcg_multi_rhs_and_precisions(pkg, gpu, dtype, rtol):
+    """the preconditioned kernels on a larger system (several row blocks, vector + tail paths: n = 61*61), 3 right-hand
+    sides sharing one M, every value type, against the oracle run per right-hand side"""
+    import scipy.sparse as sp
+    ctx, queue, kernels = gpu
+    N = 61
+    ip, ix, da = cg_numpy.poisson2d(N)
+    n = N * N
+    shift = np.linspace(0.5, 4.0, n)
+    A = sp.csr_matrix((da, ix, ip), shape=(n, n)) + sp.diags(shift)
+    A = sp.csr_matrix(A); A.sort_indices()
+    ip, ix, da = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
+    cplx = np.dtype(dtype).kind == "c"
+    if cplx:
+        da = da * (1.0 + 0.05j)
+    m = 1.0 / sp.csr_matrix((da, ix, ip), shape=(n, n)).diagonal()
+    rng = np.random.default_rng(7)
+    B = rng.standard_normal((3, n)) + (1j * rng.standard_normal((3, n)) if cplx else 0)
+    iters = 12
+    s = pkg.Solver(ctx, n, len(ix), da.astype(dtype), ip, ix, 3)
+    s.set_preconditioner(m.astype(dtype))
+    x, h = s.solve(B.reshape(-1).astype(dtype), None, iters)
+    s.close()
+    for r in range(3):
+        xo, _, ho = cg_numpy.pcg_diag(ip, ix, da, B[r].astype(complex), m, tol=0.0, maxit=iters, history=True)
+        keep = np.abs(ho) / np.abs(ho[0]) > 1e-4
+        assert np.max(np.abs(h[keep, r] - ho[keep]) / np.abs(ho[keep])) < rtol, (dtype, r)
+        assert np.linalg.norm(x[r * n:(r + 1) * n] - xo) / np.linalg.norm(xo) < max(rtol * 10, 1e-9)

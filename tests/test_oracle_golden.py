@@ -182,3 +182,25 @@ def test_byte_model_matches_baseline_table():
     assert cg_numpy.cg_iter_bytes(10_000_000, 69_720_000, 8, fused=True) == 1_756_640_004
     assert round(cg_numpy.spmv_bytes(1_000_000, 4_996_000, 8) / 1e6, 2) == 79.95
     assert round(cg_numpy.spmv_bytes(1_000_000, 4_996_000, 8, nrhs=32) / 1e6, 2) == 575.95
+
+
+def test_numpy_pcg_bit_identical_to_reference_pcg(golden):
+    """oracle pcg_diag == the unmodified reference PCG with a diagonal CSR M (helmFE_var.py:546-586): iterates,
+    stopping iteration and solution, complex (Helmholtz, M = 1/diag) and real (shifted Poisson)."""
+    g = golden["pcg_iterates"]
+    for name, tol_key, tol in (("helm16", "jacobi_tol1e-6", 1e-6), ("shifted_poisson8", "jacobi_tol1e-10", 1e-10)):
+        ip, ix, da, b, m = (g[f"{name}_{k}"] for k in ("indptr", "indices", "data", "b", "m"))
+        X = g[f"{name}_jacobi_X"]
+        for k in range(1, X.shape[0] + 1):
+            x, i = cg_numpy.pcg_diag(ip, ix, da, b, m, tol=0.0, maxit=k)
+            assert i == k - 1
+            assert np.array_equal(x, X[k - 1]), (name, k)
+        x, i = cg_numpy.pcg_diag(ip, ix, da, b, m, tol=tol, maxit=1000)
+        assert i == int(g[f"{name}_{tol_key}_i"])
+        assert np.array_equal(x, g[f"{name}_{tol_key}_x"])
+    ip, ix, da, b = (g[f"helm16_{k}"] for k in ("indptr", "indices", "data", "b"))
+    x, i = cg_numpy.pcg_diag(ip, ix, da, b, None, tol=1e-6, maxit=1000)
+    assert i == int(g["helm16_none_tol1e-6_i"]) and np.array_equal(x, g["helm16_none_tol1e-6_x"])
+    # history bookkeeping used by the GPU parity tests: entry k is r_k.r_k
+    x, i, h = cg_numpy.pcg_diag(ip, ix, da, b, g["helm16_m"], tol=0.0, maxit=7, history=True)
+    assert h.shape == (8,) and i == 6
