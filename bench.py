@@ -115,6 +115,9 @@ def main():
 
     pkg = importlib.import_module(PKG)
     lib = pkg._lib
+    for pair in filter(None, os.environ.get("CG_TUNE", "").split(",")):      # experiment knobs, e.g. CG_TUNE=vec_grid=512
+        k, v = pair.split("=")
+        lib.check(lib.load().cgamd_tune(k.encode(), int(v)))
     dtype = NP_DTYPE[args.dtype]
     nx, ny, nz = (int(v) for v in args.grid.split("x"))
     ctx = pkg.Context(local_rank)
