@@ -1045,9 +1045,13 @@ CG_DEV float2 ld_sys_val(const float2 *p) {
 CG_DEV double2 ld_sys_val(const double2 *p) { return make_double2(ld_sys_val(reinterpret_cast<const double *>(p)), ld_sys_val(reinterpret_cast<const double *>(p) + 1)); }
 
 // spin (one lane) until *word == want; false on timeout
-CG_DEV bool spin_until(const unsigned long long *word, unsigned long long want) {
+CG_DEV bool spin_until(const unsigned long long *word, unsigned long long want, const char *my_mailbox) {
+    // once any spin of this rank has timed out (error word set) later spins give up after one look: a broken
+    // exchange then costs one time-out, not one per kernel
+    const unsigned long long *err = reinterpret_cast<const unsigned long long *>(my_mailbox + kMbError);
     for (long long i = 0; i < kSpinLimit; ++i) {
         if (ld_sys(word) == want) return true;
+        if ((i & 1023) == 1023 && ld_sys(err) != 0) return false;
         __builtin_amdgcn_s_sleep(1);
     }
     return false;
@@ -1107,7 +1111,7 @@ template <typename T> __global__ __launch_bounds__(kP2pBlock) void p2p_wait_unpa
     const int cnt = a.recv_count[p], k0 = blockIdx.x * kP2pChunk + threadIdx.x;
     if ((int)blockIdx.x * kP2pChunk < cnt) {
         if (threadIdx.x == 0) {
-            if (!spin_until(reinterpret_cast<unsigned long long *>(mb + kMbHaloFlags) + a.peer_rank[p], ep))
+            if (!spin_until(reinterpret_cast<unsigned long long *>(mb + kMbHaloFlags) + a.peer_rank[p], ep, mb))
                 st_sys(reinterpret_cast<unsigned long long *>(mb + kMbError), 1ULL);
         }
         __syncthreads();
@@ -1183,7 +1187,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T>
         const unsigned long long ep = *g.x.epoch + 1;
         for (int p = 0; p < g.x.n_peers; ++p) {
             if (g.x.recv_count[p] == 0) continue;
-            if (!spin_until(reinterpret_cast<const unsigned long long *>(mb + kMbHaloFlags) + g.x.peer_rank[p], ep))
+            if (!spin_until(reinterpret_cast<const unsigned long long *>(mb + kMbHaloFlags) + g.x.peer_rank[p], ep, mb))
                 st_sys(reinterpret_cast<unsigned long long *>(const_cast<char *>(mb) + kMbError), 1ULL);
         }
     }
@@ -1272,7 +1276,7 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_p2p_kernel(int n, const T *x,
     }
     if (s < nranks) {
         const unsigned long long *in = reinterpret_cast<const unsigned long long *>(mailbox[rank] + kMbSlots) + ((long long)which * 64 + s) * 4;
-        if (!spin_until(in + 2, ep)) st_sys(reinterpret_cast<unsigned long long *>(mailbox[rank] + kMbError), 2ULL);
+        if (!spin_until(in + 2, ep, mailbox[rank])) st_sys(reinterpret_cast<unsigned long long *>(mailbox[rank] + kMbError), 2ULL);
         vx[s] = __longlong_as_double((long long)ld_sys(in));
         vy[s] = __longlong_as_double((long long)ld_sys(in + 1));
     }
@@ -1333,7 +1337,7 @@ __global__ __launch_bounds__(kScalarBlock) void p2p_allreduce_kernel(const typen
         p2p_stores_done();
         st_sys(slot + 2, ep);
         const unsigned long long *in = reinterpret_cast<const unsigned long long *>(mailbox[rank] + kMbSlots) + ((long long)which * 64 + s) * 4;
-        if (!spin_until(in + 2, ep)) st_sys(reinterpret_cast<unsigned long long *>(mailbox[rank] + kMbError), 2ULL);
+        if (!spin_until(in + 2, ep, mailbox[rank])) st_sys(reinterpret_cast<unsigned long long *>(mailbox[rank] + kMbError), 2ULL);
         vx[s] = __longlong_as_double((long long)ld_sys(in));
         vy[s] = __longlong_as_double((long long)ld_sys(in + 1));
     }
