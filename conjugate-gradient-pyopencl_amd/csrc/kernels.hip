@@ -306,9 +306,72 @@ CG_DEV void stage_slice_impl(const T *__restrict__ vals, const int *__restrict__
         }
     }
 }
+// Same job with the VALUE stream interleaved across the lanes in 16-byte chunks: chunk k of a lane is chunk k*64 + lane of
+// its wave's 256-entry span, so every load instruction of a wave covers one contiguous 1 KB (the plain version above gives
+// a lane 4 consecutive entries = 16/32/64 contiguous bytes, and each of its 1/2/4 load instructions touches every cache
+// line of the span partially).  With non-temporal loads the partially used lines of complex128 were fetched again by the
+// later instructions: 435 -> 313 us for the N=10M SpMV.  Columns (4 B) keep the quad mapping: one 16-byte load per lane.
+template <typename T> struct Chunk16;
+template <> struct Chunk16<float> { using V = f32x4; };
+template <> struct Chunk16<double> { using V = f64x2; };
+template <> struct Chunk16<float2> { using V = f32x4; };
+template <> struct Chunk16<double2> { using V = f64x2; };
+template <typename T, int BLOCK, bool NT, bool FULL>
+CG_DEV void stage_slice_ilv(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
+                            T *sv, int *sc) {
+    using V = typename Chunk16<T>::V;
+    constexpr int EPC = 16 / (int)sizeof(T);   // values per chunk
+    constexpr int NV = 4 / EPC;                // chunks per lane and quad region
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    for (long long base = cfirst; base < p1; base += 8 * BLOCK) {
+        V ch[2][NV];
+        i32x4 cc[2];
+        long long ev[2][NV], qc[2];
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            const long long rbase = base + (long long)rg * 4 * BLOCK;
+            qc[rg] = rbase + 4 * t;
+            if (qc[rg] < p1 && (FULL || qc[rg] + 4 <= nnz)) cc[rg] = ld16<i32x4, NT>(cols + qc[rg]);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                ev[rg][k] = rbase + (long long)wave * 4 * kWave + (long long)(k * kWave + lane) * EPC;
+                if (ev[rg][k] < p1 && (FULL || ev[rg][k] + EPC <= nnz)) ch[rg][k] = ld16<V, NT>(vals + ev[rg][k]);
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            if (qc[rg] < p1) {
+                const int o = (int)(qc[rg] - cfirst);
+                if (FULL || qc[rg] + 4 <= nnz) {
+                    *reinterpret_cast<i32x4 *>(sc + o) = cc[rg];
+                } else {
+                    for (int j = 0; j < 4; ++j) sc[o + j] = qc[rg] + j < nnz ? cols[qc[rg] + j] : 0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (ev[rg][k] < p1) {
+                    const int o = (int)(ev[rg][k] - cfirst);
+                    if (FULL || ev[rg][k] + EPC <= nnz) {
+                        *reinterpret_cast<V *>(sv + o) = ch[rg][k];
+                    } else {
+                        for (int j = 0; j < EPC; ++j) sv[o + j] = ev[rg][k] + j < nnz ? vals[ev[rg][k] + j] : vzero<T>();
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T> constexpr bool kIlvDefault = true;   // N=10M SpMV: f64 186 -> 165 us, c64 186 -> 166, c128 435 -> 314, f32 109 -> 105 (ab_ilv.log)
 template <typename T, int BLOCK, bool NT, int POL = -1>
 CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1, T *sv,
                         int *sc) {
+    if (POL == -2) {       // lane-interleaved value chunks
+        if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true>(vals, cols, nnz, cfirst, p1, sv, sc);
+        else stage_slice_ilv<T, BLOCK, NT, false>(vals, cols, nnz, cfirst, p1, sv, sc);
+        return;
+    }
     // only the work-group that owns the very end of the matrix can meet a partial quad: block-uniform branch,
     // so the common path carries no per-lane tail handling (whose control flow made hipcc serialise the loads)
     if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_impl<T, BLOCK, NT, true, POL>(vals, cols, nnz, cfirst, p1, sv, sc);
@@ -320,7 +383,8 @@ CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols
 // "matrix through LDS, one lane per row", ONE row block per work-group, no persistence.
 //   * The slice of aValues/aCols that belongs to BLOCK consecutive rows is contiguous; it is streamed with
 //     16 B per lane coalesced non-temporal loads (start rounded down to a multiple of 4 entries so every
-//     load is aligned) and parked RAW in LDS.
+//     load is aligned; every load instruction of a wave covers one contiguous 1 KB, stage_slice_ilv) and parked RAW
+//     in LDS.
 //   * After one barrier lane t walks row t out of LDS (up to UNROLL entries in flight).  The x gather of
 //     step k is issued by 64 lanes sitting in 64 consecutive rows: for banded matrices their k-th columns are
 //     consecutive, so one wave-level gather touches ~4 cache lines (a nnz-per-lane mapping touches ~24).
@@ -431,7 +495,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowblock_kernel(SpmvArgs<T> a) {
     const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
-    stage_slice<T, BLOCK, NT>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+    stage_slice<T, BLOCK, NT, -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
     const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
     __syncthreads();
     const int wave = t / kWave, lane = t & (kWave - 1);
@@ -524,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_mfma_kernel(SpmmMfmaArgs<T> a) {
     const int r0 = rbm * BLOCK;
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
-    stage_slice<T, BLOCK, true>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+    stage_slice<T, BLOCK, true, -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
     __syncthreads();
     const int m = lane & 15, kq = lane >> 4;
 #pragma unroll 1
@@ -1179,7 +1243,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T>
     const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
-    stage_slice<T, BLOCK, NT, -1>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+    stage_slice<T, BLOCK, NT, -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
     const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
     const bool boundary = bflag != 0;
     if (boundary && t == 0) {
@@ -1502,10 +1566,17 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : rowblock_grid(plan.row_blocks, a.cycle));
         if (rb_list && rb_count <= 0) return CGAMD_OK;
         const bool nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
-#define CG_RB(NT, UNR)                                                                                           \
-    do {                                                                                                         \
-        if (fuse) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, true, UNR>), g5, block, lds, st, a);   \
-        else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, UNR>), g5, block, lds, st, a);       \
+        // value stream interleaved across the lanes in 16-byte chunks (stage_slice_ilv): "spmv_ilv" 1/0, -1 = auto
+        const bool ilv = g_tune.spmv_ilv >= 0 ? (g_tune.spmv_ilv != 0) : kIlvDefault<T>;
+#define CG_RB(NT, UNR)                                                                                                  \
+    do {                                                                                                                \
+        if (ilv) {                                                                                                      \
+            if (fuse) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -2>), g5, block, lds, st, a);  \
+            else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -2>), g5, block, lds, st, a);      \
+        } else {                                                                                                        \
+            if (fuse) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, true, UNR>), g5, block, lds, st, a);      \
+            else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, UNR>), g5, block, lds, st, a);          \
+        }                                                                                                               \
     } while (0)
         // 8 gathers in flight per lane for 4/8-byte values; 4 for complex128 (8 would cost 3 waves/SIMD of occupancy)
         if (g_tune.spmv_policy >= 0 && sizeof(T) == 8 && !VT<T>::cplx && fuse) {

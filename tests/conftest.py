@@ -19,7 +19,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
-    return importlib.import_module(PKG_NAME)
+    mod = importlib.import_module(PKG_NAME)
+    # CG_TUNE=key=value,... runs the whole suite under a non-default kernel configuration (experiments)
+    for pair in filter(None, os.environ.get("CG_TUNE", "").split(",")):
+        k, v = pair.split("=")
+        mod._lib.check(mod._lib.load().cgamd_tune(k.encode(), int(v)))
+    return mod
 
 
 @pytest.fixture(scope="session")
