@@ -50,11 +50,11 @@ constexpr int kMaxSliceBytes = 64 * 1024;   // variant 5: largest LDS slice acce
 struct Tuning {
     int spmv_variant = 5;   // 5 = row-block kernel (matrix through LDS, one row block per work-group), 0 = generic chunked
     int spmv_nt = -1;       // non-temporal matrix loads: 1 on, 0 off, -1 auto = on unless the matrix fits the 256 MB Infinity
-                            // Cache (<= 384 MB measured break-even: below it the re-used matrix is served from the cache)
+                            // Cache (below that the re-used matrix is served from the cache; finalize_spmv_plan)
     int spmv_unroll = 0;    // row walk: LDS reads + gathers in flight per lane (4 or 8; 0 = 8, or 4 for 16-byte values)
     int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = all in one launch)
     int vec_skew = 0;       // bytes added to the pitch between the solver's vectors (multiple of 16)
-    int vec_nt = -1;        // -1 auto (3, or 0 when matrix + vectors stay cache resident); axpy2_dot: bit0 = x loaded/stored non-temporally (touched once per iteration), bit1 = q loaded
+    int vec_nt = -1;        // -1 auto (by working-set size, finalize_spmv_plan); axpy2_dot: bit0 = x loaded/stored non-temporally (touched once per iteration), bit1 = q loaded
                             // non-temporally (its last use): d and r, which are re-read, keep the caches; measured -10..-22 us/iteration
     int spmv_policy = -1;   // experiment: >= 0 = matrix stream via buffer loads with this cache-policy aux field
     int spmv_lds_pad = 0;   // experiment: extra dynamic LDS bytes per work-group (lowers occupancy)

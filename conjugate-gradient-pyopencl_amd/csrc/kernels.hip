@@ -1649,14 +1649,19 @@ int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scrat
 
 // decides once which SpMV kernel a solver uses (and therefore how many dot partials it produces)
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols) {
-    // Cache policy.  The 256 MB Infinity Cache keeps a matrix of up to ~384 MB mostly resident from one iteration to the
-    // next; streaming it non-temporally then only throws that away (N=1.25M rows, f64: SpMV 25.7 -> 21.4 us, iteration
-    // 49.3 -> 42.5 us; break-even between 313 and 418 MB, profiles/r1_experiments/ab_nt_sizes.log).  Larger matrices are
-    // streamed non-temporally so that the vectors, which ARE re-used within the iteration, keep the cache.
+    // Cache policy (profiles/r1_experiments/ab_nt_sizes2.log, z-slabs of the 250x200x200 system, fp64).  A matrix of up to
+    // ~256 MB stays mostly resident in the 256 MB Infinity Cache from one iteration to the next: streaming it
+    // non-temporally only throws that away (1.25M rows: 47.1 -> 43.3 us/iteration, 2.5M rows: 80.3 -> 76.0).  Larger
+    // matrices are streamed non-temporally so that the vectors, which ARE re-used within the iteration, keep the cache
+    // (3.75M rows: 117 -> 111 us, 5M: 152 -> 144).  axpy2_dot's streaming hints for x and q pay when the working set is
+    // far beyond the cache (>= 7.5M rows) or when the matrix competes for it (2.5M rows), not in between.
     const size_t matrix_bytes = (size_t)nnz * (dtype_size(dtype) + 4) + ((size_t)n + 1) * 4;
     const size_t vector_bytes = (size_t)n * dtype_size(dtype) * (size_t)nrhs;
-    plan->nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (matrix_bytes > ((size_t)384 << 20));
-    plan->vec_nt = g_tune.vec_nt >= 0 ? g_tune.vec_nt : ((matrix_bytes + 5 * vector_bytes <= ((size_t)200 << 20)) ? 0 : 3);
+    const size_t MB = (size_t)1 << 20;
+    plan->nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (matrix_bytes > 256 * MB);
+    if (g_tune.vec_nt >= 0) plan->vec_nt = g_tune.vec_nt;
+    else if (!plan->nt) plan->vec_nt = (matrix_bytes + 5 * vector_bytes <= 200 * MB) ? 0 : 3;
+    else plan->vec_nt = (matrix_bytes <= 512 * MB) ? 0 : 3;
     int kind = g_tune.spmv_variant;
     const bool vec = aligned16(vals) && aligned16(cols);
     if (!vec || plan->max_span <= 0) kind = 0;
