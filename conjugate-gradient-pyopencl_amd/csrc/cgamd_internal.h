@@ -58,6 +58,7 @@ struct Tuning {
                             // non-temporally (its last use): d and r, which are re-read, keep the caches; measured -10..-22 us/iteration
     int spmv_policy = -1;   // experiment: >= 0 = matrix stream via buffer loads with this cache-policy aux field
     int spmv_lds_pad = 0;   // experiment: extra dynamic LDS bytes per work-group (lowers occupancy)
+    int alpha_two_level = 1; // cg_alpha over >= 16384 partials: 32 work-groups + last-arrival combine (0 = one work-group)
     int spmv_ilv = -1;      // slice staging: value stream interleaved across lanes in 16-byte chunks (1), quads per lane (0), -1 auto
     int spmv_cycle = 64;    // row-block schedule: block-cyclic over the XCDs, cycle length in row blocks (1 = contiguous eighths)
     int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)
@@ -95,6 +96,8 @@ struct CgScalars {
     void *history = nullptr;   // T[cap][nrhs]
     int *iter = nullptr;       // iterations completed
     int history_cap = 0;
+    void *stage = nullptr;     // optional, two-level cg_alpha: acc[nrhs][32] part sums
+    unsigned *ticket = nullptr;   //          and one zero-initialised ticket counter per RHS
 };
 // delta[r] = sum partials ; history[0][r] = delta[r] ; *iter = 0
 int launch_cg_delta0(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st);

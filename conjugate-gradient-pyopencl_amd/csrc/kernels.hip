@@ -1032,6 +1032,43 @@ __global__ __launch_bounds__(kScalarBlock) void cg_alpha_kernel(const typename V
     }
 }
 
+// Two-level form for long partial arrays (one per row block: 39 063 at N=10M): kAlphaParts work-groups each sum one
+// contiguous part (fixed order inside), the last one to finish (device ticket) adds the part sums in part order and does
+// the scalar step -- the result does not depend on which work-group came last.  One work-group needed 5 rounds of 8 loads
+// per thread (8 us); this needs one (4.5 us).
+constexpr int kAlphaParts = 32;
+template <typename T>
+__global__ __launch_bounds__(kScalarBlock) void cg_alpha2_kernel(const typename VT<T>::acc *partials, int grid, int nrhs,
+                                                        const T *delta, T *alpha, int *iter,
+                                                        typename VT<T>::acc *stage, unsigned *ticket) {
+    using A = typename VT<T>::acc;
+    __shared__ A smem[kScalarBlock / kWave];
+    __shared__ bool last;
+    const int r = blockIdx.y, part = blockIdx.x;
+    const int per = (grid + kAlphaParts - 1) / kAlphaParts;
+    const int lo = min(part * per, grid), hi = min(lo + per, grid);
+    const A sum = sum_partials_block(partials + (long long)r * grid + lo, hi - lo, smem);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(reinterpret_cast<double *>(stage + (long long)r * kAlphaParts + part), to_acc2(sum).x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (VT<T>::cplx)
+            __hip_atomic_store(reinterpret_cast<double *>(stage + (long long)r * kAlphaParts + part) + 1, to_acc2(sum).y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned prev = __hip_atomic_fetch_add(ticket + r, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = prev + 1 == (unsigned)kAlphaParts;
+        if (last) {
+            __hip_atomic_store(ticket + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double2 tot = make_double2(0., 0.);
+            for (int k = 0; k < kAlphaParts; ++k) {
+                const double *p = reinterpret_cast<const double *>(stage + (long long)r * kAlphaParts + k);
+                tot.x += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (VT<T>::cplx) tot.y += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const T dqT = from_acc<T>(from_acc2<A>(tot));
+            alpha[r] = from_acc<T>(acc_div(to_acc(delta[r]), to_acc(dqT)));
+            if (r == 0) *iter = *iter + 1;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kScalarBlock) void cg_beta_kernel(const typename VT<T>::acc *partials, int grid, int nrhs, T *delta,
                                                       T *beta, T *history, int history_cap, const int *iter) {
@@ -1775,8 +1812,13 @@ int launch_cg_delta0(int dtype, const void *partials, int grid, int nrhs, const 
     CG_DISPATCH(dtype, delta0_impl, partials, grid, nrhs, s, st);
 }
 template <typename T> static int alpha_impl(const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
-    hipLaunchKernelGGL((cg_alpha_kernel<T>), dim3(nrhs), dim3(kScalarBlock), 0, st, static_cast<const typename VT<T>::acc *>(partials),
-                       grid, nrhs, (const T *)s.delta, (T *)s.alpha, s.iter);
+    using A = typename VT<T>::acc;
+    if (s.stage && s.ticket && grid >= 16384 && g_tune.alpha_two_level != 0)
+        hipLaunchKernelGGL((cg_alpha2_kernel<T>), dim3(kAlphaParts, nrhs), dim3(kScalarBlock), 0, st, static_cast<const A *>(partials),
+                           grid, nrhs, (const T *)s.delta, (T *)s.alpha, s.iter, (A *)s.stage, s.ticket);
+    else
+        hipLaunchKernelGGL((cg_alpha_kernel<T>), dim3(nrhs), dim3(kScalarBlock), 0, st, static_cast<const A *>(partials),
+                           grid, nrhs, (const T *)s.delta, (T *)s.alpha, s.iter);
     return check_launch("cg_alpha");
 }
 int launch_cg_alpha(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {

@@ -178,6 +178,9 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) rc = dmalloc(&s->sc.beta, vs * nRHS, "beta");
     if (!rc) rc = dmalloc(&s->sc.delta, vs * nRHS, "delta");
     if (!rc) rc = dmalloc((void **)&s->sc.iter, 16, "iter");
+    if (!rc) rc = dmalloc(&s->sc.stage, acc_size(dtype) * 32 * (size_t)nRHS, "alpha stage");
+    if (!rc) rc = dmalloc((void **)&s->sc.ticket, sizeof(unsigned) * (size_t)nRHS, "alpha tickets");
+    if (!rc && hipMemset(s->sc.ticket, 0, sizeof(unsigned) * (size_t)nRHS) != hipSuccess) rc = fail(CGAMD_ERR_HIP, "hipMemset(alpha tickets)");
     if (!rc) rc = ensure_history(s, 1024);
     if (!rc) rc = compute_spmv_plan(s->ptr, s->cols, size, s->sc.iter, ctx->stream, &s->plan);
     if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, size, nnz, s->vals, s->cols);
@@ -206,7 +209,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
         if (s->cols) (void)hipFree(s->cols);
     }
     void *bufs[] = {s->slab, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
-                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2};
+                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;
