@@ -203,38 +203,66 @@ class DistSolver:
         idbuf = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)
         torch.cuda.synchronize()
         h = ctypes.c_void_p()
+        create_err = None
+        try:
+            self._create(ctx, plan, indptr_local, values, idbuf, peers, sc, rc, flags, h)
+        except Exception as e:      # noqa: BLE001 -- with the peer-to-peer backend the failure is raised on every rank
+            if comm != "p2p":
+                raise
+            create_err = e
+        self.handle = h if create_err is None else None
+        self.iterations = 0
+        if comm == "p2p":
+            self._attach_p2p(group, create_err)
+
+    def _create(self, ctx, plan, indptr_local, values, idbuf, peers, sc, rc, flags, h):
         check(self._lib.cgamd_dist_create(
             ctx.handle, ptr(idbuf), plan.rank, plan.world, _lib.DTYPE_CODE[self.dtype], plan.n_local, plan.n_halo,
             int(plan.cols_local.numel()), ptr(values), ptr(indptr_local), ptr(plan.cols_local), len(plan.peers),
             ptr(peers) if len(peers) else None, ptr(sc) if len(sc) else None, ptr(rc) if len(rc) else None,
             ptr(plan.send_index) if plan.send_index.numel() else None, int(flags), ctypes.byref(h)))
-        self.handle = h
-        self.iterations = 0
-        if comm == "p2p":
-            self._attach_p2p(group)
 
-    def _attach_p2p(self, group):
+    def _attach_p2p(self, group, create_err=None):
+        """Collective over `group`.  A failure on any rank (allocation, IPC mapping) is raised on EVERY rank, so that the
+        ranks keep executing the same sequence of collectives."""
         import torch.distributed as dist
         plan = self.plan
-        mb = ctypes.c_void_p()
-        handle = np.zeros(64, dtype=np.uint8)
-        check(self._lib.cgamd_p2p_mailbox_alloc(self.ctx.handle, plan.n_halo, _lib.DTYPE_CODE[self.dtype], ctypes.byref(mb), ptr(handle)))
-        self.mailbox = mb
+        err, handle = create_err, np.zeros(64, dtype=np.uint8)
+        try:
+            if err:
+                raise err
+            mb = ctypes.c_void_p()
+            check(self._lib.cgamd_p2p_mailbox_alloc(self.ctx.handle, plan.n_halo, _lib.DTYPE_CODE[self.dtype], ctypes.byref(mb), ptr(handle)))
+            self.mailbox = mb
+        except Exception as e:      # noqa: BLE001 -- reported collectively below
+            err = e
         recv_off, off = {}, 0
         for peer, cnt in zip(plan.peers, plan.recv_counts):      # where each peer's entries land in MY halo area
             recv_off[int(peer)] = off
             off += int(cnt)
-        mine = (handle.tobytes(), recv_off)
+        mine = (None if err else handle.tobytes(), recv_off)
         if plan.world > 1:
             everyone = [None] * plan.world
             dist.all_gather_object(everyone, mine, group=group)
         else:
             everyone = [mine]
-        handles = np.frombuffer(b"".join(e[0] for e in everyone), dtype=np.uint8).copy()
-        dst = np.asarray([everyone[int(p)][1][plan.rank] for p in plan.peers], dtype=np.int32)
-        check(self._lib.cgamd_dist_attach_p2p(self.handle, mb, ptr(handles), ptr(dst) if len(dst) else None))
-        if plan.world > 1:
-            dist.barrier(group=group)        # every mailbox is mapped before anyone pushes
+        if any(e[0] is None for e in everyone):
+            raise err if err else RuntimeError("peer-to-peer backend: a peer rank could not allocate its mailbox")
+        try:
+            if err:
+                raise err
+            handles = np.frombuffer(b"".join(e[0] for e in everyone), dtype=np.uint8).copy()
+            dst = np.asarray([everyone[int(p)][1][plan.rank] for p in plan.peers], dtype=np.int32)
+            check(self._lib.cgamd_dist_attach_p2p(self.handle, self.mailbox, ptr(handles), ptr(dst) if len(dst) else None))
+        except Exception as e:      # noqa: BLE001
+            err = e
+        if plan.world > 1:          # doubles as the barrier "every mailbox is mapped before anyone pushes"
+            oks = [None] * plan.world
+            dist.all_gather_object(oks, err is None, group=group)
+            if not all(oks):
+                raise err if err else RuntimeError("peer-to-peer backend: a peer rank could not map the mailboxes")
+        elif err:
+            raise err
 
     def p2p_error(self):
         return self._lib.cgamd_dist_p2p_error(self.handle)

@@ -25,6 +25,10 @@ def _free_port():
 
 def _system(kind):
     import cg_numpy
+    if kind.endswith("_f32") or kind.endswith("_c64"):          # single-precision variants of the same systems
+        ip, ix, da, b = _system(kind[:-4])
+        dt = np.float32 if kind.endswith("_f32") else np.complex64
+        return ip, ix, da.astype(dt), b.astype(dt)
     if kind == "lap3d":
         ip, ix, da = cg_numpy.laplace3d(24, 20, 36)          # 17280 rows: overlap lists are built (>= 16 row blocks/rank)
         b = np.linspace(1.0, 2.0, len(ip) - 1)
@@ -78,19 +82,23 @@ def _worker(rank, world, port, kind, iters, flags, out_dir):
 # flags: 0 = four-launch iteration (push + wait inside the SpMV launch, halo read in place, beta all-reduce inside aypx),
 # 8 = the same from a hipGraph, 128 = staged push / unpack / all-reduce launches (+8 graph, +32 no interior/boundary overlap)
 @pytest.mark.parametrize("world,kind,flags", [(2, "lap3d", 0), (3, "lap3d", 8), (2, "helm", 8), (3, "helm", 0), (4, "lap3d", 0),
-                                              (2, "lap3d", 128), (3, "lap3d", 128 | 8), (3, "helm", 128 | 32)])
+                                              (2, "lap3d", 128), (3, "lap3d", 128 | 8), (3, "helm", 128 | 32),
+                                              (2, "lap3d_f32", 0), (3, "helm_c64", 0)])
 def test_p2p_multirank_on_one_gpu(tmp_path, world, kind, flags):
     import torch.multiprocessing as mp
     import cg_oracle
     iters = 30
     mp.spawn(_worker, args=(world, _free_port(), kind, iters, flags, str(tmp_path)), nprocs=world, join=True)
     ip, ix, da, b = _system(kind)
-    xo, ho = cg_oracle.cg(ip, ix, da, b.astype(da.dtype), n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
+    # single-precision runs are held against the fp64 oracle (stated tolerance 1e-4 while delta_k/delta_0 > 1e-4)
+    wide = np.complex128 if np.dtype(da.dtype).kind == "c" else np.float64
+    xo, ho = cg_oracle.cg(ip, ix, da.astype(wide), b.astype(wide), n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
     parts = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
     assert all(int(p["err"]) == 0 for p in parts)
     for p in parts[1:]:
         assert np.array_equal(p["hist"], parts[0]["hist"])        # rank-ordered sums: bitwise identical on all ranks
-    keep = np.abs(ho[:, 0]) / np.abs(ho[0, 0]) > 1e-8
-    assert np.max(np.abs(parts[0]["hist"][keep] - ho[keep, 0]) / np.abs(ho[keep, 0])) < 1e-10
+    single = np.dtype(da.dtype).itemsize <= 8 and np.dtype(da.dtype) in (np.dtype(np.float32), np.dtype(np.complex64))
+    keep = np.abs(ho[:, 0]) / np.abs(ho[0, 0]) > (1e-4 if single else 1e-8)
+    assert np.max(np.abs(parts[0]["hist"][keep] - ho[keep, 0]) / np.abs(ho[keep, 0])) < (1e-4 if single else 1e-10)
     x = np.concatenate([p["x"] for p in parts])
-    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-9
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < (1e-3 if single else 1e-9)
