@@ -59,6 +59,7 @@ struct Tuning {
     int spmv_policy = -1;   // experiment: >= 0 = matrix stream via buffer loads with this cache-policy aux field
     int spmv_lds_pad = 0;   // experiment: extra dynamic LDS bytes per work-group (lowers occupancy)
     int alpha_two_level = 1; // cg_alpha over >= 16384 partials: 32 work-groups + last-arrival combine (0 = one work-group)
+    int fold_alpha = 1;     // small systems (<= 2048 d.q partials): alpha in the prologue of axpy2_dot, three launches per iteration
     int spmv_ilv = -1;      // slice staging: value stream interleaved across lanes in 16-byte chunks (1), quads per lane (0), -1 auto
     int spmv_cycle = 64;    // row-block schedule: block-cyclic over the XCDs, cycle length in row blocks (1 = contiguous eighths)
     int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)
@@ -99,6 +100,10 @@ struct CgScalars {
     void *stage = nullptr;     // optional, two-level cg_alpha: acc[nrhs][32] part sums
     unsigned *ticket = nullptr;   //          and one zero-initialised ticket counter per RHS
 };
+// small systems: alpha = delta / sum(part_dq) in the prologue (three-launch iteration); fold_alpha_ok says when
+bool fold_alpha_ok(int n_partials);
+int launch_axpy2_dot_alpha(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *part_dq,
+                           int P, const CgScalars &sc, int nrhs, void *partials, int grid, hipStream_t st);
 // delta[r] = sum partials ; history[0][r] = delta[r] ; *iter = 0
 int launch_cg_delta0(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st);
 // alpha[r] = delta[r] / sum partials_dq

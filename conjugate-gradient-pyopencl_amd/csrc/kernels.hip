@@ -671,17 +671,13 @@ template <int BLOCK> __global__ void spmv_span_kernel(int n, const int *__restri
 // Streaming vector kernels.  grid = (G, nRHS); RHS r lives at base + r*ld.
 // =================================================================================================
 // x += alpha d ; r -= alpha q ; partial(r.r)
-template <typename T, int BLOCK, bool VEC, int VNT = 0>
-__global__ __launch_bounds__(BLOCK) void axpy2_dot_kernel(int n, const T *__restrict__ d, T *__restrict__ x,
-                                                          const T *__restrict__ q, T *__restrict__ rv, long long ld,
-                                                          const T *__restrict__ alpha,
-                                                          typename VT<T>::acc *__restrict__ partials) {
+template <typename T, int BLOCK, bool VEC, int VNT>
+CG_DEV void axpy2_dot_body(int n, const T *__restrict__ d, T *__restrict__ x, const T *__restrict__ q, T *__restrict__ rv,
+                           long long ld, T al, typename VT<T>::acc *__restrict__ partials, typename VT<T>::acc *red) {
     using A = typename VT<T>::acc;
-    __shared__ A red[BLOCK / kWave];
     const int r = blockIdx.y;
     const long long off = (long long)r * ld;
     d += off; x += off; q += off; rv += off;
-    const T al = alpha[r];
     A acc = vzero<A>();
     constexpr int E = Pack<T>::N;
     const long long stride = (long long)gridDim.x * BLOCK;
@@ -710,6 +706,49 @@ __global__ __launch_bounds__(BLOCK) void axpy2_dot_kernel(int n, const T *__rest
     }
     const A tot = block_sum<BLOCK>(acc, red);
     if (threadIdx.x == 0) partials[(long long)r * gridDim.x + blockIdx.x] = tot;
+}
+
+template <typename T, int BLOCK, bool VEC, int VNT = 0>
+__global__ __launch_bounds__(BLOCK) void axpy2_dot_kernel(int n, const T *__restrict__ d, T *__restrict__ x,
+                                                          const T *__restrict__ q, T *__restrict__ rv, long long ld,
+                                                          const T *__restrict__ alpha,
+                                                          typename VT<T>::acc *__restrict__ partials) {
+    __shared__ typename VT<T>::acc red[BLOCK / kWave];
+    axpy2_dot_body<T, BLOCK, VEC, VNT>(n, d, x, q, rv, ld, alpha[blockIdx.y], partials, red);
+}
+
+// Three-launch iteration for small systems (at most kFoldAlphaMax d.q partials per RHS): alpha is computed in the
+// prologue of this launch -- every work-group adds the SpMV's d.q partials in the same fixed order, so all hold the
+// bit-identical alpha = delta / d.q (clcg.c:317-327); work-group 0 records alpha and advances the iteration counter
+// (nothing else in this launch reads either).  Saves the cg_alpha launch: 18.8 -> ~14 us per iteration at 250k rows.
+constexpr int kFoldAlphaMax = 2048;
+template <typename T, int BLOCK, bool VEC>
+__global__ __launch_bounds__(BLOCK) void axpy2_dot_alpha_kernel(int n, const T *__restrict__ d, T *__restrict__ x,
+                                                                const T *__restrict__ q, T *__restrict__ rv, long long ld,
+                                                                const typename VT<T>::acc *__restrict__ part_dq, int P,
+                                                                const T *__restrict__ delta, T *alpha, int *iter,
+                                                                typename VT<T>::acc *__restrict__ partials) {
+    using A = typename VT<T>::acc;
+    __shared__ A red[BLOCK / kWave];
+    __shared__ T alpha_s;
+    const int r = blockIdx.y;
+    {
+        A acc = vzero<A>();
+        const A *p = part_dq + (long long)r * P;
+        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, p[i]);
+        const A dq = block_sum<BLOCK>(acc, red);
+        if (threadIdx.x == 0) {
+            const T dqT = from_acc<T>(dq);      // the reference rounds d.q to the value type before dividing (clcg.c:318-327)
+            const T al = from_acc<T>(acc_div(to_acc(delta[r]), to_acc(dqT)));
+            alpha_s = al;
+            if (blockIdx.x == 0) {
+                alpha[r] = al;
+                if (r == 0) *iter = *iter + 1;
+            }
+        }
+        __syncthreads();
+    }
+    axpy2_dot_body<T, BLOCK, VEC, 0>(n, d, x, q, rv, ld, alpha_s, partials, red);
 }
 
 template <typename T, int BLOCK, bool VEC>
@@ -1795,6 +1834,21 @@ static int axpy2_impl(int n, const void *d, void *x, const void *q, void *r, lon
     else if (vec) hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
     else hipLaunchKernelGGL((axpy2_dot_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
     return check_launch("axpy2_dot");
+}
+template <typename T>
+static int axpy2_alpha_impl(int n, const void *d, void *x, const void *q, void *r, long long ld, const void *part_dq, int P,
+                            const CgScalars &sc, int nrhs, void *partials, int grid, bool vec, hipStream_t st) {
+    dim3 g(grid, nrhs), blk(kBlock);
+    using A = typename VT<T>::acc;
+    if (vec) hipLaunchKernelGGL((axpy2_dot_alpha_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const A *)part_dq, P, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
+    else hipLaunchKernelGGL((axpy2_dot_alpha_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const A *)part_dq, P, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
+    return check_launch("axpy2_dot_alpha");
+}
+bool fold_alpha_ok(int n_partials) { return g_tune.fold_alpha != 0 && n_partials <= kFoldAlphaMax; }
+int launch_axpy2_dot_alpha(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *part_dq,
+                           int P, const CgScalars &sc, int nrhs, void *partials, int grid, hipStream_t st) {
+    const bool vec = vec_ok(dtype, ld, nrhs, {d, x, q, r});
+    CG_DISPATCH(dtype, axpy2_alpha_impl, n, d, x, q, r, ld, part_dq, P, sc, nrhs, partials, grid, vec, st);
 }
 int launch_axpy2_dot(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *alpha,
                      int nrhs, void *partials, int grid, hipStream_t st, int vec_nt) {

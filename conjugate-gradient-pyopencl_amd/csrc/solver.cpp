@@ -77,8 +77,13 @@ static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
     }
     if (!(s->flags & CGAMD_UNFUSED)) {
         if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
-        if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
-        if ((rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt))) return rc;
+        if (fold_alpha_ok(s->plan.n_partials)) {      // small system: three launches
+            if ((rc = launch_axpy2_dot_alpha(dt, n, s->d, s->x, s->q, s->r, n, s->part_dq, s->plan.n_partials, s->sc, nr, s->part_rr,
+                                             s->vgrid, st))) return rc;
+        } else {
+            if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
+            if ((rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt))) return rc;
+        }
         return launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
     }
     if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, nullptr, nullptr, st))) return rc;
