@@ -34,6 +34,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmv_cycle") g_tune.spmv_cycle = value;
     else if (k == "spmv_ilv") g_tune.spmv_ilv = value;
     else if (k == "fold_alpha") g_tune.fold_alpha = value;
+    else if (k == "defer_x") g_tune.defer_x = value;
     else if (k == "alpha_two_level") g_tune.alpha_two_level = value;
     else if (k == "spmv_unroll") g_tune.spmv_unroll = value;
     else if (k == "spmm_rb") g_tune.spmm_rb = value;

@@ -59,6 +59,7 @@ struct Tuning {
     int spmv_policy = -1;   // experiment: >= 0 = matrix stream via buffer loads with this cache-policy aux field
     int spmv_lds_pad = 0;   // experiment: extra dynamic LDS bytes per work-group (lowers occupancy)
     int alpha_two_level = 1; // cg_alpha over >= 16384 partials: 32 work-groups + last-arrival combine (0 = one work-group)
+    int defer_x = 1;        // fused loop: x += alpha d rides in the aypx launch (10 vector passes per iteration instead of 11)
     int fold_alpha = 1;     // small systems (<= 2048 d.q partials): alpha in the prologue of axpy2_dot, three launches per iteration
     int spmv_ilv = -1;      // slice staging: value stream interleaved across lanes in 16-byte chunks (1), quads per lane (0), -1 auto
     int spmv_cycle = 64;    // row-block schedule: block-cyclic over the XCDs, cycle length in row blocks (1 = contiguous eighths)
@@ -100,6 +101,13 @@ struct CgScalars {
     void *stage = nullptr;     // optional, two-level cg_alpha: acc[nrhs][32] part sums
     unsigned *ticket = nullptr;   //          and one zero-initialised ticket counter per RHS
 };
+// ten-vector-pass iteration (x update deferred into the aypx launch): see kernels.hip
+int launch_axpy_dot(int dtype, int n, const void *q, void *r, long long ld, const void *alpha, int nrhs, void *partials, int grid,
+                    hipStream_t st, int vec_nt = 3);
+int launch_axpy_dot_alpha(int dtype, int n, const void *q, void *r, long long ld, const void *part_dq, int P, const CgScalars &sc,
+                          int nrhs, void *partials, int grid, hipStream_t st);
+int launch_aypx_beta_x(int dtype, int n, const void *x, void *y, void *xs, long long ld, const void *partials, int P, int nrhs,
+                       const CgScalars &sc, hipStream_t st, int vec_nt = 3);
 // small systems: alpha = delta / sum(part_dq) in the prologue (three-launch iteration); fold_alpha_ok says when
 bool fold_alpha_ok(int n_partials);
 int launch_axpy2_dot_alpha(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *part_dq,
@@ -152,8 +160,9 @@ int launch_spmv_p2p(int dtype, const SpmvPlan &plan, int n, long long nnz, const
                     const void *d_ext, void *q, void *partials, const int *halo_flag, int rotate, const P2pExchange &e,
                     hipStream_t st);
 int spmv_p2p_grid(const SpmvPlan &plan);
-int launch_aypx_beta_p2p(int dtype, int n, const void *x, void *y, const void *partials, int P, char *const *mailbox, int rank,
-                         int nranks, int which, const unsigned long long *epoch, const CgScalars &sc, hipStream_t st);
+int launch_aypx_beta_p2p(int dtype, int n, const void *x, void *y, void *xs, const void *partials, int P, char *const *mailbox,
+                         int rank, int nranks, int which, const unsigned long long *epoch, const CgScalars &sc, hipStream_t st,
+                         int vec_nt = 0);
 int launch_p2p_exchange(int dtype, const P2pExchange &e, void *v_ext, hipStream_t st);
 // global sum (rank order) of the local sum of `partials`, followed in the same launch by the scalar step that consumes
 // it: mode 1 = cg_delta0, 2 = cg_alpha, 3 = cg_beta; which in {0,1} selects the slot set

@@ -179,14 +179,14 @@ static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
     const long long ldx = (long long)d->n_local + d->n_halo;
     int rc;
     if (d->direct && d->p2p_attached) {
-        // peer-to-peer, four launches: [push | wait | SpMV | d.q], [all-reduce d.q, alpha], [axpy x2 + r.r], [all-reduce r.r, beta, aypx]
+        // peer-to-peer, four launches: [push | wait | SpMV | d.q], [all-reduce d.q, alpha], [r -= alpha q, r.r], [all-reduce r.r, beta, x += alpha d, aypx]
         if ((rc = launch_spmv_p2p(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, d->q, d->part_dq, d->halo_flag,
                                   d->rotate, d->xch, st))) return rc;
         if ((rc = launch_p2p_allreduce(dt, 2, d->part_dq, d->plan.n_partials, d->mailbox_dev, d->rank, d->nranks, 0, d->epochs + 1,
                                        d->sc, st, d->epochs, d->epochs + 2))) return rc;
-        if ((rc = launch_axpy2_dot(dt, n, d->d_ext, d->x, d->q, d->r, n, d->sc.alpha, 1, d->part_rr, d->vgrid, st, d->plan.vec_nt))) return rc;
-        return launch_aypx_beta_p2p(dt, n, d->r, d->d_ext, d->part_rr, d->vgrid, d->mailbox_dev, d->rank, d->nranks, 1,
-                                    d->epochs + 2, d->sc, st);
+        if ((rc = launch_axpy_dot(dt, n, d->q, d->r, n, d->sc.alpha, 1, d->part_rr, d->vgrid, st, d->plan.vec_nt))) return rc;
+        return launch_aypx_beta_p2p(dt, n, d->r, d->d_ext, d->x, d->part_rr, d->vgrid, d->mailbox_dev, d->rank, d->nranks, 1,
+                                    d->epochs + 2, d->sc, st, d->plan.vec_nt);
     }
     if (d->overlap) {
         // fork: the exchange runs on the comm stream while the row blocks that reference no halo column are

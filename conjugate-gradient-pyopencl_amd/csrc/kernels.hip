@@ -751,6 +751,79 @@ __global__ __launch_bounds__(BLOCK) void axpy2_dot_alpha_kernel(int n, const T *
     axpy2_dot_body<T, BLOCK, VEC, 0>(n, d, x, q, rv, ld, alpha_s, partials, red);
 }
 
+// ---- ten-vector-pass iteration -------------------------------------------------------------------------------
+// x is read by nothing inside the loop, so x += alpha d may ride in the aypx launch, which reads d anyway:
+//   axpy_dot_kernel      r -= alpha q, partials of r.r                      reads q, r    writes r      3 NV
+//   aypx_beta_x_kernel   beta in the prologue; x += alpha d; d = beta d + r reads r, d, x writes d, x   5 NV
+// instead of 6 NV + 3 NV: d is read once per iteration, not twice (fused minimum 10 NV + SpMV).  Every element sees the
+// same operations in the same order as before, so x is bit-identical.
+template <typename T, int BLOCK, bool VEC, int VNT>
+CG_DEV void axpy_dot_body(int n, const T *__restrict__ q, T *__restrict__ rv, long long ld, T al,
+                          typename VT<T>::acc *__restrict__ partials, typename VT<T>::acc *red) {
+    using A = typename VT<T>::acc;
+    const int r = blockIdx.y;
+    q += (long long)r * ld; rv += (long long)r * ld;
+    A acc = vzero<A>();
+    constexpr int E = Pack<T>::N;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (VEC) {
+        const long long npack = n / E;
+        for (long long i = i0; i < npack; i += stride) {
+            const Pack<T> pq = (VNT & 2) ? ld_pack_nt(q + i * E) : ld_pack(q + i * E);
+            Pack<T> pr = ld_pack(rv + i * E);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                pr.v[k] = vsub(pr.v[k], vmul(al, pq.v[k]));
+                acc = vadd(acc, to_acc(vmul(pr.v[k], pr.v[k])));
+            }
+            st_pack(rv + i * E, pr);
+        }
+        i0 += npack * E;
+    }
+    for (long long i = i0; i < n; i += stride) {
+        const T rn = vsub(rv[i], vmul(al, q[i]));
+        rv[i] = rn;
+        acc = vadd(acc, to_acc(vmul(rn, rn)));
+    }
+    const A tot = block_sum<BLOCK>(acc, red);
+    if (threadIdx.x == 0) partials[(long long)r * gridDim.x + blockIdx.x] = tot;
+}
+template <typename T, int BLOCK, bool VEC, int VNT = 0>
+__global__ __launch_bounds__(BLOCK) void axpy_dot_kernel(int n, const T *__restrict__ q, T *__restrict__ rv, long long ld,
+                                                         const T *__restrict__ alpha, typename VT<T>::acc *__restrict__ partials) {
+    __shared__ typename VT<T>::acc red[BLOCK / kWave];
+    axpy_dot_body<T, BLOCK, VEC, VNT>(n, q, rv, ld, alpha[blockIdx.y], partials, red);
+}
+// small systems: alpha in the prologue (see axpy2_dot_alpha_kernel)
+template <typename T, int BLOCK, bool VEC>
+__global__ __launch_bounds__(BLOCK) void axpy_dot_alpha_kernel(int n, const T *__restrict__ q, T *__restrict__ rv, long long ld,
+                                                               const typename VT<T>::acc *__restrict__ part_dq, int P,
+                                                               const T *__restrict__ delta, T *alpha, int *iter,
+                                                               typename VT<T>::acc *__restrict__ partials) {
+    using A = typename VT<T>::acc;
+    __shared__ A red[BLOCK / kWave];
+    __shared__ T alpha_s;
+    const int r = blockIdx.y;
+    {
+        A acc = vzero<A>();
+        const A *p = part_dq + (long long)r * P;
+        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, p[i]);
+        const A dq = block_sum<BLOCK>(acc, red);
+        if (threadIdx.x == 0) {
+            const T dqT = from_acc<T>(dq);
+            const T al = from_acc<T>(acc_div(to_acc(delta[r]), to_acc(dqT)));
+            alpha_s = al;
+            if (blockIdx.x == 0) {
+                alpha[r] = al;
+                if (r == 0) *iter = *iter + 1;
+            }
+        }
+        __syncthreads();
+    }
+    axpy_dot_body<T, BLOCK, VEC, 0>(n, q, rv, ld, alpha_s, partials, red);
+}
+
 template <typename T, int BLOCK, bool VEC>
 __global__ __launch_bounds__(BLOCK) void dot_partials_kernel(int n, const T *__restrict__ a, const T *__restrict__ b,
                                                              long long ld, typename VT<T>::acc *__restrict__ partials) {
@@ -860,6 +933,63 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_kernel(int n, const T *__rest
         i0 += npack * E;
     }
     for (long long i = i0; i < n; i += stride) y[i] = vadd(vmul(al, y[i]), x[i]);
+}
+
+// the same with the deferred x += alpha d (ten-vector-pass iteration): xs = solution vector, alpha of THIS iteration
+template <typename T, int BLOCK, bool VEC, int VNT>
+__global__ __launch_bounds__(BLOCK) void aypx_beta_x_kernel(int n, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ xs,
+                                                            long long ld, const typename VT<T>::acc *__restrict__ partials, int P,
+                                                            int nrhs, const T *__restrict__ alpha, T *delta, T *beta, T *history,
+                                                            const int *iter) {
+    using A = typename VT<T>::acc;
+    __shared__ A red[BLOCK / kWave];
+    __shared__ T beta_s;
+    const int r = blockIdx.y;
+    {
+        A acc = vzero<A>();
+        const A *p = partials + (long long)r * P;
+        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, p[i]);
+        const A tot = block_sum<BLOCK>(acc, red);
+        if (threadIdx.x == 0) {
+            const int it = *iter;
+            const T dnT = from_acc<T>(tot);
+            const T dold = history[(long long)(it - 1) * nrhs + r];
+            const T b = from_acc<T>(acc_div(to_acc(dnT), to_acc(dold)));
+            beta_s = b;
+            if (blockIdx.x == 0) {
+                beta[r] = b;
+                delta[r] = dnT;
+                history[(long long)it * nrhs + r] = dnT;
+            }
+        }
+        __syncthreads();
+    }
+    const T bt = beta_s, al = alpha[r];
+    x += (long long)r * ld; y += (long long)r * ld; xs += (long long)r * ld;
+    constexpr int E = Pack<T>::N;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (VEC) {
+        const long long npack = n / E;
+        for (long long i = i0; i < npack; i += stride) {
+            const Pack<T> px = ld_pack(x + i * E);
+            Pack<T> py = ld_pack(y + i * E);
+            Pack<T> ps = (VNT & 1) ? ld_pack_nt(xs + i * E) : ld_pack(xs + i * E);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                ps.v[k] = vadd(ps.v[k], vmul(al, py.v[k]));
+                py.v[k] = vadd(vmul(bt, py.v[k]), px.v[k]);
+            }
+            if (VNT & 1) st_pack_nt(xs + i * E, ps); else st_pack(xs + i * E, ps);
+            st_pack(y + i * E, py);
+        }
+        i0 += npack * E;
+    }
+    for (long long i = i0; i < n; i += stride) {
+        const T dv = y[i];
+        xs[i] = vadd(xs[i], vmul(al, dv));
+        y[i] = vadd(vmul(bt, dv), x[i]);
+    }
 }
 
 // =================================================================================================
@@ -1279,7 +1409,8 @@ template <typename T> __global__ __launch_bounds__(kP2pBlock) void p2p_wait_unpa
 // -------------------------------------------------------------------------------------------------
 // Peer-to-peer CG iteration in four launches (same count as the single-GPU loop):
 //   spmv_rowblock_p2p_kernel : push + wait + SpMV + d.q partials     p2p_allreduce_kernel<2>: alpha (bumps the epochs)
-//   axpy2_dot_kernel         : unchanged                              aypx_beta_p2p_kernel  : all-reduce of r.r + beta + aypx
+//   axpy_dot_kernel          : r -= alpha q, r.r partials             aypx_beta_p2p_kernel  : all-reduce of r.r + beta,
+//                                                                                            x += alpha d, d = beta d + r
 // spmv_rowblock_p2p_kernel = spmv_rowblock_kernel (same block-cyclic XCD schedule, rotated so that the leading boundary
 // row blocks of a slab partition are visited last) plus a per-row-block flag "references a halo column", where
 //   * the first n_peers * push_chunks work-groups first ship one chunk of my boundary entries of d into the peers'
@@ -1388,8 +1519,9 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T>
 // its own mailbox and adds them in rank order (bitwise the same beta everywhere).  The epoch was advanced by the alpha
 // kernel of this iteration, so it is read-only here; slots are safe to reuse because a peer can only publish its next
 // value after it has seen my next d.q, which I publish after this launch has completed.
-template <typename T, int BLOCK, bool VEC>
-__global__ __launch_bounds__(BLOCK) void aypx_beta_p2p_kernel(int n, const T *x, T *y, const typename VT<T>::acc *partials, int P,
+template <typename T, int BLOCK, bool VEC, int VNT = 0>
+__global__ __launch_bounds__(BLOCK) void aypx_beta_p2p_kernel(int n, const T *x, T *y, T *xs, const T *alpha,
+                                                              const typename VT<T>::acc *partials, int P,
                                                               char *const *mailbox, int rank, int nranks, int which,
                                                               const unsigned long long *epoch, T *delta, T *beta, T *history,
                                                               int history_cap, const int *iter) {
@@ -1436,7 +1568,8 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_p2p_kernel(int n, const T *x,
         }
     }
     __syncthreads();
-    const T al = beta_s;
+    // deferred x += alpha d of this iteration rides along (ten-vector-pass iteration, see aypx_beta_x_kernel)
+    const T bt = beta_s, al = alpha[0];
     constexpr int E = Pack<T>::N;
     const long long stride = (long long)gridDim.x * BLOCK;
     long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -1444,14 +1577,22 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_p2p_kernel(int n, const T *x,
         const long long npack = n / E;
         for (long long i = i0; i < npack; i += stride) {
             const Pack<T> px = ld_pack(x + i * E);
-            Pack<T> py = ld_pack(y + i * E);
+            Pack<T> py = ld_pack(y + i * E), ps = (VNT & 1) ? ld_pack_nt(xs + i * E) : ld_pack(xs + i * E);
 #pragma unroll
-            for (int k = 0; k < E; ++k) py.v[k] = vadd(vmul(al, py.v[k]), px.v[k]);
+            for (int k = 0; k < E; ++k) {
+                ps.v[k] = vadd(ps.v[k], vmul(al, py.v[k]));
+                py.v[k] = vadd(vmul(bt, py.v[k]), px.v[k]);
+            }
+            if (VNT & 1) st_pack_nt(xs + i * E, ps); else st_pack(xs + i * E, ps);
             st_pack(y + i * E, py);
         }
         i0 += npack * E;
     }
-    for (long long i = i0; i < n; i += stride) y[i] = vadd(vmul(al, y[i]), x[i]);
+    for (long long i = i0; i < n; i += stride) {
+        const T dv = y[i];
+        xs[i] = vadd(xs[i], vmul(al, dv));
+        y[i] = vadd(vmul(bt, dv), x[i]);
+    }
 }
 
 // local partials -> sum over all ranks, in rank order on every rank (bitwise identical everywhere):
@@ -1844,6 +1985,54 @@ static int axpy2_alpha_impl(int n, const void *d, void *x, const void *q, void *
     else hipLaunchKernelGGL((axpy2_dot_alpha_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const A *)part_dq, P, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
     return check_launch("axpy2_dot_alpha");
 }
+template <typename T>
+static int axpy_dot_impl(int n, const void *q, void *r, long long ld, const void *alpha, int nrhs, void *partials, int grid, bool vec,
+                         int vnt, hipStream_t st) {
+    dim3 g(grid, nrhs), blk(kBlock);
+    auto *pp = static_cast<typename VT<T>::acc *>(partials);
+    if (vec && (vnt & 2)) hipLaunchKernelGGL((axpy_dot_kernel<T, kBlock, true, 2>), g, blk, 0, st, n, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    else if (vec) hipLaunchKernelGGL((axpy_dot_kernel<T, kBlock, true, 0>), g, blk, 0, st, n, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    else hipLaunchKernelGGL((axpy_dot_kernel<T, kBlock, false, 0>), g, blk, 0, st, n, (const T *)q, (T *)r, ld, (const T *)alpha, pp);
+    return check_launch("axpy_dot");
+}
+int launch_axpy_dot(int dtype, int n, const void *q, void *r, long long ld, const void *alpha, int nrhs, void *partials, int grid,
+                    hipStream_t st, int vec_nt) {
+    const bool vec = vec_ok(dtype, ld, nrhs, {q, r});
+    const int vnt = g_tune.vec_nt >= 0 ? g_tune.vec_nt : vec_nt;
+    CG_DISPATCH(dtype, axpy_dot_impl, n, q, r, ld, alpha, nrhs, partials, grid, vec, vnt, st);
+}
+template <typename T>
+static int axpy_dot_alpha_impl(int n, const void *q, void *r, long long ld, const void *part_dq, int P, const CgScalars &sc, int nrhs,
+                               void *partials, int grid, bool vec, hipStream_t st) {
+    dim3 g(grid, nrhs), blk(kBlock);
+    using A = typename VT<T>::acc;
+    if (vec) hipLaunchKernelGGL((axpy_dot_alpha_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)q, (T *)r, ld, (const A *)part_dq, P, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
+    else hipLaunchKernelGGL((axpy_dot_alpha_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)q, (T *)r, ld, (const A *)part_dq, P, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
+    return check_launch("axpy_dot_alpha");
+}
+int launch_axpy_dot_alpha(int dtype, int n, const void *q, void *r, long long ld, const void *part_dq, int P, const CgScalars &sc,
+                          int nrhs, void *partials, int grid, hipStream_t st) {
+    const bool vec = vec_ok(dtype, ld, nrhs, {q, r});
+    CG_DISPATCH(dtype, axpy_dot_alpha_impl, n, q, r, ld, part_dq, P, sc, nrhs, partials, grid, vec, st);
+}
+template <typename T>
+static int aypx_beta_x_impl(int n, const void *x, void *y, void *xs, long long ld, const void *partials, int P, int nrhs,
+                            const CgScalars &sc, bool vec, int vnt, hipStream_t st) {
+    dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
+    auto *pp = static_cast<const typename VT<T>::acc *>(partials);
+#define CG_AX(V, N) hipLaunchKernelGGL((aypx_beta_x_kernel<T, kBlock, V, N>), g, blk, 0, st, n, (const T *)x, (T *)y, (T *)xs, ld, pp, P, nrhs, \
+                                       (const T *)sc.alpha, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, (const int *)sc.iter)
+    if (vec && (vnt & 1)) CG_AX(true, 1); else if (vec) CG_AX(true, 0); else CG_AX(false, 0);
+#undef CG_AX
+    return check_launch("aypx_beta_x");
+}
+int launch_aypx_beta_x(int dtype, int n, const void *x, void *y, void *xs, long long ld, const void *partials, int P, int nrhs,
+                       const CgScalars &sc, hipStream_t st, int vec_nt) {
+    if (n <= 0) return CGAMD_OK;
+    const bool v = vec_ok(dtype, ld, nrhs, {x, y, xs});
+    const int vnt = g_tune.vec_nt >= 0 ? g_tune.vec_nt : vec_nt;
+    CG_DISPATCH(dtype, aypx_beta_x_impl, n, x, y, xs, ld, partials, P, nrhs, sc, v, vnt, st);
+}
 bool fold_alpha_ok(int n_partials) { return g_tune.fold_alpha != 0 && n_partials <= kFoldAlphaMax; }
 int launch_axpy2_dot_alpha(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *part_dq,
                            int P, const CgScalars &sc, int nrhs, void *partials, int grid, hipStream_t st) {
@@ -2064,20 +2253,23 @@ int launch_spmv_p2p(int dtype, const SpmvPlan &plan, int n, long long nnz, const
 int spmv_p2p_grid(const SpmvPlan &plan) { return rowblock_grid(plan.row_blocks, g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1); }
 
 template <typename T>
-static int aypx_beta_p2p_impl(int n, const void *x, void *y, const void *partials, int P, char *const *mailbox, int rank,
-                              int nranks, int which, const unsigned long long *epoch, const CgScalars &sc, bool vec, hipStream_t st) {
+static int aypx_beta_p2p_impl(int n, const void *x, void *y, void *xs, const void *partials, int P, char *const *mailbox, int rank,
+                              int nranks, int which, const unsigned long long *epoch, const CgScalars &sc, bool vec, int vnt, hipStream_t st) {
     dim3 g(vec_grid(n, VT<T>::dtype)), blk(kBlock);
     auto *pp = static_cast<const typename VT<T>::acc *>(partials);
-    if (vec) hipLaunchKernelGGL((aypx_beta_p2p_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)x, (T *)y, pp, P, mailbox, rank, nranks, which, epoch, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (const int *)sc.iter);
-    else hipLaunchKernelGGL((aypx_beta_p2p_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)x, (T *)y, pp, P, mailbox, rank, nranks, which, epoch, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (const int *)sc.iter);
+    if (vec && (vnt & 1)) hipLaunchKernelGGL((aypx_beta_p2p_kernel<T, kBlock, true, 1>), g, blk, 0, st, n, (const T *)x, (T *)y, (T *)xs, (const T *)sc.alpha, pp, P, mailbox, rank, nranks, which, epoch, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (const int *)sc.iter);
+    else if (vec) hipLaunchKernelGGL((aypx_beta_p2p_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)x, (T *)y, (T *)xs, (const T *)sc.alpha, pp, P, mailbox, rank, nranks, which, epoch, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (const int *)sc.iter);
+    else hipLaunchKernelGGL((aypx_beta_p2p_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)x, (T *)y, (T *)xs, (const T *)sc.alpha, pp, P, mailbox, rank, nranks, which, epoch, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (const int *)sc.iter);
     return check_launch("aypx_beta_p2p");
 }
-int launch_aypx_beta_p2p(int dtype, int n, const void *x, void *y, const void *partials, int P, char *const *mailbox, int rank,
-                         int nranks, int which, const unsigned long long *epoch, const CgScalars &sc, hipStream_t st) {
+int launch_aypx_beta_p2p(int dtype, int n, const void *x, void *y, void *xs, const void *partials, int P, char *const *mailbox,
+                         int rank, int nranks, int which, const unsigned long long *epoch, const CgScalars &sc, hipStream_t st,
+                         int vec_nt) {
     if (n <= 0) return CGAMD_OK;
     if (nranks > 64) return fail(CGAMD_ERR_INVALID, "p2p all-reduce: at most 64 ranks");
-    const bool v = vec_ok(dtype, n, 1, {x, y});
-    CG_DISPATCH(dtype, aypx_beta_p2p_impl, n, x, y, partials, P, mailbox, rank, nranks, which, epoch, sc, v, st);
+    const bool v = vec_ok(dtype, n, 1, {x, y, xs});
+    const int vnt = g_tune.vec_nt >= 0 ? g_tune.vec_nt : vec_nt;
+    CG_DISPATCH(dtype, aypx_beta_p2p_impl, n, x, y, xs, partials, P, mailbox, rank, nranks, which, epoch, sc, v, vnt, st);
 }
 
 template <typename T> static int p2p_exchange_impl(const P2pExchange &e, void *v_ext, hipStream_t st) {

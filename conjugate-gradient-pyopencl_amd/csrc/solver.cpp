@@ -37,6 +37,7 @@ struct cgamd_solver {
     hipGraph_t g1g = nullptr, gUg = nullptr;
     int U = 8;
     bool graph_failed = false;
+    bool defer_x = true;    // x += alpha d in the aypx launch (fixed at creation: captured graphs depend on it)
 };
 
 static void destroy_graphs(cgamd_solver *s) {
@@ -77,13 +78,17 @@ static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
     }
     if (!(s->flags & CGAMD_UNFUSED)) {
         if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
-        if (fold_alpha_ok(s->plan.n_partials)) {      // small system: three launches
-            if ((rc = launch_axpy2_dot_alpha(dt, n, s->d, s->x, s->q, s->r, n, s->part_dq, s->plan.n_partials, s->sc, nr, s->part_rr,
-                                             s->vgrid, st))) return rc;
-        } else {
-            if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
-            if ((rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt))) return rc;
+        const bool fold = fold_alpha_ok(s->plan.n_partials);      // small system: alpha in the next launch's prologue
+        if (!fold && (rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
+        if (s->defer_x) {     // r -= alpha q (+ r.r) ; then beta, x += alpha d, d = beta d + r : 3 + 5 vector passes
+            if (fold) rc = launch_axpy_dot_alpha(dt, n, s->q, s->r, n, s->part_dq, s->plan.n_partials, s->sc, nr, s->part_rr, s->vgrid, st);
+            else rc = launch_axpy_dot(dt, n, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
+            if (rc) return rc;
+            return launch_aypx_beta_x(dt, n, s->r, s->d, s->x, n, s->part_rr, s->vgrid, nr, s->sc, st, s->plan.vec_nt);
         }
+        if (fold) rc = launch_axpy2_dot_alpha(dt, n, s->d, s->x, s->q, s->r, n, s->part_dq, s->plan.n_partials, s->sc, nr, s->part_rr, s->vgrid, st);
+        else rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
+        if (rc) return rc;
         return launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
     }
     if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, nullptr, nullptr, st))) return rc;
@@ -144,6 +149,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     s->ctx = ctx; s->dtype = dtype; s->n = size; s->nnz = nnz; s->nrhs = nRHS; s->flags = flags;
     s->plan = make_spmv_plan(size);
     s->vgrid = vec_grid(size, dtype);
+    s->defer_x = g_tune.defer_x != 0;
     int rc = CGAMD_OK;
     if (flags & CGAMD_MATRIX_ON_DEVICE) {
         s->vals = const_cast<void *>(aValues);
@@ -320,8 +326,13 @@ int cgamd_solver_iterate_timed(cgamd_solver *s, int nIterations, float *spmv_ms_
         rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st);
         CG_HIP(hipEventRecord(ev[(size_t)2 * i + 1], st));
         if (!rc) rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st);
-        if (!rc) rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
-        if (!rc) rc = launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
+        if (s->defer_x) {
+            if (!rc) rc = launch_axpy_dot(dt, n, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
+            if (!rc) rc = launch_aypx_beta_x(dt, n, s->r, s->d, s->x, n, s->part_rr, s->vgrid, nr, s->sc, st, s->plan.vec_nt);
+        } else {
+            if (!rc) rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
+            if (!rc) rc = launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
+        }
     }
     CG_HIP(hipEventRecord(ev[(size_t)2 * nIterations + 1], st));
     CG_HIP(hipStreamSynchronize(st));

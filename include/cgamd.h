@@ -138,7 +138,8 @@ int cgamd_solver_spmv(cgamd_solver *s, const void *x, void *y, int fused_dot);
  * out[c*rows + r] = in[r*cols + c]. */
 int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS);
 int cgamd_transpose(cgamd_ctx *ctx, int dtype, int rows, int cols, const void *in, void *out);
-/* algorithmic HBM bytes of one SpMV / one CG iteration of this solver (SURVEY §8d formulae) */
+/* algorithmic HBM bytes of one SpMV / one CG iteration of this solver (SURVEY §8d formulae: 14 vector passes for the
+ * reference's op structure, 11 for its "fused minimum"; the default loop here moves 10) */
 long long cgamd_solver_spmv_bytes(cgamd_solver *s);
 long long cgamd_solver_iter_bytes(cgamd_solver *s, int fused);
 
