@@ -7,7 +7,8 @@ A "step" is one CG iteration (the reference's loop body, clcg.c:297-419) on the 
 250x200x200 (N=10 000 000, nnz=69 720 000, fp64), matrix and vectors resident in HBM before the timed
 region.  With N>1 ranks the SAME system is row-partitioned into N contiguous z-slabs (strong scaling, as the
 north star asks: "iterations/sec at 8 GPUs vs 1 GPU on the 10M-row system"): neighbour halo exchange +
-2 scalar all-reduces per iteration over RCCL.
+2 scalar all-reduces per iteration, by peer-to-peer mailbox writes over xGMI inside the iteration's four kernel launches
+(RCCL send/recv + all-reduce as the fallback); every candidate loop is validated against the single-GPU residual history.
 Prints ONE JSON line on rank 0.
 """
 import argparse
