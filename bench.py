@@ -192,6 +192,9 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
         spmv_ms = spmv_alone_ms
     spmv_gbs = spmv_bytes / (spmv_ms * 1e-3) / 1e9
 
+    V = np.dtype(dtype).itemsize
+    passes = 14 if args.unfused else 10      # SpMV 2 + r update 3 + (beta, x update, aypx) 5; see DESIGN.md section 4
+    moved_bytes = nnz * (V + 4) + (n + 1) * 4 + passes * n * V
     delta0, deltak = abs(hist[0, 0]), abs(hist[-1, 0])
     res = {
         "metric": "CG iterations/sec + SpMV effective HBM GB/s (% of 8 TB/s peak), N=10M CSR",
@@ -206,6 +209,9 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
         "spmv_back_to_back_pct_of_8tbs": 100.0 * spmv_bytes / (spmv_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "cg_iter_algorithmic_gbs": iter_bytes * it_s / 1e9,
         "cg_iter_pct_of_8tbs": 100.0 * iter_bytes * it_s / 1e9 / HBM_PEAK_GBS,
+        # the byte model above is the reference's op structure (14 vector passes); the loop that ran moves fewer:
+        "cg_iter_moved_bytes": moved_bytes,
+        "cg_iter_moved_pct_of_8tbs": 100.0 * moved_bytes * it_s / 1e9 / HBM_PEAK_GBS,
         "residual_check": {"delta_0": float(delta0), "delta_last": float(deltak), "iterations": int(hist.shape[0] - 1)},
         "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel (CSR SpMV fused with d.q partials), in-loop average over the instrumented pass",
                      "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
