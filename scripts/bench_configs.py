@@ -104,6 +104,31 @@ if "c4" in which or "c4mfma" in which:
             print(json.dumps({"config": f"C4 SpMM MFMA row-major nrhs={nrhs} N=1M {nm}", "spmm_us": us, "spmm_gbs": sb / us / 1e3,
                               "spmm_pct_of_8tbs": 100 * sb / us / 1e3 / 8000}), flush=True)
         s.close()
+if "report" in which:
+    # context only: the one matrix of the upstream report that can be regenerated offline --
+    # helm_fem: complex, n = 16 384, nnz = 113 666 = helmFE_var(N=128); the report ran 5000 iterations in fp32 complex and
+    # counts 8 nnz + 40 n flops per iteration (its Table II): 2.390 GFLOPS on an RTX 2080S, 0.351 on an i5-8250U
+    import cg_numpy
+    N = 128
+    hp, hx, hd = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    ip, ix = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
+    da = torch.from_numpy(hd.astype(np.complex64)).to(dev)
+    n, nnz = N * N, len(hx)
+    s = pkg.Solver(ctx, n, nnz, da, ip, ix, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=np.complex64)
+    b = torch.full((n,), 5.0, dtype=torch.complex64, device=dev)
+    torch.cuda.synchronize()
+    s.set_rhs(b, None, on_device=True)
+    s.iterate(200)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    s.iterate(5000)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    flops = 8 * nnz + 40 * n
+    print(json.dumps({"config": "report helm_fem equivalent: helmFE_var(128) c64, n=16384, nnz=%d, 5000 iterations" % nnz,
+                      "cg_it_per_s": 5000 / dt, "us_per_iter": dt / 5000 * 1e6, "gflops_report_model": flops * 5000 / dt / 1e9,
+                      "published_2080S_gflops": 2.390}), flush=True)
+    s.close()
 if "m32" in which:
     ip, ix, da = pkg.generators.laplace3d(ctx, 250, 200, 200, dtype=np.float32)
     run("M 3D 7-pt N=10M f32", ip, ix, da, np.float32, 1)
