@@ -50,10 +50,13 @@ const char *cgamd_last_error(void);
 int cgamd_version(void);
 size_t cgamd_dtype_size(int dtype);
 
-/* run-time tuning knobs (A/B experiments and profiling): "spmv_variant" (5 = row-block kernel, default;
- * 0 = generic chunked kernel), "spmv_nt" (non-temporal matrix loads, default 1), "spmv_cycle" (row-block
- * schedule: block-cyclic over the 8 XCDs with this cycle length in row blocks, default 64; 1 = contiguous eighths), "spmv_grid" / "vec_grid" (0 = auto).  Read when a solver is created
- * (variant, grids) or at launch (nt, cycle). */
+/* run-time tuning knobs (A/B experiments and profiling; the defaults are the shipped configuration, -1 = decided per
+ * solver): "spmv_variant" (5 = row-block kernel, 0 = generic chunked kernel), "spmv_nt" / "vec_nt" (non-temporal matrix
+ * stream / streaming hints of the vector kernels, default -1: by working-set size), "spmv_ilv" (slice staging interleaved
+ * across lanes, default on), "spmv_cycle" (block-cyclic schedule over the 8 XCDs, cycle length in row blocks, default
+ * 64), "spmv_unroll", "alpha_two_level", "fold_alpha" (alpha in the prologue of the r update for small systems),
+ * "defer_x" (x += alpha d in the aypx launch), "spmv_grid" / "vec_grid" (0 = auto).  Read when a solver is created or
+ * at launch; not synchronised with running solvers. */
 int cgamd_tune(const char *key, int value);
 
 /* ---- devices / context (reference cl.py:16-31) -------------------------- */
