@@ -35,15 +35,19 @@ struct SpmvPlan {
     int grid = 0;        // work-groups launched (multiple of 8 when >= 8)
     int row_blocks = 0;  // ceil(n / kBlock)
     int max_span = 0;    // largest 4-aligned nnz span of a kBlock-row slice (0 = unknown -> generic kernel)
-    int kind = 0;        // kernel chosen by finalize_spmv_plan (0 generic ... 5 row-block)
+    int kind = 0;        // kernel chosen by finalize_spmv_plan (0 generic, 5 row-block, 6 its SpMM form, 7 chunked row-block)
+    int chunk_span[3] = {0, 0, 0};   // largest 4-aligned span of a 128 / 64 / 32-row slice
+    int lpr = 1;         // kind 7: lanes per row (2, 4, 8) = chunks per 256-row block
     int n_partials = 0;  // fused-dot partials per RHS written by that kernel
     int nt = 1;          // matrix stream loaded non-temporally (finalize_spmv_plan: off when the matrix fits the Infinity Cache)
     int vec_nt = 3;      // axpy2_dot streaming hints (see Tuning::vec_nt), resolved by finalize_spmv_plan
 };
 SpmvPlan make_spmv_plan(int n);
-// fills plan->max_span from the matrix structure; synchronises `st`; scratch_dev: >= 4 bytes
+// fills plan->max_span / chunk_span from the matrix structure; synchronises `st`; scratch_dev: >= 16 bytes
 int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan);
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols);
+constexpr int kChunkBytes = 24 * 1024;      // kind 7: preferred LDS chunk slice (6 work-groups per CU)
+constexpr int kMaxChunkBytes = 48 * 1024;   //         largest accepted, with 8 lanes per row (3 work-groups per CU)
 constexpr int kMaxSliceBytes = 64 * 1024;   // variant 5: largest LDS slice accepted (else the generic chunked kernel runs)
 
 // run-time tuning knobs (cgamd_tune); defaults are the shipped configuration
@@ -61,6 +65,8 @@ struct Tuning {
     int alpha_two_level = 1; // cg_alpha over >= 16384 partials: 32 work-groups + last-arrival combine (0 = one work-group)
     int defer_x = 1;        // fused loop: x += alpha d rides in the aypx launch (10 vector passes per iteration instead of 11)
     int fold_alpha = 1;     // small systems (<= 2048 d.q partials): alpha in the prologue of axpy2_dot, three launches per iteration
+    int spmv_chunk_kb = 0;  // chunked row-block kernel: preferred LDS chunk in KB (0 = kChunkBytes); smaller -> more lanes per row
+    int spmv_chunked = 1;   // rows too dense for the row-block kernel: chunked row-block kernel (0 = generic kernel)
     int spmv_ilv = -1;      // slice staging: value stream interleaved across lanes in 16-byte chunks (1), quads per lane (0), -1 auto
     int spmv_cycle = 64;    // row-block schedule: block-cyclic over the XCDs, cycle length in row blocks (1 = contiguous eighths)
     int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)

@@ -464,6 +464,76 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// The same kernel for DENSER rows (a 256-row slice no longer fits LDS: > ~21 non-zeros per row in fp64).  The work-group
+// still owns 256 rows and writes one d.q partial, but stages and walks them in LPR chunks of 256/LPR rows, LPR = 2, 4 or
+// 8 lanes per row: lane l of a row takes entries s+l, s+l+LPR, ... (consecutive lanes -> consecutive entries -> for
+// stencil / FE rows consecutive columns), the LPR partial sums meet in a shuffle tree.  The generic kernel, which these
+// matrices used before, runs the 27-point stencil at 50 % of the HBM roofline.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int LPR, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void spmv_rowblock_chunked_kernel(SpmvArgs<T> a) {
+    using A = typename VT<T>::acc;
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    T *sv = reinterpret_cast<T *>(dyn_smem);
+    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));
+    __shared__ A red[BLOCK / kWave];
+    constexpr int RC = BLOCK / LPR;                 // rows per chunk
+    const int t = threadIdx.x, j = t / LPR, l = t % LPR;
+    const int rb = rowblock_of(blockIdx.x, a.row_blocks, a.cycle);
+    if (rb < 0) return;
+    A dot1 = vzero<A>();
+    for (int c = 0; c < LPR; ++c) {
+        const int c0 = rb * BLOCK + c * RC;
+        if (c0 >= a.n) break;                       // block-uniform
+        const int row = c0 + j;
+        const int rclamp = min(row, a.n - 1);
+        const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
+        const int p0 = a.ptr[c0], p1 = a.ptr[min(c0 + RC, a.n)];
+        const int cfirst = p0 & ~3;
+        if (c) __syncthreads();                     // the previous chunk's walk is over before LDS is overwritten
+        stage_slice<T, BLOCK, NT, -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+        const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
+        __syncthreads();
+        T sum = vzero<T>();
+        for (int k = s + l; k < e; k += UNROLL * LPR) {
+            T xv[UNROLL], av[UNROLL];
+            int cj[UNROLL];
+            const int last = k + ((e - 1 - k) / LPR) * LPR;      // this lane's last valid entry
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int idx = min(k + u * LPR, last);
+                cj[u] = sc[idx];
+                av[u] = sv[idx];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) xv[u] = a.x[cj[u]];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const T nxt = vfma(av[u], xv[u], sum);
+                sum = vsel(k + u * LPR < e, nxt, sum);
+            }
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) {
+            if constexpr (VT<T>::cplx) {
+                sum.x += __shfl_xor(sum.x, off, kWave);
+                sum.y += __shfl_xor(sum.y, off, kWave);
+            } else {
+                sum += __shfl_xor(sum, off, kWave);
+            }
+        }
+        if (l == 0 && row < a.n) {
+            a.y[row] = sum;
+            if (FUSE_DOT) dot1 = vadd(dot1, to_acc(vmul(a.dvec[row], sum)));
+        }
+    }
+    if (FUSE_DOT) {
+        const A tot = block_sum<BLOCK>(dot1, red);
+        if (t == 0) a.partials[rb] = tot;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // SpMM fast path (nRHS > 1, RHS-major vectors as the reference ABI defines them: element i of RHS r at
 // i + r*ld).  Same structure as spmv_rowblock_kernel -- the block's matrix slice goes through LDS ONCE -- and
 // lane t then walks row t for RB right-hand sides at a time, keeping RB row sums in registers:
@@ -659,12 +729,23 @@ template <int BLOCK> __global__ void rowblock_halo_flag_kernel(int n, const int 
 
 // largest (4-aligned) non-zero span of any BLOCK-row slice: decides whether the fast path applies
 template <int BLOCK> __global__ void spmv_span_kernel(int n, const int *__restrict__ ptr, int row_blocks, int *out) {
-    int m = 0;
+    // out[0]: span of BLOCK-row slices; out[1..3]: of BLOCK/2, BLOCK/4, BLOCK/8-row slices (chunked row-block kernel)
+    int m[4] = {0, 0, 0, 0};
     for (int rb = blockIdx.x * blockDim.x + threadIdx.x; rb < row_blocks; rb += gridDim.x * blockDim.x) {
-        const int p0 = ptr[rb * BLOCK], p1 = ptr[min(rb * BLOCK + BLOCK, n)];
-        m = max(m, p1 - (p0 & ~3));
+#pragma unroll
+        for (int lv = 0; lv < 4; ++lv) {
+            const int rows = BLOCK >> lv;
+            for (int c = 0; c < (1 << lv); ++c) {
+                const int ra = rb * BLOCK + c * rows;
+                if (ra >= n) break;
+                const int p0 = ptr[ra], p1 = ptr[min(ra + rows, n)];
+                m[lv] = max(m[lv], p1 - (p0 & ~3));
+            }
+        }
     }
-    if (m > 0) atomicMax(out, m);
+#pragma unroll
+    for (int lv = 0; lv < 4; ++lv)
+        if (m[lv] > 0) atomicMax(out + lv, m[lv]);
 }
 
 // =================================================================================================
@@ -1812,6 +1893,25 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
 #undef CG_RB
         return check_launch("spmv_rowblock");
     }
+    if (vec && nrhs == 1 && plan.kind == 7 && !rb_list) {
+        const int span = plan.chunk_span[plan.lpr == 2 ? 0 : plan.lpr == 4 ? 1 : 2];
+        a.cap = (span + 3) & ~3;
+        a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
+        const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
+        const dim3 g7(rowblock_grid(plan.row_blocks, a.cycle));
+        const bool nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
+        constexpr int U = sizeof(T) > 8 ? 4 : 8;
+#define CG_CH(NT, L)                                                                                                     \
+    do {                                                                                                                  \
+        if (fuse) hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, true, L, U>), g7, block, lds, st, a);   \
+        else hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, false, L, U>), g7, block, lds, st, a);       \
+    } while (0)
+        if (plan.lpr == 2) { if (nt) CG_CH(true, 2); else CG_CH(false, 2); }
+        else if (plan.lpr == 4) { if (nt) CG_CH(true, 4); else CG_CH(false, 4); }
+        else { if (nt) CG_CH(true, 8); else CG_CH(false, 8); }
+#undef CG_CH
+        return check_launch("spmv_rowblock_chunked");
+    }
     if (vec && nrhs > 1 && plan.kind == 6) {
         a.cap = (plan.max_span + 3) & ~3;
         a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
@@ -1853,13 +1953,16 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
 int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan) {
     // (1) largest slice span -> which kernels apply, LDS size
     const int row_blocks = (n + kBlock - 1) / kBlock;
-    CG_HIP(hipMemsetAsync(scratch_dev, 0, sizeof(int), st));
+    CG_HIP(hipMemsetAsync(scratch_dev, 0, 4 * sizeof(int), st));
     int g = (row_blocks + 255) / 256;
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL((spmv_span_kernel<kBlock>), dim3(g), dim3(256), 0, st, n, ptr_dev, row_blocks, scratch_dev);
     if (int rc = check_launch("spmv_span")) return rc;
-    CG_HIP(hipMemcpyAsync(&plan->max_span, scratch_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    int spans[4] = {0, 0, 0, 0};
+    CG_HIP(hipMemcpyAsync(spans, scratch_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     CG_HIP(hipStreamSynchronize(st));
+    plan->max_span = spans[0];
+    for (int lv = 0; lv < 3; ++lv) plan->chunk_span[lv] = spans[lv + 1];
     (void)cols_dev;
     return CGAMD_OK;
 }
@@ -1882,9 +1985,28 @@ void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nn
     int kind = g_tune.spmv_variant;
     const bool vec = aligned16(vals) && aligned16(cols);
     if (!vec || plan->max_span <= 0) kind = 0;
+    plan->lpr = 1;
     if (kind == 5 && (size_t)plan->max_span * (dtype_size(dtype) + 4) + acc_size(dtype) * (size_t)nrhs * (kBlock / 64) >
-                         (size_t)kMaxSliceBytes) kind = 0;
-    if (kind != 5) kind = 0;
+                         (size_t)kMaxSliceBytes) {
+        kind = 0;
+        // denser rows: the chunked form of the row-block kernel (single right-hand side).  Smallest LPR whose chunk slice
+        // stays below ~24 KB (27-point stencil: 4 lanes per row 138 us / CG 170 us, 2 lanes 139 / 177, 8 lanes 209); rows
+        // so dense that even 32 of them exceed that may use up to 48 KB with 8 lanes per row
+        if (nrhs == 1 && g_tune.spmv_chunked != 0) {
+            const size_t ebytes = dtype_size(dtype) + 4;
+            const size_t want = (size_t)(g_tune.spmv_chunk_kb > 0 ? g_tune.spmv_chunk_kb * 1024 : kChunkBytes);
+            for (int lv = 0; lv < 3 && kind == 0; ++lv)
+                if (plan->chunk_span[lv] > 0 && (size_t)plan->chunk_span[lv] * ebytes <= want) {
+                    kind = 7;
+                    plan->lpr = 2 << lv;
+                }
+            if (kind == 0 && plan->chunk_span[2] > 0 && (size_t)plan->chunk_span[2] * ebytes <= (size_t)kMaxChunkBytes) {
+                kind = 7;
+                plan->lpr = 8;
+            }
+        }
+    }
+    if (kind != 5 && kind != 7) kind = 0;
     if (kind == 5 && nrhs > 1) kind = 6;      // SpMM form of the row-block kernel
     plan->kind = kind;
     plan->n_partials = kind ? plan->row_blocks : plan->grid;

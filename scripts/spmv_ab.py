@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--helm", type=int, default=0, help="use the Helmholtz FE matrix helm_fe_var(N) instead of the 3-D stencil")
+    ap.add_argument("--stencil27", type=int, default=0, help="use the 3-D 27-point stencil on an N^3 grid (27 nnz/row: generic kernel)")
     ap.add_argument("cfgs", nargs="*", default=["spmv_variant=0", "spmv_variant=1", "spmv_variant=2"])
     args = ap.parse_args()
     import torch
@@ -40,6 +41,16 @@ def main():
         n = args.helm ** 2
         indptr, indices = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
         data = torch.from_numpy(hd.astype(dtype)).to(dev)
+    elif args.stencil27:
+        import scipy.sparse as sp
+        m = args.stencil27
+        t1 = sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], [-1, 0, 1], format="csr")
+        A = sp.kron(sp.kron(t1, t1, format="csr"), t1, format="csr")
+        A = (sp.identity(m ** 3, format="csr") * 27.0 - A * 0.5).tocsr()
+        A.sort_indices()
+        n = m ** 3
+        indptr, indices = torch.from_numpy(A.indptr.astype(np.int32)).to(dev), torch.from_numpy(A.indices.astype(np.int32)).to(dev)
+        data = torch.from_numpy(A.data.astype(dtype)).to(dev)
     else:
         indptr, indices, data = pkg.generators.laplace3d(ctx, nx, ny, nz, dtype=dtype)
     nnz = int(indices.numel())
@@ -51,7 +62,7 @@ def main():
     ys = torch.empty(n, dtype=tdt, device=dev)
     torch.cuda.synchronize()
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-    defaults = {"spmv_variant": 5, "spmv_nt": -1, "spmv_grid": 0, "vec_grid": 0, "spmv_cycle": 64, "spmv_ilv": -1, "defer_x": 1, "fold_alpha": 1, "alpha_two_level": 1, "spmv_unroll": 0, "spmv_lds_pad": 0, "spmv_policy": -1, "vec_nt": -1, "vec_skew": 0}
+    defaults = {"spmv_variant": 5, "spmv_nt": -1, "spmv_grid": 0, "vec_grid": 0, "spmv_cycle": 64, "spmv_ilv": -1, "defer_x": 1, "spmv_chunked": 1, "spmv_chunk_kb": 0, "fold_alpha": 1, "alpha_two_level": 1, "spmv_unroll": 0, "spmv_lds_pad": 0, "spmv_policy": -1, "vec_nt": -1, "vec_skew": 0}
     solvers = []
     for cfg in args.cfgs:
         kv = dict(defaults)

@@ -197,3 +197,46 @@ def test_error_reporting_on_gpu(pkg, gpu):
     with pytest.raises(pkg.CgAmdError):
         s.spmm_rowmajor(s.vector("x"), s.vector("r"), 8)                               # nRHS must be 16 or 32
     s.close()
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("n,avg,long_row", [(3000, 24, None), (3001, 40, None), (2500, 90, None), (4000, 30, (777, 3500)),
+                                            (700, 260, None)])
+def test_solver_spmv_and_cg_dense_rows(pkg, gpu, dtype, n, avg, long_row):
+    """rows too dense for a 256-row LDS slice: the solver's plan picks the chunked row-block kernel (2, 4 or 8 lanes per
+    row) or, when even a 32-row chunk is too large (one very long row, 260 entries per row), the generic kernel.  SpMV and
+    the fused d.q against the oracle, then a short CG on a diagonally dominant system with the same pattern."""
+    import scipy.sparse as sp
+    ctx, queue, kernels = gpu
+    rng = np.random.default_rng(n + avg)
+    indptr, indices, data = rand_csr(rng, n, avg, dtype, empty_rows=True, long_row=long_row)
+    x = rand_vec(rng, n, dtype)
+    want = cg_oracle.spmv(indptr, indices, data, x, mode=cg_oracle.MODE_SEQUENTIAL)
+    s = pkg.Solver(ctx, n, len(indices), data, indptr, indices, 1)
+    xb, yb = _buf(pkg, ctx, x), _buf(pkg, ctx, np.full(n, 3, dtype=dtype))
+    for fused in (False, True):
+        s.spmv(xb, yb, fused_dot=fused)
+        ctx.synchronize()
+        got = yb.get()
+        scale = np.abs(sp.csr_matrix((np.abs(data), indices, indptr), shape=(n, n))) @ np.abs(x) + 1e-30
+        assert np.max(np.abs(got - want) / scale) < RTOL[np.dtype(dtype)], fused
+    s.close()
+    # CG: A = |pattern| made symmetric and diagonally dominant (complex: complex-symmetric, as the recurrence expects)
+    P = sp.csr_matrix((np.abs(data).astype(np.float64) + 0.1, indices, indptr), shape=(n, n))
+    P = P + P.T
+    cplx = np.dtype(dtype).kind == "c"
+    A = sp.csr_matrix(P * ((1.0 + 0.05j) if cplx else 1.0) + sp.diags(np.asarray(abs(P).sum(axis=1)).ravel() + 1.0))
+    A.sort_indices()
+    ip, ix, da = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(dtype)
+    b = rand_vec(rng, n, dtype)
+    wide = np.complex128 if cplx else np.float64
+    xo, ho = cg_oracle.cg(ip, ix, da.astype(wide), b.astype(wide), n_iterations=8, mode=cg_oracle.MODE_SEQUENTIAL)
+    s = pkg.Solver(ctx, n, len(ix), da, ip, ix, 1)
+    xg, hg = s.solve(b, None, 8)
+    s.close()
+    single = np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64))
+    if long_row is not None:
+        return      # one row/column of 3500 entries: CG amplifies rounding by 1e5 within 8 iterations -- SpMV check only
+    keep = np.abs(ho[:, 0]) / np.abs(ho[0, 0]) > (1e-4 if single else 1e-9)
+    assert np.max(np.abs(hg[keep, 0] - ho[keep, 0]) / np.abs(ho[keep, 0])) < (1e-4 if single else 1e-10)
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) < (1e-4 if single else 1e-9)
