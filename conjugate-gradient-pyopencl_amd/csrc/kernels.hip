@@ -1987,7 +1987,7 @@ void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nn
     if (!vec || plan->max_span <= 0) kind = 0;
     plan->lpr = 1;
     if (kind == 5 && (size_t)plan->max_span * (dtype_size(dtype) + 4) + acc_size(dtype) * (size_t)nrhs * (kBlock / 64) >
-                         (size_t)kMaxSliceBytes) {
+                         (size_t)(g_tune.spmv_slice_kb > 0 ? g_tune.spmv_slice_kb * 1024 : kMaxSliceBytes)) {
         kind = 0;
         // denser rows: the chunked form of the row-block kernel (single right-hand side).  Smallest LPR whose chunk slice
         // stays below ~24 KB (27-point stencil: 4 lanes per row 138 us / CG 170 us, 2 lanes 139 / 177, 8 lanes 209); rows
