@@ -46,9 +46,11 @@ SpmvPlan make_spmv_plan(int n);
 // fills plan->max_span / chunk_span from the matrix structure; synchronises `st`; scratch_dev: >= 16 bytes
 int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan);
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols);
-constexpr int kChunkBytes = 24 * 1024;      // kind 7: preferred LDS chunk slice (6 work-groups per CU)
+constexpr int kChunkBytes = 32 * 1024;      // kind 7: preferred LDS chunk slice (4-5 work-groups per CU)
 constexpr int kMaxChunkBytes = 48 * 1024;   //         largest accepted, with 8 lanes per row (3 work-groups per CU)
-constexpr int kMaxSliceBytes = 64 * 1024;   // variant 5: largest LDS slice accepted (else the generic chunked kernel runs)
+constexpr int kMaxSpmmSliceBytes = 64 * 1024;   // SpMM forms (nRHS > 1, row-major matrix-core op): largest 256-row LDS slice
+constexpr int kMaxSliceBytes = 40 * 1024;   // variant 5: largest 256-row LDS slice (4 work-groups per CU); denser rows -> chunked kernel.
+                                            // 27-point f32 (55 KB): 114 us one lane per row, 91 us chunked; 7-point c128 (36 KB): 314 vs 357
 
 // run-time tuning knobs (cgamd_tune); defaults are the shipped configuration
 struct Tuning {

@@ -1987,10 +1987,11 @@ void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nn
     if (!vec || plan->max_span <= 0) kind = 0;
     plan->lpr = 1;
     if (kind == 5 && (size_t)plan->max_span * (dtype_size(dtype) + 4) + acc_size(dtype) * (size_t)nrhs * (kBlock / 64) >
-                         (size_t)(g_tune.spmv_slice_kb > 0 ? g_tune.spmv_slice_kb * 1024 : kMaxSliceBytes)) {
+                         (size_t)(g_tune.spmv_slice_kb > 0 ? g_tune.spmv_slice_kb * 1024 : nrhs > 1 ? kMaxSpmmSliceBytes : kMaxSliceBytes)) {
         kind = 0;
         // denser rows: the chunked form of the row-block kernel (single right-hand side).  Smallest LPR whose chunk slice
-        // stays below ~24 KB (27-point stencil: 4 lanes per row 138 us / CG 170 us, 2 lanes 139 / 177, 8 lanes 209); rows
+        // stays below ~32 KB (27-point stencil fp64: 4 lanes per row 138 us / CG 170 us, 2 lanes 139 / 177, 8 lanes 209;
+        // f32: 2 lanes 91 / 117, 4 lanes 94 / 122); rows
         // so dense that even 32 of them exceed that may use up to 48 KB with 8 lanes per row
         if (nrhs == 1 && g_tune.spmv_chunked != 0) {
             const size_t ebytes = dtype_size(dtype) + 4;

@@ -405,7 +405,7 @@ int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS
     if (nRHS != 16 && nRHS != 32) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: nRHS must be 16 or 32");
     if (s->dtype != CGAMD_F32 && s->dtype != CGAMD_F64) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: real value types only");
     if (!aligned16(s->vals) || !aligned16(s->cols)) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: matrix arrays must be 16-byte aligned");
-    if (s->plan.max_span <= 0 || (size_t)s->plan.max_span * (dtype_size(s->dtype) + 4) > (size_t)kMaxSliceBytes)
+    if (s->plan.max_span <= 0 || (size_t)s->plan.max_span * (dtype_size(s->dtype) + 4) > (size_t)kMaxSpmmSliceBytes)
         return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: a 256-row slice of this matrix does not fit LDS; use cgamd_spmv");
     CG_HIP(hipSetDevice(s->ctx->device));
     return launch_spmm_mfma(s->dtype, s->plan, s->n, s->nnz, s->vals, s->ptr, s->cols, x, y, nRHS, s->ctx->stream);

@@ -95,7 +95,7 @@ def main():
                     ref = y
                 else:
                     err = (y - ref).abs().max().item() / ref.abs().max().item()
-                    assert err < 1e-12, (cfg, err)
+                    assert err < (1e-12 if np.dtype(dtype).itemsize // (2 if np.dtype(dtype).kind == "c" else 1) == 8 else 1e-5), (cfg, err)
             if kv.get("spmv_dbg", 0) & 3:
                 res[cfg]["iter"].append(1.0)
                 continue
