@@ -1917,12 +1917,27 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
         const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave);
         dim3 g6(rowblock_grid(plan.row_blocks, a.cycle));
-        constexpr int RB = sizeof(T) <= 8 ? 8 : 4;
+        constexpr int RBMAX = sizeof(T) <= 8 ? 8 : 4;
         // One launch covers all right-hand sides (groups of RB inside the kernel).  Splitting into one launch per
         // group (cgamd_tune "spmm_rb") re-reads the matrix per group and shrinks the x window per XCD; measured
         // slower at nRHS = 32 (253 vs 220 us) and at nRHS = 9 -- kept as an experiment knob only.
         const int chunk = (g_tune.spmm_rb > 0 && g_tune.spmm_rb < nrhs) ? g_tune.spmm_rb : nrhs;
         const bool nt6 = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
+        // group width: the right-hand sides are cut into ceil(n / RBMAX) groups of (nearly) equal width, so that the last
+        // group is not mostly padding -- the reference's own shape, 9 sub-domains, runs as 5 + 4 instead of 8 + 1
+        const int ngroups = (chunk + RBMAX - 1) / RBMAX;
+        int rbw = g_tune.spmm_group > 0 ? g_tune.spmm_group : (chunk + ngroups - 1) / ngroups;
+        if (rbw > RBMAX) rbw = RBMAX;
+#define CG_MM(RBW)                                                                                                         \
+    do {                                                                                                                    \
+        if (fuse) {                                                                                                         \
+            if (nt6) hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, true, true, RBW>), g6, block, lds, st, b);         \
+            else hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, false, true, RBW>), g6, block, lds, st, b);            \
+        } else {                                                                                                            \
+            if (nt6) hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, true, false, RBW>), g6, block, lds, st, b);        \
+            else hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, false, false, RBW>), g6, block, lds, st, b);           \
+        }                                                                                                                   \
+    } while (0)
         for (int g0 = 0; g0 < nrhs; g0 += chunk) {
             SpmvArgs<T> b = a;
             b.nrhs = (nrhs - g0 < chunk) ? nrhs - g0 : chunk;
@@ -1931,13 +1946,15 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
             if (fuse) {
                 b.dvec = a.dvec + (long long)g0 * ldx;
                 b.partials = a.partials + (long long)g0 * plan.row_blocks;
-                if (nt6) hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, true, true, RB>), g6, block, lds, st, b);
-                else hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, false, true, RB>), g6, block, lds, st, b);
-            } else {
-                if (nt6) hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, true, false, RB>), g6, block, lds, st, b);
-                else hipLaunchKernelGGL((spmm_rowblock_kernel<T, kBlock, false, false, RB>), g6, block, lds, st, b);
             }
+            if (RBMAX == 8 && rbw > 6) CG_MM(RBMAX);
+            else if (RBMAX == 8 && rbw == 6) CG_MM(6);
+            else if (RBMAX == 8 && rbw == 5) CG_MM(5);
+            else if (rbw == 4 || (RBMAX == 4 && rbw > 3)) CG_MM(4);
+            else if (rbw == 3) CG_MM(3);
+            else CG_MM(2);
         }
+#undef CG_MM
         return check_launch("spmm_rowblock");
     }
     if (vec) {
