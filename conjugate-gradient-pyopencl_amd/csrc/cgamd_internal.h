@@ -162,7 +162,7 @@ int p2p_push_chunks(const P2pExchange &e);
 int launch_pcg_axpy2_dot2(int dtype, bool init, int n, const void *d, void *x, const void *q, void *r, const void *m,
                           long long ld, const void *alpha, int nrhs, void *part_rz, void *part_rr, int grid, hipStream_t st);
 int launch_pcg_aypx_beta(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *part_rz,
-                         const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st);
+                         const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, void *xs, hipStream_t st);
 int launch_pcg_delta0(int dtype, const void *part_rz, const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st);
 // four-launch peer-to-peer iteration (see kernels.hip): SpMV with the push and the wait inside, aypx with the beta all-reduce.
 // halo_flag: device int per row block (1 = references a halo column); rotate: first row block of the visiting order

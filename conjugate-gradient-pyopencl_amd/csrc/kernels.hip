@@ -1077,8 +1077,9 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_x_kernel(int n, const T *__re
 // Diagonally (Jacobi) preconditioned CG -- the reference's PCG with a diagonal CSR `M`, z = M.dot(r)
 // (helmFE_var.py:546-586): rho = r.z, p = z + (rho/rho_old) p, q = A p, alpha = rho / p.q, x += alpha p, r -= alpha q,
 // stop on sqrt|r.r|.  Same four launches as the plain loop: the SpMV (+p.q) and cg_alpha are shared (delta holds rho);
-//   pcg_axpy2_dot2_kernel : x += alpha p, r -= alpha q, partials of r.(m r) and of r.r      (7NV bytes)
-//   pcg_aypx_beta_kernel  : beta in the prologue, p = m r + beta p                           (4NV bytes)
+//   pcg_axpy2_dot2_kernel : r -= alpha q, partials of r.(m r) and of r.r                    (4NV bytes)
+//   pcg_aypx_beta_kernel  : beta in the prologue, x += alpha p, p = m r + beta p            (6NV bytes)
+// (x += alpha p rides in the second launch, which reads p anyway: see the ten-vector-pass iteration above)
 // m[i] is what multiplies r[i] (the inverse diagonal for Jacobi), shared by all right-hand sides.  rho of the previous
 // iteration is read from a two-entry parity buffer so that work-group 0 may publish the new one in the same launch.
 // =================================================================================================
@@ -1106,14 +1107,9 @@ __global__ __launch_bounds__(BLOCK) void pcg_axpy2_dot2_kernel(int n, const T *_
             Pack<T> pr = ld_pack(rv + i * E);
             const Pack<T> pm = ld_pack(m + i * E);
             if (!INIT) {
-                const Pack<T> pd = ld_pack(d + i * E), pq = ld_pack(q + i * E);
-                Pack<T> px = ld_pack(x + i * E);
+                const Pack<T> pq = ld_pack(q + i * E);
 #pragma unroll
-                for (int k = 0; k < E; ++k) {
-                    px.v[k] = vadd(px.v[k], vmul(al, pd.v[k]));
-                    pr.v[k] = vsub(pr.v[k], vmul(al, pq.v[k]));
-                }
-                st_pack(x + i * E, px);
+                for (int k = 0; k < E; ++k) pr.v[k] = vsub(pr.v[k], vmul(al, pq.v[k]));
                 st_pack(rv + i * E, pr);
             }
             Pack<T> pz;
@@ -1130,7 +1126,6 @@ __global__ __launch_bounds__(BLOCK) void pcg_axpy2_dot2_kernel(int n, const T *_
     for (long long i = i0; i < n; i += stride) {
         T rn = rv[i];
         if (!INIT) {
-            x[i] = vadd(x[i], vmul(al, d[i]));
             rn = vsub(rn, vmul(al, q[i]));
             rv[i] = rn;
         }
@@ -1150,7 +1145,8 @@ __global__ __launch_bounds__(BLOCK) void pcg_aypx_beta_kernel(int n, const T *__
                                                               const T *__restrict__ m, long long ld,
                                                               const typename VT<T>::acc *__restrict__ part_rz,
                                                               const typename VT<T>::acc *__restrict__ part_rr, int P, int nrhs,
-                                                              T *delta, T *beta, T *history, T *rho2, const int *iter) {
+                                                              T *delta, T *beta, T *history, T *rho2, const int *iter,
+                                                              T *__restrict__ xs, const T *__restrict__ alpha) {
     using A = typename VT<T>::acc;
     __shared__ A red[BLOCK / kWave];
     __shared__ T beta_s;
@@ -1181,8 +1177,8 @@ __global__ __launch_bounds__(BLOCK) void pcg_aypx_beta_kernel(int n, const T *__
         }
         __syncthreads();
     }
-    const T bt = beta_s;
-    rv += (long long)r * ld; pv += (long long)r * ld;
+    const T bt = beta_s, al = alpha[r];
+    rv += (long long)r * ld; pv += (long long)r * ld; xs += (long long)r * ld;
     constexpr int E = Pack<T>::N;
     const long long stride = (long long)gridDim.x * BLOCK;
     long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -1190,14 +1186,22 @@ __global__ __launch_bounds__(BLOCK) void pcg_aypx_beta_kernel(int n, const T *__
         const long long npack = n / E;
         for (long long i = i0; i < npack; i += stride) {
             const Pack<T> pr = ld_pack(rv + i * E), pm = ld_pack(m + i * E);
-            Pack<T> pp = ld_pack(pv + i * E);
+            Pack<T> pp = ld_pack(pv + i * E), px = ld_pack(xs + i * E);
 #pragma unroll
-            for (int k = 0; k < E; ++k) pp.v[k] = vadd(vmul(bt, pp.v[k]), vmul(pm.v[k], pr.v[k]));
+            for (int k = 0; k < E; ++k) {
+                px.v[k] = vadd(px.v[k], vmul(al, pp.v[k]));
+                pp.v[k] = vadd(vmul(bt, pp.v[k]), vmul(pm.v[k], pr.v[k]));
+            }
+            st_pack(xs + i * E, px);
             st_pack(pv + i * E, pp);
         }
         i0 += npack * E;
     }
-    for (long long i = i0; i < n; i += stride) pv[i] = vadd(vmul(bt, pv[i]), vmul(m[i], rv[i]));
+    for (long long i = i0; i < n; i += stride) {
+        const T pv0 = pv[i];
+        xs[i] = vadd(xs[i], vmul(al, pv0));
+        pv[i] = vadd(vmul(bt, pv0), vmul(m[i], rv[i]));
+    }
 }
 
 // set_rhs: delta = rho0 = sum r.z partials, rho2[0] = rho0, history[0] = r.r, iter = 0
@@ -2322,17 +2326,17 @@ int launch_pcg_axpy2_dot2(int dtype, bool init, int n, const void *d, void *x, c
 }
 template <typename T>
 static int pcg_aypx_impl(int n, const void *r, void *p, const void *m, long long ld, const void *part_rz, const void *part_rr,
-                         int P, int nrhs, const CgScalars &sc, void *rho2, bool vec, hipStream_t st) {
+                         int P, int nrhs, const CgScalars &sc, void *rho2, void *xs, bool vec, hipStream_t st) {
     dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
     using A = typename VT<T>::acc;
-    if (vec) hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, (T *)rho2, (const int *)sc.iter);
-    else hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, (T *)rho2, (const int *)sc.iter);
+    if (vec) hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
+    else hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
     return check_launch("pcg_aypx_beta");
 }
 int launch_pcg_aypx_beta(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *part_rz,
-                         const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st) {
-    const bool vec = vec_ok(dtype, ld, nrhs, {r, p, m});
-    CG_DISPATCH(dtype, pcg_aypx_impl, n, r, p, m, ld, part_rz, part_rr, P, nrhs, sc, rho2, vec, st);
+                         const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, void *xs, hipStream_t st) {
+    const bool vec = vec_ok(dtype, ld, nrhs, {r, p, m, xs});
+    CG_DISPATCH(dtype, pcg_aypx_impl, n, r, p, m, ld, part_rz, part_rr, P, nrhs, sc, rho2, xs, vec, st);
 }
 template <typename T>
 static int pcg_delta0_impl(const void *part_rz, const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st) {

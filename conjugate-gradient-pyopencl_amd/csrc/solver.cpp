@@ -74,7 +74,7 @@ static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
         if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
         if ((rc = launch_pcg_axpy2_dot2(dt, false, n, s->d, s->x, s->q, s->r, s->mdiag, n, s->sc.alpha, nr, s->part_rz, s->part_rr,
                                         s->vgrid, st))) return rc;
-        return launch_pcg_aypx_beta(dt, n, s->r, s->d, s->mdiag, n, s->part_rz, s->part_rr, s->vgrid, nr, s->sc, s->rho2, st);
+        return launch_pcg_aypx_beta(dt, n, s->r, s->d, s->mdiag, n, s->part_rz, s->part_rr, s->vgrid, nr, s->sc, s->rho2, s->x, st);
     }
     if (!(s->flags & CGAMD_UNFUSED)) {
         if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
