@@ -26,7 +26,7 @@ def run(name, indptr, indices, data, dtype, nrhs, iters=200, reps=30):
     n = indptr.numel() - 1
     nnz = indices.numel()
     tdt = pkg.generators.torch_dtype(dtype)
-    s = pkg.Solver(ctx, n, nnz, data, indptr, indices, nrhs, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=dtype)
+    s = pkg.Solver(ctx, n, nnz, data, indptr, indices, nrhs, flags=pkg._lib.MATRIX_ON_DEVICE | (pkg._lib.NO_GRAPH if "nograph" in sys.argv else 0), dtype=dtype)
     b = torch.full((n * nrhs,), 5.0, dtype=tdt, device=dev)
     torch.cuda.synchronize()
     s.set_rhs(b, None, on_device=True)
@@ -56,7 +56,7 @@ def run(name, indptr, indices, data, dtype, nrhs, iters=200, reps=30):
     s.close()
 
 
-which = [w for w in sys.argv[1:] if "=" not in w] or ["c2", "c3", "c4", "m32", "c2f32", "c3c64"]
+which = [w for w in sys.argv[1:] if "=" not in w and w != "nograph"] or ["c2", "c3", "c4", "m32", "c2f32", "c3c64"]
 for kv in sys.argv[1:]:
     if "=" in kv:
         k, v = kv.split("=")
