@@ -29,6 +29,15 @@ def _system(kind):
         ip, ix, da, b = _system(kind[:-4])
         dt = np.float32 if kind.endswith("_f32") else np.complex64
         return ip, ix, da.astype(dt), b.astype(dt)
+    if kind == "rand":               # ~9 entries per row, random pattern: every rank is every other rank's halo peer
+        import scipy.sparse as sp
+        rng = np.random.default_rng(12)
+        n = 7000
+        P = sp.random(n, n, density=4.0 / n, random_state=rng, format="csr")
+        P = P + P.T
+        A = sp.csr_matrix(P + sp.diags(np.asarray(abs(P).sum(axis=1)).ravel() + 1.0))
+        A.sort_indices()
+        return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data, np.linspace(1.0, 2.0, n)
     if kind == "dense":              # ~60 entries per row: the chunked row-block kernel; no halo flags -> staged in-line exchange
         import scipy.sparse as sp
         rng = np.random.default_rng(11)
@@ -92,7 +101,8 @@ def _worker(rank, world, port, kind, iters, flags, out_dir):
 # 8 = the same from a hipGraph, 128 = staged push / unpack / all-reduce launches (+8 graph, +32 no interior/boundary overlap)
 @pytest.mark.parametrize("world,kind,flags", [(2, "lap3d", 0), (3, "lap3d", 8), (2, "helm", 8), (3, "helm", 0), (4, "lap3d", 0),
                                               (2, "lap3d", 128), (3, "lap3d", 128 | 8), (3, "helm", 128 | 32),
-                                              (2, "lap3d_f32", 0), (3, "helm_c64", 0), (2, "dense", 0), (3, "dense", 8)])
+                                              (2, "lap3d_f32", 0), (3, "helm_c64", 0), (2, "dense", 0), (3, "dense", 8),
+                                              (4, "rand", 0), (3, "rand", 8), (3, "rand", 128)])
 def test_p2p_multirank_on_one_gpu(tmp_path, world, kind, flags):
     import torch.multiprocessing as mp
     import cg_oracle
