@@ -35,6 +35,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmv_ilv") g_tune.spmv_ilv = value;
     else if (k == "spmv_chunked") g_tune.spmv_chunked = value;
     else if (k == "spmm_group") g_tune.spmm_group = value;
+    else if (k == "spmm_ynt") g_tune.spmm_ynt = value;
     else if (k == "spmv_chunk_kb") g_tune.spmv_chunk_kb = value;
     else if (k == "spmv_slice_kb") g_tune.spmv_slice_kb = value;
     else if (k == "fold_alpha") g_tune.fold_alpha = value;

@@ -58,6 +58,7 @@ struct Tuning {
     int spmv_nt = -1;       // non-temporal matrix loads: 1 on, 0 off, -1 auto = on unless the matrix fits the 256 MB Infinity
                             // Cache (below that the re-used matrix is served from the cache; finalize_spmv_plan)
     int spmv_unroll = 0;    // row walk: LDS reads + gathers in flight per lane (4 or 8; 0 = 8, or 4 for 16-byte values)
+    int spmm_ynt = 0;       // experiment: SpMM stores y non-temporally
     int spmm_group = 0;     // SpMM: right-hand sides per register group (0 = equal-width groups of at most 8, 4 for complex128)
     int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = all in one launch)
     int vec_skew = 0;       // bytes added to the pitch between the solver's vectors (multiple of 16)

@@ -105,6 +105,7 @@ template <typename T> struct SpmvArgs {
     int rb_count;
     int cap;   // row-block kernel: LDS slice capacity in entries (multiple of 4)
     int cycle; // row-block kernel: block-cyclic schedule over the XCDs, cycle length in row blocks (1 = one contiguous eighth per XCD)
+    int ynt;   // SpMM: store y non-temporally (experiment knob "spmm_ynt")
 };
 
 // Row-block schedule shared by the row-block kernels: work-group b runs on XCD b%8 as that XCD's (b/8)-th block.
@@ -593,7 +594,10 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowblock_kernel(SpmvArgs<T> a) {
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             if (g0 + j < a.nrhs) {       // wave-uniform
-                if (row < a.n) a.y[row + (long long)(g0 + j) * a.ldy] = sum[j];
+                if (row < a.n) {
+                    if (a.ynt) st_nt(a.y + row + (long long)(g0 + j) * a.ldy, sum[j]);
+                    else a.y[row + (long long)(g0 + j) * a.ldy] = sum[j];
+                }
                 if (FUSE_DOT) {
                     const A contrib = (row < a.n) ? to_acc(vmul(a.dvec[row + (long long)(g0 + j) * a.ldx], sum[j])) : vzero<A>();
                     const A w = wave_sum(contrib);
@@ -1856,6 +1860,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     a.partials = static_cast<typename VT<T>::acc *>(partials);
     a.row_blocks = plan.row_blocks;
     a.rb_list = rb_list; a.rb_count = rb_count;
+    a.ynt = g_tune.spmm_ynt;
     const bool vec = aligned16(vals) && aligned16(cols);
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
