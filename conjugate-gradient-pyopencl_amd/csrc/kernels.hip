@@ -1,18 +1,24 @@
 // Hand-written gfx950 kernels of the CG hot path.
 //
-//   spmv_stream_kernel   CSR SpMV/SpMM (replaces reference kernel/{real,complex}/spmv.cl), optionally fused
-//                        with the d.q partial reduction (reference vdot.cl + host sum clcg.c:317-324)
-//   dot_partials_kernel  reference kernel/{real,complex}/vdot.cl (partials stay on the device)
-//   axpy / aypx / sub    reference kernel/{real,complex}/{axpy,aypx,sub}.cl
-//   axpy2_dot_kernel     x += alpha d ; r -= alpha q ; partial r.r in one pass (reference clcg.c:338-374)
-//   cg_alpha/beta/delta0 the scalar work the reference does on the host (clcg.c:274-292,317-334,376-411)
+//   spmv_rowblock_kernel          CSR SpMV (replaces reference kernel/{real,complex}/spmv.cl) fused with the d.q partial
+//                                 reduction (reference vdot.cl + host sum clcg.c:317-324): matrix slice through LDS, one lane
+//                                 per row; _chunked: 2/4/8 lanes per row for denser rows; _p2p: with the halo push / wait
+//   spmm_rowblock_kernel          the same for nRHS > 1 (RHS-major, the ABI layout); spmm_mfma_kernel: row-major, matrix cores
+//   spmv_stream_kernel            generic chunked CSR stream (huge rows, unaligned pointers)
+//   dot_partials_kernel           reference kernel/{real,complex}/vdot.cl (partials stay on the device)
+//   ewise_kernel                  reference kernel/{real,complex}/{axpy,aypx,sub}.cl
+//   axpy_dot / aypx_beta_x        the fused loop: r -= alpha q + r.r partials; beta, x += alpha d, d = beta d + r
+//                                 (reference clcg.c:338-416); axpy2_dot / aypx_beta: the form with x updated in the r launch
+//   pcg_*                         diagonally preconditioned recurrence (reference helmFE_var.py:546-586)
+//   cg_alpha/beta/delta0          the scalar work the reference does on the host (clcg.c:274-292,317-334,376-411)
+//   p2p_*                         peer-to-peer mailbox protocol of the row-partitioned multi-GPU loop
 //
-// Design (MI355X): every kernel is HBM-bound.  Work-groups are 256 threads (4 wave64); streaming
-// kernels launch <= 2048 persistent work-groups (256 CUs x 8) that own contiguous ranges, mapped so
-// that each XCD owns one contiguous range (xcd_remap).  Loads are 16 B per lane; matrix streams are
-// non-temporal so they do not evict the gathered vector from L2.  Reductions are wave64 shuffles,
-// then LDS across the 4 waves, then a fixed-order pass over the per-work-group partials: bitwise
-// reproducible run to run, no atomics.
+// Design (MI355X): every kernel is bound by the memory system.  Work-groups are 256 threads (4 wave64).  The SpMV kernels
+// run one work-group per 256-row block, dealt block-cyclically over the 8 XCDs; the vector kernels launch <= 2048 grid-
+// stride work-groups (256 CUs x 8).  Loads are 16 B per lane and every load instruction of a wave covers contiguous
+// memory; matrix streams are non-temporal unless the matrix fits the Infinity Cache.  Reductions are wave64 shuffles,
+// then LDS across the 4 waves, then a fixed-order pass over the per-work-group partials: bitwise reproducible run to
+// run (atomics only hand out tickets).
 #include "cgamd_internal.h"
 #include "device_types.h"
 
