@@ -58,42 +58,88 @@ def host_cores():
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1_pmc_traffic.json, written by scripts/pmc_traffic.py); None when absent."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    """(HBM bytes per launch of the dominant kernel, where that number comes from).  PMC counters need rocprofv3 around
+    the process, so the figure is read from the committed counter passes of the same command (scripts/pmc_traffic.py);
+    the newest round's file wins.  (None, reason) when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    for f in reversed(files):
+        try:
+            j = json.load(open(f))
+            return j["hbm_bytes_per_launch"], (f"profiles/{os.path.basename(f)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                               f"over bench.py, {j.get('launches_averaged', '?')} launches averaged; not measured in this run)")
+        except Exception:
+            continue
+    return None, "no committed PMC pass found"
 
 
-def cpu_baseline(nx, ny, nz_full, dtype, budget_s=20.0):
-    """The CPU oracle (C restatement of the reference op structure, OpenMP) on a bounded sample:
-    the same 7-point system truncated along z so that ~10-30 s of host work are timed."""
+def cpu_baseline(nx, ny, nz, dtype, budget_s=10.0, batch=50):
+    """The CPU oracle (C restatement of the reference op structure clcg.c:298-416: spmv, vdot, axpy, axpy, vdot, aypx,
+    host-resident scalars, no fusion; OpenMP) on the FULL system of the GPU run -- same matrix, same b, same dtype --
+    for about `budget_s` seconds of host work: solves of `batch` iterations from x0 = 0, repeated."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cg_numpy
     import cg_oracle
     threads = cg_oracle.set_threads(host_cores())
-    nz = max(2, min(nz_full, 20))                      # 250x200x20 = 1M rows
-    indptr, indices, data = cg_numpy.laplace3d(nx, ny, nz, dtype=dtype)
+    if np.dtype(dtype).kind == "f":
+        indptr, indices, data = cg_oracle.laplace3d(nx, ny, nz, dtype=dtype)
+    else:
+        indptr, indices, data = cg_numpy.laplace3d(nx, ny, nz, dtype=dtype)
     n = nx * ny * nz
     b = np.full(n, 5.0, dtype=dtype)                   # main.c:44 convention
+    cg_oracle.cg(indptr, indices, data, b, n_iterations=1, mode=cg_oracle.MODE_FAST)      # first touch / warm-up
+    iters, hist = 0, None
     t0 = time.perf_counter()
-    cg_oracle.cg(indptr, indices, data, b, n_iterations=2, mode=cg_oracle.MODE_FAST)
-    per_it = (time.perf_counter() - t0) / 3.0
-    iters = int(max(5, min(400, budget_s / max(per_it, 1e-6))))
-    t0 = time.perf_counter()
-    cg_oracle.cg(indptr, indices, data, b, n_iterations=iters, mode=cg_oracle.MODE_FAST)
+    while iters == 0 or (time.perf_counter() - t0 < budget_s and iters < 100 * batch):
+        _, hist = cg_oracle.cg(indptr, indices, data, b, n_iterations=batch, mode=cg_oracle.MODE_FAST)
+        iters += batch
     dt = time.perf_counter() - t0
-    it_s_sample = iters / dt
-    # iterations/s scale inversely with rows for this bandwidth-bound loop: quote it on the full system
-    scale = nz / float(nz_full)
-    return {"value": it_s_sample * scale, "unit": "CG iterations/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/cg_oracle.c (OpenMP, reference op structure) {iters} iterations on {nx}x{ny}x{nz} "
-                      f"({n} rows) = {it_s_sample:.1f} it/s, scaled by rows to {nx}x{ny}x{nz_full}"}
+    # every solve also runs the setup (one SpMV, sub, copy, dot: clcg.c:255-292), ~0.6 of an iteration per `batch`: not counted
+    return {"value": iters / dt, "unit": "CG iterations/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/cg_oracle.c (OpenMP, {threads} threads, reference op structure) {iters} iterations "
+                      f"({iters // batch} solves of {batch} from x0=0, setup included in the time) on the full {nx}x{ny}x{nz} "
+                      f"system ({n} rows, {len(indices)} non-zeros, {np.dtype(dtype).name}) in {dt:.2f} s; "
+                      f"delta_{batch}/delta_0 = {abs(hist[-1, 0]) / abs(hist[0, 0]):.3e}"}
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N rank processes ourselves.
+
+    Runs BEFORE anything in this process has touched HIP (torch is not even imported here): the ranks are fresh children
+    of `python -m torch.distributed.run`, this process only relays rank 0's JSON line and the exit code -- a process
+    that has initialised the GPU is never re-executed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line_json = None
+    for line in proc.stdout:
+        if line.lstrip().startswith("{") and '"metric"' in line:
+            line_json = line.strip()
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    if rc == 0 and line_json is None:
+        sys.stderr.write("bench.py: the rank processes exited 0 without a result line\n")
+        rc = 1
+    return rc
 
 
 def main():
     args = parse()
+    # multi-process GPU work on this pool needs dmabuf IPC (INTEGRATION.md); set before any HIP call of this process
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("CG_FORCE_DIST", "0") != "1":
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     import torch
     import torch.distributed as dist
 
@@ -103,12 +149,14 @@ def main():
     if args.gpus != world and world > 1:
         args.gpus = world
     ndev = torch.cuda.device_count()
-    if local_rank >= ndev:      # rehearsal of >1 ranks on a 1-GPU box; never the case on the 8-GPU node
+    shared = world > max(ndev, 1)     # rehearsal of N ranks on fewer GPUs (a 1-GPU box); never the case on the 8-GPU node
+    if local_rank >= ndev:
         local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("CG_FORCE_DIST", "0") == "1":
-        backend = os.environ.get("CG_DIST_BACKEND", "nccl")     # "gloo": rehearsal of N ranks on one GPU (p2p loops only)
+        # RCCL refuses two ranks on one device: ranks that share a GPU bootstrap over gloo and run the peer-to-peer loops only
+        backend = os.environ.get("CG_DIST_BACKEND", "gloo" if shared else "nccl")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -116,7 +164,12 @@ def main():
 
     pkg = importlib.import_module(PKG)
     lib = pkg._lib
-    for pair in filter(None, os.environ.get("CG_TUNE", "").split(",")):      # experiment knobs, e.g. CG_TUNE=vec_grid=512
+    tune = os.environ.get("CG_TUNE", "")
+    if shared and "vec_grid" not in tune:
+        # ranks sharing one GPU must leave each other's spinning work-groups room to run
+        per_dev = (world + max(ndev, 1) - 1) // max(ndev, 1)
+        tune = ",".join(filter(None, [tune, f"vec_grid={max(64, 1536 // per_dev)}"]))
+    for pair in filter(None, tune.split(",")):      # experiment knobs, e.g. CG_TUNE=vec_grid=512
         k, v = pair.split("=")
         lib.check(lib.load().cgamd_tune(k.encode(), int(v)))
     dtype = NP_DTYPE[args.dtype]
@@ -129,6 +182,8 @@ def main():
         from importlib import import_module
         distmod = import_module(PKG + ".dist")
         result = distmod.bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, rank, world)
+        if shared:
+            result["rehearsal"] = f"{world} ranks share {max(ndev, 1)} GPU(s): bootstrap over gloo, peer-to-peer loops only, not a scaling number"
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
@@ -137,7 +192,7 @@ def main():
             except Exception as e:   # the baseline is a reported extra, never the measured path
                 result["cpu_baseline"] = {"value": None, "unit": "CG iterations/s", "cores": os.cpu_count(),
                                           "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -215,7 +270,8 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
         "residual_check": {"delta_0": float(delta0), "delta_last": float(deltak), "iterations": int(hist.shape[0] - 1)},
         "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel (CSR SpMV fused with d.q partials), in-loop average over the instrumented pass",
                      "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms},
+                     "traffic": pmc_traffic()[0], "traffic_source": pmc_traffic()[1],
+                     "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms},
     }
     solver.close()
     return res

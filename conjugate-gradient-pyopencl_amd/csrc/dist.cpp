@@ -33,6 +33,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -57,6 +58,7 @@ void load_rccl() {
     BIND(GetUniqueId, "ncclGetUniqueId")
     BIND(CommInitRank, "ncclCommInitRank")
     BIND(CommDestroy, "ncclCommDestroy")
+    BIND(CommCount, "ncclCommCount")
     BIND(AllReduce, "ncclAllReduce")
     BIND(Send, "ncclSend")
     BIND(Recv, "ncclRecv")
@@ -557,6 +559,15 @@ int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, 
     if (d->direct && spmv_p2p_grid(d->plan) < np * p2p_push_chunks(x)) d->direct = false;   // too few work-groups to carry the push
     d->p2p_attached = true;
     return CGAMD_OK;
+}
+
+// ranks of the RCCL communicator this handle runs on, read back from RCCL (0 = no communicator: peer-to-peer backend or
+// a single rank without peers); bench.py prints it next to the RCCL timings
+int cgamd_dist_comm_ranks(cgamd_dist *d) {
+    if (!d || !d->comm) return 0;
+    int n = 0;
+    if (g_rccl.CommCount(d->comm, &n) != ncclSuccess) return -1;
+    return n;
 }
 
 // 0 = fine; != 0: a bounded spin of the peer-to-peer protocol timed out (1 boundary exchange, 2 all-reduce)

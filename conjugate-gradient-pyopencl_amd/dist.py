@@ -168,14 +168,22 @@ def broadcast_unique_id(rank, group=None, device=None):
     import torch
     import torch.distributed as dist
     lib = _lib.load()
-    buf = np.zeros(128, dtype=np.uint8)
+    buf = np.zeros(129, dtype=np.uint8)         # [128] = 1: rank 0 made an id (the broadcast runs either way)
+    err = None
     if rank == 0:
-        check(lib.cgamd_comm_unique_id(ptr(buf)))
+        try:
+            check(lib.cgamd_comm_unique_id(ptr(buf)))
+            buf[128] = 1
+        except Exception as e:      # noqa: BLE001 -- raised on every rank after the broadcast
+            err = e
     t = torch.from_numpy(buf)
     if device is not None and dist.get_backend() == "nccl":
         t = t.to(device)
     dist.broadcast(t, src=0, group=group)
-    return t.cpu().numpy().copy()
+    out = t.cpu().numpy().copy()
+    if out[128] != 1:
+        raise err if err else RuntimeError("rank 0 could not create an RCCL unique id")
+    return out[:128].copy()
 
 
 class DistSolver:
@@ -267,6 +275,10 @@ class DistSolver:
     def p2p_error(self):
         return self._lib.cgamd_dist_p2p_error(self.handle)
 
+    def comm_ranks(self):
+        """ranks of the RCCL communicator, as RCCL reports them (0: no communicator)"""
+        return int(self._lib.cgamd_dist_comm_ranks(self.handle))
+
     def set_rhs(self, b_local, x0_local=None):
         check(self._lib.cgamd_dist_set_rhs(self.handle, ptr(b_local), ptr(x0_local)))
         self.iterations = 0
@@ -347,39 +359,85 @@ def _cdev(dist, dev):
     return dev if dist.get_backend() == "nccl" else "cpu"
 
 
+def _all_ok(flag, dist, torch, dev):
+    """logical AND of `flag` over all ranks (one all-reduce: every rank must call it the same number of times)"""
+    t = torch.tensor([1.0 if flag else 0.0], device=_cdev(dist, dev))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item()) == 1.0
+
+
 def _run_dist(solver, b, warmup, steps, dist, torch, dev):
+    """Time `steps` iterations after `warmup` untimed ones, bracketed by barrier + synchronize on both sides.
+    -> (max over ranks of the wall time, every rank got through, local error text or None).
+    A local failure (an exception of this rank's C loop) never skips a collective: the barriers and the final
+    all-reduce run on every rank whatever happened in between, so one failing rank cannot leave the others hanging."""
     import time
-    solver.set_rhs(b, None)
-    solver.iterate(warmup)
-    solver.synchronize()
+    err = None
+    try:
+        solver.set_rhs(b, None)
+        solver.iterate(warmup)
+        solver.synchronize()
+    except Exception as e:      # noqa: BLE001 -- reported collectively below
+        err = f"{type(e).__name__}: {e}"
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    solver.iterate(steps)
-    solver.synchronize()
+    if err is None:
+        try:
+            solver.iterate(steps)
+            solver.synchronize()
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=_cdev(dist, dev))
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    return float(tmax.item())
+    red = torch.tensor([dt, 0.0 if err is None else 1.0], dtype=torch.float64, device=_cdev(dist, dev))
+    dist.all_reduce(red, op=dist.ReduceOp.MAX)
+    return float(red[0].item()), float(red[1].item()) == 0.0, err
+
+
+def _history_check(solver, ref_hist, entries=9):
+    """(ok, text): no peer-to-peer time-out, finite history, first `entries` residuals equal to the single-GPU ones to 1e-9"""
+    try:
+        perr = solver.p2p_error()
+        h = solver.history()
+    except Exception as e:      # noqa: BLE001
+        return False, f"{type(e).__name__}: {e}"
+    if perr != 0:
+        return False, f"peer-to-peer protocol time-out (error word {perr})"
+    if not np.all(np.isfinite(h)):
+        return False, "non-finite residual history"
+    if ref_hist is not None:
+        k = min(entries, len(ref_hist))
+        if len(h) < k:
+            return False, f"history has {len(h)} entries, expected >= {k}"
+        dev_rel = float(np.max(np.abs(h[:k] - ref_hist[:k]) / np.abs(ref_hist[:k])))
+        if not dev_rel < 1e-9:
+            return False, f"residual history deviates from the single-GPU solver by {dev_rel:.3e} (> 1e-9)"
+    return True, ""
+
+
+DIST_MODES = ("p2p4", "p2p4+graph", "p2p", "p2p+graph", "rccl+graph", "rccl")
 
 
 def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, rank, world):
     """bench.py --gpus N (N > 1): the SAME N=10M system, rows partitioned into N contiguous z-slabs.
 
-    Candidate loops, each validated on a short run before it may be timed -- its residual history must match, to 1e-9,
-    the history of the SAME global system solved by the single-GPU solver, which every rank computes for itself (the whole
-    system fits one GPU; no communication library is involved in the check):
+    Candidate loops (all of them are built, validated and trialled; RCCL is always timed next to the peer-to-peer loops):
       p2p4        peer-to-peer mailboxes over xGMI, FOUR launches per iteration: the halo push and the wait ride inside
                   the SpMV launch (halo read in place), the r.r all-reduce inside the aypx launch; plain launches
       p2p4+graph  the same, replayed from a hipGraph
       p2p         peer-to-peer with separate push / unpack / all-reduce launches (seven per iteration)
       p2p+graph   the same from a hipGraph
-      rccl+graph  RCCL send/recv + all-reduce captured in a hipGraph      } tried only when no peer-to-peer loop
-      rccl        RCCL, plain launches, exchange overlapped               } validated, or with CG_DIST_TRY_RCCL=1
-    The fastest valid candidate (short trial, max over ranks) runs the timed region.  If the C loop is
-    unavailable altogether the Python loop over torch.distributed drives the same HIP kernels."""
+      rccl+graph  RCCL send/recv + all-reduce captured in a hipGraph
+      rccl        RCCL, plain launches, exchange overlapped with the interior row blocks
+    Validation before a loop may be timed: 8 iterations whose residual history must match, to 1e-9, the history of the SAME
+    global system solved by the single-GPU solver, which every rank computes for itself (the whole system fits one GPU; no
+    communication library is involved in the check).  The valid loops run a short trial; the fastest runs the timed
+    region, AFTER which it is validated again (no protocol time-out on any rank, finite history, first residuals equal
+    to the reference): a loop that fails that check is dropped and the next fastest runs the timed region instead, so
+    `value` never comes from a run that went wrong.  If no C loop survives, the Python loop over torch.distributed
+    drives the same HIP kernels."""
     import time
     n = nx * ny * nz
     ranges = row_ranges(n, world)
@@ -390,10 +448,16 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
     tdt = pkg.generators.torch_dtype(dtype)
     b = torch.full((plan.n_local,), 5.0, dtype=tdt, device=dev)          # main.c:44: b = (r+1)*5, x0 = 0
     torch.cuda.synchronize()
-    notes, trials = [], {}
+    notes, trials, rejected, solvers = [], {}, {}, {}
     skip = getattr(args, "dist_skip", "").split(",")
-    want = [m for m in ("p2p4", "p2p4+graph", "p2p", "p2p+graph") if m not in skip]
-    want_rccl = [m for m in ("rccl+graph", "rccl") if m not in skip and dist.get_backend() == "nccl"]
+    have_rccl = dist.get_backend() == "nccl"
+    want = [m for m in DIST_MODES if m not in skip and (have_rccl or not m.startswith("rccl"))]
+    if not have_rccl:
+        rejected["rccl+graph"] = rejected["rccl"] = "ranks bootstrap over gloo (they share a GPU): RCCL refuses duplicate devices"
+    rccl_ranks = None
+
+    def all_ok(flag):
+        return _all_ok(flag, dist, torch, dev)
 
     def make(mode):
         flags = _lib.DIST_GRAPH if mode.endswith("+graph") else 0
@@ -401,14 +465,19 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
             if not mode.startswith("p2p4"):
                 flags |= _lib.DIST_P2P_STAGED | _lib.DIST_NO_OVERLAP
             return DistSolver(ctx, plan, indptr, data, dtype, flags=flags, comm="p2p")
-        return DistSolver(ctx, plan, indptr, data, dtype, unique_id=broadcast_unique_id(rank, device=dev), flags=flags)
+        uid = broadcast_unique_id(rank, device=dev)      # collective; raises on every rank when rank 0 could not make one
+        return DistSolver(ctx, plan, indptr, data, dtype, unique_id=uid, flags=flags)
 
-    def all_ok(flag):
-        t = torch.tensor([1.0 if flag else 0.0], device=_cdev(dist, dev))
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return float(t.item()) == 1.0
+    def drop(mode, solver, why):
+        rejected[mode] = why
+        notes.append(f"{mode}: {why}")
+        if solver is not None:
+            try:
+                solver.close()
+            except Exception:   # noqa: BLE001
+                pass
 
-    ref_hist, best, best_mode, best_t = None, None, None, None
+    ref_hist = None
     try:    # reference history: the whole system on this rank's GPU with the single-GPU solver
         from . import cl
         ip_f, ix_f, da_f = pkg.generators.laplace3d(ctx, nx, ny, nz, dtype=dtype)
@@ -421,58 +490,56 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
         ref.close()
         del ip_f, ix_f, da_f, b_f, ref
         torch.cuda.empty_cache()
-    except Exception as e:
+    except Exception as e:      # noqa: BLE001
         notes.append(f"single-GPU reference history unavailable: {type(e).__name__}: {e}")
+    if not all_ok(ref_hist is not None):
+        ref_hist = None         # every rank validates the same way or none does
 
-    def candidates():
-        for m in want:
-            yield m
-        if want_rccl and (best is None or os.environ.get("CG_DIST_TRY_RCCL", "0") == "1"):
-            for m in want_rccl:
-                yield m
-
-    for mode in candidates():
-        solver = None
+    for mode in want:
+        solver, err = None, None
         try:
             solver = make(mode)
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        if not all_ok(err is None):
+            drop(mode, solver, "could not be created" + (f" ({err})" if err else " on another rank"))
+            continue
+        good, why = False, ""
+        try:
             solver.set_rhs(b, None)
             solver.iterate(8)
-            h = solver.history()
-            good = solver.p2p_error() == 0 and np.all(np.isfinite(h))
-            dev_rel = None
-            if ref_hist is not None:
-                dev_rel = float(np.max(np.abs(h - ref_hist) / np.abs(ref_hist))) if len(h) == len(ref_hist) else float("inf")
-                good = good and dev_rel < 1e-9
-            if not all_ok(good):
-                notes.append(f"{mode}: validation against the single-GPU residual history failed "
-                             f"(p2p error {solver.p2p_error()}, max rel deviation {dev_rel})")
-                solver.close()
-                continue
-            t = _run_dist(solver, b, 5, 30, dist, torch, dev)
-            trials[mode] = 30.0 / t
-            if best_t is None or t < best_t:
-                if best is not None:
-                    best.close()
-                best, best_mode, best_t = solver, mode, t
-            else:
-                solver.close()
-        except Exception as e:
-            notes.append(f"{mode}: {type(e).__name__}: {e}")
-            try:
-                if solver is not None:
-                    solver.close()
-            except Exception:
-                pass
-            if not all_ok(False):
-                pass
-    if best is not None:
-        mode = best_mode
-        dt = _run_dist(best, b, args.warmup, args.steps, dist, torch, dev)
-        hist = best.history()
-        if best.p2p_error() != 0:
-            notes.append("peer-to-peer protocol reported a timeout during the timed run")
-        best.close()
-    else:   # still the HIP kernels through the C ABI, only the loop moves to Python
+            good, why = _history_check(solver, ref_hist)
+        except Exception as e:  # noqa: BLE001
+            why = f"{type(e).__name__}: {e}"
+        if not all_ok(good):
+            drop(mode, solver, "validation run failed" + (f": {why}" if why else " on another rank"))
+            continue
+        t, ok, err = _run_dist(solver, b, 5, 30, dist, torch, dev)
+        if not ok:
+            drop(mode, solver, "trial run failed" + (f": {err}" if err else " on another rank"))
+            continue
+        trials[mode] = 30.0 / t
+        solvers[mode] = solver
+        if mode.startswith("rccl") and rccl_ranks is None:
+            rccl_ranks = solver.comm_ranks()
+
+    mode, dt, hist = None, None, None
+    for cand in sorted(trials, key=lambda m: -trials[m]):
+        solver = solvers[cand]
+        t, ok, err = _run_dist(solver, b, args.warmup, args.steps, dist, torch, dev)
+        good, why = (False, err or "another rank failed") if not ok else _history_check(solver, ref_hist)
+        if all_ok(good):
+            mode, dt, hist = cand, t, solver.history()
+            break
+        rejected[cand] = "timed run failed its check" + (f": {why}" if why else " on another rank")
+        notes.append(f"{cand}: {rejected[cand]}; falling through to the next candidate")
+    for solver in solvers.values():
+        try:
+            solver.close()
+        except Exception:       # noqa: BLE001
+            pass
+    validated = mode is not None
+    if mode is None:   # still the HIP kernels through the C ABI, only the loop moves to Python
         notes.append("no C loop available; Python loop over torch.distributed")
         mode = "python-loop"
         ops = HipOps(ctx, plan, indptr, data, dtype)
@@ -480,8 +547,9 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
         _, h8 = cg_loop(ops, comm, plan, b, torch.zeros_like(b), 8)
         if ref_hist is not None:
             dev8 = float(np.max(np.abs(h8.cpu().numpy() - ref_hist) / np.abs(ref_hist)))
+            validated = dev8 < 1e-9
             notes.append(f"python loop: max rel deviation from the single-GPU residual history over 8 iterations = {dev8:.3e}"
-                         + ("" if dev8 < 1e-9 else "  -- RESULT NOT VALIDATED"))
+                         + ("" if validated else "  -- RESULT NOT VALIDATED"))
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -515,5 +583,6 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
         "roofline": {"bound": "hbm", "kernel": "whole CG iteration (all ranks)", "achieved": iter_bytes * it_s / 1e9,
                      "peak": 8000.0 * world, "unit": "GB/s", "frac": iter_bytes * it_s / 1e9 / (8000.0 * world),
                      "traffic": None},
-        "loop_trials_it_per_s": trials, "notes": notes,
+        "backend": mode, "backend_validated": bool(validated), "backend_rejected": rejected,
+        "loop_trials_it_per_s": trials, "rccl_ranks": rccl_ranks, "notes": notes,
     }

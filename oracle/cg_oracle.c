@@ -129,6 +129,41 @@ int cgo_sub(int dtype, int size, const void *a, const void *b, void *result, int
              vsub_c64(size, a, b, result, nRHS), vsub_c128(size, a, b, result, nRHS))
 }
 
+/* 3-D 7-point Laplacian, x fastest, Dirichlet, diag 6 / off-diag -1 (SURVEY 8d "M"; no reference generator exists for
+ * it): the full-size input of bench.py's cpu_baseline leg, built in parallel so that the N=10M system costs a fraction
+ * of a second.  Same matrix as oracle/cg_numpy.py::laplace3d (tests/test_oracle_golden.py compares them).
+ * aPointers: nx*ny*nz+1 ints; aValues/aCols sized from the closed form 7n - 2(nx ny + ny nz + nx nz).  Real types only. */
+int cgo_laplace3d(int dtype, int nx, int ny, int nz, void *aValues, int *aPointers, int *aCols) {
+    if ((dtype != 0 && dtype != 1) || nx < 1 || ny < 1 || nz < 1) return -1;
+    const long long pl = (long long)nx * ny, n = pl * nz;
+    aPointers[0] = 0;
+    /* entries before row i, closed form: 7 i - (missing neighbours of rows < i) */
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i <= n; i++) {
+        const long long x0 = (i + nx - 1) / nx, x1 = i / nx;
+        const long long full = i / pl, rem = i % pl;
+        const long long y0 = full * nx + (rem < nx ? rem : nx);
+        const long long y1 = full * nx + (rem > pl - nx ? rem - (pl - nx) : 0);
+        const long long z0 = i < pl ? i : pl, z1 = i > n - pl ? i - (n - pl) : 0;
+        aPointers[i] = (int)(7 * i - (x0 + x1 + y0 + y1 + z0 + z1));
+    }
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < n; i++) {
+        const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / pl);
+        long long p = aPointers[i];
+#define PUT(c, v) do { aCols[p] = (int)(c); if (dtype == 0) ((float *)aValues)[p] = (float)(v); else ((double *)aValues)[p] = (v); ++p; } while (0)
+        if (iz > 0) PUT(i - pl, -1.0);
+        if (iy > 0) PUT(i - nx, -1.0);
+        if (ix > 0) PUT(i - 1, -1.0);
+        PUT(i, 6.0);
+        if (ix < nx - 1) PUT(i + 1, -1.0);
+        if (iy < ny - 1) PUT(i + nx, -1.0);
+        if (iz < nz - 1) PUT(i + pl, -1.0);
+#undef PUT
+    }
+    return 0;
+}
+
 /* Same argument order as the reference cg() (clcg.h:3-5: values, b, pointers,
  * cols, x) plus dtype in front and history/mode behind. */
 int cgo_cg(int dtype, int size, int nonZeros, const void *aValues, const void *b,
