@@ -43,6 +43,9 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "alpha_two_level") g_tune.alpha_two_level = value;
     else if (k == "spmv_unroll") g_tune.spmv_unroll = value;
     else if (k == "spmm_rb") g_tune.spmm_rb = value;
+    else if (k == "spmm_wgs") g_tune.spmm_wgs = value;
+    else if (k == "spmm_tq") g_tune.spmm_tq = value;
+    else if (k == "spmm_rowmajor") g_tune.spmm_rowmajor = value;
     else if (k == "spmv_lds_pad") g_tune.spmv_lds_pad = value;
     else if (k == "spmv_policy") g_tune.spmv_policy = value;
     else if (k == "vec_nt") g_tune.vec_nt = value;

@@ -37,13 +37,14 @@ struct SpmvPlan {
     int max_span = 0;    // largest 4-aligned nnz span of a kBlock-row slice (0 = unknown -> generic kernel)
     int kind = 0;        // kernel chosen by finalize_spmv_plan (0 generic, 5 row-block, 6 its SpMM form, 7 chunked row-block)
     int chunk_span[3] = {0, 0, 0};   // largest 4-aligned span of a 128 / 64 / 32-row slice
+    int max_quad = 0;    // most non-zeros in 4 consecutive rows starting at a multiple of 4 (row-major SpMM: K-steps per quad)
     int lpr = 1;         // kind 7: lanes per row (2, 4, 8) = chunks per 256-row block
     int n_partials = 0;  // fused-dot partials per RHS written by that kernel
     int nt = 1;          // matrix stream loaded non-temporally (finalize_spmv_plan: off when the matrix fits the Infinity Cache)
     int vec_nt = 3;      // axpy2_dot streaming hints (see Tuning::vec_nt), resolved by finalize_spmv_plan
 };
 SpmvPlan make_spmv_plan(int n);
-// fills plan->max_span / chunk_span from the matrix structure; synchronises `st`; scratch_dev: >= 16 bytes
+// fills plan->max_span / chunk_span from the matrix structure; synchronises `st`; scratch_dev: >= 32 bytes
 int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan);
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols);
 constexpr int kChunkBytes = 32 * 1024;      // kind 7: preferred LDS chunk slice (4-5 work-groups per CU)
@@ -61,6 +62,10 @@ struct Tuning {
     int spmm_ynt = 0;       // experiment: SpMM stores y non-temporally
     int spmm_group = 0;     // SpMM: right-hand sides per register group (0 = equal-width groups of at most 8, 4 for complex128)
     int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = all in one launch)
+    int spmm_wgs = 0;       // row-major SpMM sweep: work-groups per XCD (0 = 64: 256 strips of 16 rows open per XCD)
+    int spmm_tq = 0;        // fp64 row-major SpMM: 8 = always the generic 8-K-steps-per-quad instance (experiment)
+    int spmm_rowmajor = 1;  // solvers with 16/32/64 right-hand sides (f32, f64; complex64: 16/32) keep the block row-major
+                            // and multiply on the matrix cores (0 = RHS-major VALU kernel as for every other width)
     int vec_skew = 0;       // bytes added to the pitch between the solver's vectors (multiple of 16)
     int vec_nt = -1;        // -1 auto (by working-set size, finalize_spmv_plan); axpy2_dot: bit0 = x loaded/stored non-temporally (touched once per iteration), bit1 = q loaded
                             // non-temporally (its last use): d and r, which are re-read, keep the caches; measured -10..-22 us/iteration
@@ -139,10 +144,21 @@ int launch_aypx_beta(int dtype, int n, const void *x, void *y, long long ld, con
 int launch_reduce_to_acc(int dtype, const void *partials, int grid, int nrhs, void *out, hipStream_t st);
 int launch_pack(int dtype, int count, const int *index, const void *v, void *out, hipStream_t st);
 
-// Y[n][nrhs] = A X[ncols][nrhs], ROW-MAJOR right-hand-side block, nrhs in {16, 32}, f32/f64, on the matrix cores;
-// plan.max_span must be known and the slice must fit LDS.  [rows][cols] -> [cols][rows] transpose for the layout change.
-int launch_spmm_mfma(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr,
-                     const int *cols, const void *x, void *y, int nrhs, hipStream_t st);
+// ---- row-major multi-RHS path (rowmajor.hip): the RHS block is X[n][nrhs], element (i, r) at i*nrhs + r ----------------
+// Y = A X on the matrix cores (+ per-RHS d.q partials [nrhs][spmm_rm_grid(n)] in accumulator precision when partials != 0,
+// the dot being x.y); f64 with 16 / 32 right-hand sides, f32 with 16 / 32 / 64, complex64 with 16 / 32; any CSR matrix
+bool spmm_rm_supported(int dtype, int nrhs);
+int spmm_rm_grid(int n);
+// max_quad: most non-zeros in 4 consecutive rows (SpmvPlan::max_quad; 0 = unknown), picks the fp64 kernel's K-steps per quad
+int launch_spmm_rm(int dtype, int n, long long nnz, const void *vals, const int *ptr, const int *cols, const void *x, void *y,
+                   int nrhs, void *partials, int max_quad, hipStream_t st);
+// vector kernels with per-column scalars; partials[r * grid + wg]
+int rm_vec_grid(long long total_elems, int dtype);
+int launch_rm_dot(int dtype, int n, int nrhs, const void *a, const void *b, void *partials, int grid, hipStream_t st);
+int launch_rm_axpy_dot(int dtype, int n, int nrhs, const void *q, void *r, const void *alpha, void *partials, int grid, hipStream_t st);
+int launch_rm_aypx_x(int dtype, int n, int nrhs, const void *r, void *d, void *x, const void *alpha, const void *beta, int grid,
+                     hipStream_t st);
+// [rows][cols] -> [cols][rows]: RHS-major (the reference ABI) <-> row-major
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);
 
 // ---- peer-to-peer backend (kernels.hip "Peer-to-peer communication over xGMI") ----------------------------

@@ -3,7 +3,7 @@
 //   spmv_rowblock_kernel          CSR SpMV (replaces reference kernel/{real,complex}/spmv.cl) fused with the d.q partial
 //                                 reduction (reference vdot.cl + host sum clcg.c:317-324): matrix slice through LDS, one lane
 //                                 per row; _chunked: 2/4/8 lanes per row for denser rows; _p2p: with the halo push / wait
-//   spmm_rowblock_kernel          the same for nRHS > 1 (RHS-major, the ABI layout); spmm_mfma_kernel: row-major, matrix cores
+//   spmm_rowblock_kernel          the same for nRHS > 1 (RHS-major, the ABI layout); the row-major matrix-core path is rowmajor.hip
 //   spmv_stream_kernel            generic chunked CSR stream (huge rows, unaligned pointers)
 //   dot_partials_kernel           reference kernel/{real,complex}/vdot.cl (partials stay on the device)
 //   ewise_kernel                  reference kernel/{real,complex}/{axpy,aypx,sub}.cl
@@ -21,68 +21,11 @@
 // run (atomics only hand out tickets).
 #include "cgamd_internal.h"
 #include "device_types.h"
+#include "device_mem.h"
 
 #include <algorithm>
 
 namespace cgamd {
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// ---- 16-byte packs -----------------------------------------------------------------------------
-template <typename T> struct Pack {
-    static constexpr int N = 16 / sizeof(T);
-    T v[N];
-} __attribute__((aligned(16)));
-
-template <typename T> CG_DEV Pack<T> ld_pack(const T *p) { return *reinterpret_cast<const Pack<T> *>(p); }
-template <typename T> CG_DEV void st_pack(T *p, const Pack<T> &v) { *reinterpret_cast<Pack<T> *>(p) = v; }
-// non-temporal forms for data that is touched once per iteration (x) or for the last time (q): keeps the
-// vectors that are re-read (d, r) in L2 / Infinity Cache
-template <typename T> CG_DEV Pack<T> ld_pack_nt(const T *p) {
-    union { u32x4 raw; Pack<T> v; } u;
-    u.raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return u.v;
-}
-template <typename T> CG_DEV void st_pack_nt(T *p, const Pack<T> &v) {
-    union { u32x4 raw; Pack<T> v; } u;
-    u.v = v;
-    __builtin_nontemporal_store(u.raw, reinterpret_cast<u32x4 *>(p));
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-CG_DEV void st_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
-CG_DEV void st_nt(double *p, double v) { __builtin_nontemporal_store(v, p); }
-CG_DEV void st_nt(float2 *p, float2 v) { f32x2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<f32x2 *>(p)); }
-CG_DEV void st_nt(double2 *p, double2 v) { f64x2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<f64x2 *>(p)); }
-
-// 4 consecutive values by 16-byte loads, register to register (a union of ext-vectors and HIP vector structs
-// sent the complex128 instance through scratch memory: 2x slower).  NT = non-temporal.
-template <typename V, bool NT> CG_DEV V ld16(const void *p) {
-    return NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(p)) : *reinterpret_cast<const V *>(p);
-}
-template <bool NT> CG_DEV void ld4(const float *p, float (&o)[4]) {
-    const f32x4 w = ld16<f32x4, NT>(p);
-    o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = w.w;
-}
-template <bool NT> CG_DEV void ld4(const double *p, double (&o)[4]) {
-    const f64x2 a = ld16<f64x2, NT>(p), b = ld16<f64x2, NT>(p + 2);
-    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
-}
-template <bool NT> CG_DEV void ld4(const float2 *p, float2 (&o)[4]) {
-    const f32x4 a = ld16<f32x4, NT>(p), b = ld16<f32x4, NT>(p + 2);
-    o[0] = make_float2(a.x, a.y); o[1] = make_float2(a.z, a.w); o[2] = make_float2(b.x, b.y); o[3] = make_float2(b.z, b.w);
-}
-template <bool NT> CG_DEV void ld4(const double2 *p, double2 (&o)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f64x2 a = ld16<f64x2, NT>(p + i);
-        o[i] = make_double2(a.x, a.y);
-    }
-}
-template <typename T> CG_DEV void ld4_nt(const T *p, T (&out)[4]) { ld4<true>(p, out); }
 
 // =================================================================================================
 // SpMV / SpMM, CSR-stream: a work-group owns BLOCK consecutive rows at a time.  Their non-zeros are one
@@ -623,94 +566,6 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowblock_kernel(SpmvArgs<T> a) {
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// SpMM on the matrix cores for a ROW-MAJOR block of right-hand sides, Y[N][R] = A * X[N][R], R = 16 or 32
-// (BASELINE config 4: "MFMA tall-B tile path").  In row-major form the operand gathered for one non-zero,
-// X[col][0:R], is a dense contiguous row (128/256 B), and the product over a 16-row strip of A is a real
-// contraction:   Y_tile(16 x 16) += S(16 x 4) * Xg(4 x 16)
-// where the 4 K-slots are 4 consecutive non-zeros of the strip (CSR order), Xg[k][n] = X[col_k][n0+n] is the
-// tall dense B tile, and S[m][k] = a_k if non-zero k belongs to row m, else 0 (each lane decides with its own
-// row's [s,e) bounds: two compares, no search).  One v_mfma_{f64,f32}_16x16x4 per 4 non-zeros per 16 columns
-// of X replaces the LDS/shuffle row reduction; accumulation order inside a row is CSR order (the MFMA adds
-// its 4 K-slots in k order, slots of other rows contribute exact zeros).
-// Only 1 of the 16 S entries of a slot is non-zero, so the matrix pipe runs at 1/16 useful rate; that is
-// affordable only because the kernel is bound by the X gather, not by FLOPs.  A non-finite X entry reaches all
-// 16 rows of its strip (0 * inf); CG with non-finite iterates is lost anyway.
-// Work-group = 256 rows = 16 strips, 4 per wave; the block's matrix slice goes through LDS as in
-// spmv_rowblock_kernel.  Lane maps: A/B one element per lane, A[m=l&15][k=l>>4], B[k=l>>4][n=l&15];
-// C/D f64: row = (l>>4) + 4*reg, f32: row = 4*(l>>4) + reg (cdna_hip_programming.md §3).
-// -------------------------------------------------------------------------------------------------
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-CG_DEV f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-CG_DEV f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-template <typename T> struct Mfma;
-template <> struct Mfma<double> { using acc = f64x4; static CG_DEV int row(int lane, int reg) { return (lane >> 4) + 4 * reg; } };
-template <> struct Mfma<float> { using acc = f32x4; static CG_DEV int row(int lane, int reg) { return 4 * (lane >> 4) + reg; } };
-
-template <typename T> struct SpmmMfmaArgs {
-    int n, nrhs, row_blocks, cap, cycle;
-    long long nnz;
-    const T *vals;
-    const int *ptr, *cols;
-    const T *x;   // [n_cols][nrhs] row-major
-    T *y;         // [n][nrhs] row-major
-};
-
-template <typename T, int BLOCK, int NH>
-__global__ __launch_bounds__(BLOCK) void spmm_mfma_kernel(SpmmMfmaArgs<T> a) {
-    using Acc = typename Mfma<T>::acc;
-    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
-    T *sv = reinterpret_cast<T *>(dyn_smem);
-    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));
-    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
-    const int rbm = rowblock_of(blockIdx.x, a.row_blocks, a.cycle);
-    if (rbm < 0) return;
-    const int r0 = rbm * BLOCK;
-    const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
-    const int cfirst = p0 & ~3;
-    stage_slice<T, BLOCK, true, -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
-    __syncthreads();
-    const int m = lane & 15, kq = lane >> 4;
-#pragma unroll 1
-    for (int tt = 0; tt < 4; ++tt) {                                  // 64 rows per wave = 4 strips of 16
-        const int rowbase = r0 + wave * 64 + tt * 16;
-        if (rowbase >= a.n) break;                                     // wave-uniform
-        const int s_m = a.ptr[min(rowbase + m, a.n)] - cfirst;
-        const int e_m = a.ptr[min(rowbase + m + 1, a.n)] - cfirst;
-        const int t_begin = __shfl(s_m, 0, kWave);                   // strip = [start of row 0, end of row 15)
-        const int t_end = __shfl(e_m, 15, kWave);
-        Acc acc[NH];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) acc[h] = Acc{0, 0, 0, 0};
-        constexpr int U = 4;                                           // K-steps whose X rows are in flight together
-        for (int j0 = t_begin; j0 < t_end; j0 += 4 * U) {
-            T a_op[U], bv[U][NH];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = j0 + 4 * u + kq;
-                const int jc = min(j, t_end - 1);                     // clamped slot: a valid LDS entry of this strip
-                const T v = sv[jc];
-                const int c = sc[jc];
-                a_op[u] = (j >= s_m && j < e_m) ? v : (T)0;            // j >= t_end never lies inside a row
-                const T *xr = a.x + (long long)c * a.nrhs + m;
-#pragma unroll
-                for (int h = 0; h < NH; ++h) bv[u][h] = xr[h * 16];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int h = 0; h < NH; ++h) acc[h] = mfma16(a_op[u], bv[u][h], acc[h]);
-        }
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = rowbase + Mfma<T>::row(lane, reg);
-                if (row < a.n) a.y[(long long)row * a.nrhs + h * 16 + m] = acc[h][reg];
-            }
-    }
-}
-
 // [rows][cols] -> [cols][rows]: RHS-major (the reference ABI, nRHS x N) <-> row-major (N x nRHS)
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, const T *__restrict__ in, T *__restrict__ out) {
@@ -739,8 +594,9 @@ template <int BLOCK> __global__ void rowblock_halo_flag_kernel(int n, const int 
 
 // largest (4-aligned) non-zero span of any BLOCK-row slice: decides whether the fast path applies
 template <int BLOCK> __global__ void spmv_span_kernel(int n, const int *__restrict__ ptr, int row_blocks, int *out) {
-    // out[0]: span of BLOCK-row slices; out[1..3]: of BLOCK/2, BLOCK/4, BLOCK/8-row slices (chunked row-block kernel)
-    int m[4] = {0, 0, 0, 0};
+    // out[0]: span of BLOCK-row slices; out[1..3]: of BLOCK/2, BLOCK/4, BLOCK/8-row slices (chunked row-block kernel);
+    // out[4]: most non-zeros in 4 consecutive rows starting at a multiple of 4 (row-major SpMM)
+    int m[4] = {0, 0, 0, 0}, mq = 0;
     for (int rb = blockIdx.x * blockDim.x + threadIdx.x; rb < row_blocks; rb += gridDim.x * blockDim.x) {
 #pragma unroll
         for (int lv = 0; lv < 4; ++lv) {
@@ -752,10 +608,12 @@ template <int BLOCK> __global__ void spmv_span_kernel(int n, const int *__restri
                 m[lv] = max(m[lv], p1 - (p0 & ~3));
             }
         }
+        for (int ra = rb * BLOCK; ra < min(rb * BLOCK + BLOCK, n); ra += 4) mq = max(mq, ptr[min(ra + 4, n)] - ptr[ra]);
     }
 #pragma unroll
     for (int lv = 0; lv < 4; ++lv)
         if (m[lv] > 0) atomicMax(out + lv, m[lv]);
+    if (mq > 0) atomicMax(out + 4, mq);
 }
 
 // =================================================================================================
@@ -1985,16 +1843,17 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
 int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan) {
     // (1) largest slice span -> which kernels apply, LDS size
     const int row_blocks = (n + kBlock - 1) / kBlock;
-    CG_HIP(hipMemsetAsync(scratch_dev, 0, 4 * sizeof(int), st));
+    CG_HIP(hipMemsetAsync(scratch_dev, 0, 5 * sizeof(int), st));
     int g = (row_blocks + 255) / 256;
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL((spmv_span_kernel<kBlock>), dim3(g), dim3(256), 0, st, n, ptr_dev, row_blocks, scratch_dev);
     if (int rc = check_launch("spmv_span")) return rc;
-    int spans[4] = {0, 0, 0, 0};
-    CG_HIP(hipMemcpyAsync(spans, scratch_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    int spans[5] = {0, 0, 0, 0, 0};
+    CG_HIP(hipMemcpyAsync(spans, scratch_dev, 5 * sizeof(int), hipMemcpyDeviceToHost, st));
     CG_HIP(hipStreamSynchronize(st));
     plan->max_span = spans[0];
     for (int lv = 0; lv < 3; ++lv) plan->chunk_span[lv] = spans[lv + 1];
+    plan->max_quad = spans[4];
     (void)cols_dev;
     return CGAMD_OK;
 }
@@ -2269,26 +2128,6 @@ template <typename T> static int pack_impl(int count, const int *index, const vo
 int launch_pack(int dtype, int count, const int *index, const void *v, void *out, hipStream_t st) {
     if (count <= 0) return CGAMD_OK;
     CG_DISPATCH(dtype, pack_impl, count, index, v, out, st);
-}
-
-template <typename T>
-static int spmm_mfma_impl(const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
-                          const void *x, void *y, int nrhs, hipStream_t st) {
-    SpmmMfmaArgs<T> a;
-    a.n = n; a.nrhs = nrhs; a.row_blocks = plan.row_blocks; a.cap = (plan.max_span + 3) & ~3; a.nnz = nnz;
-    a.vals = (const T *)vals; a.ptr = ptr; a.cols = cols; a.x = (const T *)x; a.y = (T *)y;
-    const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
-    a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
-    dim3 g(rowblock_grid(plan.row_blocks, a.cycle)), b(kBlock);
-    if (nrhs == 16) hipLaunchKernelGGL((spmm_mfma_kernel<T, kBlock, 1>), g, b, lds, st, a);
-    else hipLaunchKernelGGL((spmm_mfma_kernel<T, kBlock, 2>), g, b, lds, st, a);
-    return check_launch("spmm_mfma");
-}
-int launch_spmm_mfma(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr,
-                     const int *cols, const void *x, void *y, int nrhs, hipStream_t st) {
-    if (dtype == CGAMD_F64) return spmm_mfma_impl<double>(plan, n, nnz, vals, ptr, cols, x, y, nrhs, st);
-    if (dtype == CGAMD_F32) return spmm_mfma_impl<float>(plan, n, nnz, vals, ptr, cols, x, y, nrhs, st);
-    return fail(CGAMD_ERR_INVALID, "spmm_mfma: real value types only (f32, f64)");
 }
 
 template <typename T> static int transpose_impl(int rows, int cols, const void *in, void *out, hipStream_t st) {

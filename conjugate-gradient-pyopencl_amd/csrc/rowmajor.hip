@@ -1,0 +1,740 @@
+// Row-major multi-RHS path (BASELINE config 4, "MFMA tall-B tile path"): the block of right-hand sides is kept as
+// X[N][R] (element i of RHS r at i*R + r) through the whole CG loop, so that the operand gathered for one non-zero,
+// X[col][0:R], is one dense contiguous row (64...256 B) and the product over a strip of rows is a real contraction on the
+// matrix cores.  Replaces reference kernel/{real,complex}/spmv.cl with N_RHS > 1 (+ vdot.cl, axpy.cl, aypx.cl on the
+// same layout); the reference's ABI layout (RHS-major, spmv.cl:25,48) is converted once per solve at the boundary
+// (set_rhs / get_x), not per iteration.
+//
+//   spmm_rm_mfma_kernel   Y = A X (+ per-RHS d.q partials), CSR A, f32 / f64 / complex64, R*(1|2) in {16, 32, 64} real columns
+//   rm_dot / rm_axpy_dot / rm_aypx_x   the vector kernels of the fused loop with per-column scalars
+//
+// SpMM design (MI355X).  Measured problem of the round-1 kernels (profiles/r1/pmc_spmm_c4_summary.txt): X was fetched
+// 2.75x because each XCD had 256 work-groups x 256 rows = 16 MB of X rows open at once, far beyond its 4 MB L2, so a
+// line brought in for row i was gone before rows i +- nx asked for it.  Here:
+//   * the unit of work is a STRIP of 16 rows handled by ONE wave; waves are persistent and every XCD sweeps its own
+//     contiguous eighth of the strips in order (wave w of the XCD takes strips w, w + W, w + 2W, ...), so the rows open
+//     per XCD are W x 16 (W = waves per XCD; 512 -> 2 MB of fp64 X rows at R = 32): the +-nx reuse falls inside L2;
+//   * a wave keeps a whole strip's gathers in flight (up to UB K-steps of 4 non-zeros = 64 lanes x 16 B each), and
+//     prefetches the NEXT strip's row pointers and matrix entries (registers -> wave-private LDS, no work-group barrier
+//     anywhere in the loop), so a strip costs one memory round trip, not three;
+//   * fp64 uses v_mfma_f64_4x4x4_4b (4 blocks = 4 quads of right-hand sides, 4 rows x 4 non-zeros each): the selection
+//     matrix S[row][k] = a_k if non-zero k lies in that row has ONE non-zero per column, so the 16x16x4 form wastes
+//     15/16 of a 64-cycle instruction, the 4x4x4 form 3/4 of a ~20-cycle one (scripts/microbench/mfma_probe.hip:
+//     29.8 ns vs 9.9 ns per instruction, lane maps A[b][i][k] @ 16k+4b+i, B[b][k][j] @ 16k+4b+j, D[b][i][j] @ 16i+4b+j);
+//     f32 and complex64 use v_mfma_f32_16x16x4 (32 cycles);
+//   * column permutation: lane (k = l>>4, m = l&15) loads NH consecutive values X[col_k][NH*m .. NH*m+NH-1] with one
+//     8/16-byte load and MFMA h uses component h, so MFMA h produces the real columns {NH*m + h}: every load
+//     instruction of a wave covers 4 whole X rows and every store instruction 4 whole Y rows;
+//   * complex64: the row is 2R interleaved floats; a lane holds whole (re, im) pairs, so Y += a_re * X + a_im * X' with
+//     X' = (-im, re) formed in registers: two real accumulations per K-step, no cross-lane traffic;
+//   * accumulation order inside a row is CSR order (K-slots are consecutive non-zeros; other rows contribute exact zeros);
+//   * fused d.q: the strip's own X rows are loaded once more (L1/L2 hits), per-lane column sums live in registers for the
+//     whole sweep and leave as ONE partial per work-group and RHS (fixed order -> bitwise reproducible).
+#include "cgamd_internal.h"
+#include "device_types.h"
+#include "device_mem.h"
+
+#include <algorithm>
+
+namespace cgamd {
+
+constexpr int kRmCap = 128;      // entries of a strip staged per round and wave (32 K-steps); longer strips take more rounds
+
+template <typename T, int NH> struct alignas(NH * sizeof(T)) RowVec { T v[NH]; };
+template <typename T, int NH> CG_DEV RowVec<T, NH> ld_rowvec(const T *p) { return *reinterpret_cast<const RowVec<T, NH> *>(p); }
+template <bool NT, typename T, int NH> CG_DEV void st_rowvec(T *p, const RowVec<T, NH> &v) {
+    if constexpr (!NT) {
+        *reinterpret_cast<RowVec<T, NH> *>(p) = v;
+    } else {
+        constexpr int W = NH * (int)sizeof(T) / 4;
+        typedef unsigned uvec __attribute__((ext_vector_type(W)));
+        union { RowVec<T, NH> r; uvec u; unsigned s; } cv;
+        cv.r = v;
+        if constexpr (W == 1) __builtin_nontemporal_store(cv.s, reinterpret_cast<unsigned *>(p));
+        else __builtin_nontemporal_store(cv.u, reinterpret_cast<uvec *>(p));
+    }
+}
+
+CG_DEV f32x4 mfma_f32_16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+CG_DEV double mfma_f64_4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+template <typename T> struct SpmmRmArgs {
+    int n, strips, nwg, ynt;
+    long long nnz;
+    const T *vals;          // nnz values (complex: 2 nnz interleaved re, im)
+    const int *ptr, *cols;
+    const T *x;             // [columns][RC] row-major, RC = 16 NH real columns
+    T *y;                   // [n][RC]
+    double *partials;       // fused d.q: real [RC][nwg] doubles; complex [RC/2][nwg] (re, im) pairs
+};
+
+// T = float | double (real element type), NH = real columns / 16, CPLX: values and X/Y columns are (re, im) pairs
+template <typename T, int NH, bool CPLX, bool FUSE_DOT, bool YNT>
+__global__ __launch_bounds__(256, 2) void spmm_rm_mfma_kernel(SpmmRmArgs<T> a) {
+    constexpr bool F64 = sizeof(T) == 8;
+    static_assert(!(F64 && CPLX), "complex128 runs the RHS-major kernel");
+    constexpr int RC = 16 * NH, VW = CPLX ? 2 : 1;
+    constexpr int UBraw = 80 / (NH * (int)sizeof(T) / 4);
+    constexpr int UB = UBraw > 32 ? 32 : (UBraw < 4 ? 4 : UBraw);          // K-steps whose X rows are in flight together
+    using RV = RowVec<T, NH>;
+    __shared__ T sv[4][2][kRmCap * VW];
+    __shared__ int sc[4][2][kRmCap];
+    __shared__ double red[4][2 * RC];
+
+    // the wave index is the same in all 64 lanes: say so (readfirstlane), or every strip-level decision below is
+    // compiled as a divergent branch with exec masking
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 15, kq = lane >> 4;
+    const int xcd = blockIdx.x & 7, W = ((int)gridDim.x >> 3) * 4, wl = ((int)blockIdx.x >> 3) * 4 + wave;
+    const int sb = (int)((long long)xcd * a.strips / 8), se = (int)((long long)(xcd + 1) * a.strips / 8);
+
+    double dsum[NH], dcross[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { dsum[h] = 0.; dcross[h] = 0.; }
+
+    auto load_ptr = [&](int s) -> int {
+        const int row = s * 16 + (lane < 16 ? lane : 16);
+        return a.ptr[row < a.n ? row : a.n];
+    };
+    // entries [tb + r0, min(tb + r0 + kRmCap, te)) of a strip: two per lane, coalesced, streamed past the caches
+    auto fetch = [&](int tb, int te, int r0, T (&ev)[2][VW], int (&ec)[2]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const long long j = (long long)tb + r0 + e * 64 + lane;
+            if (j < te) {
+                ec[e] = __builtin_nontemporal_load(a.cols + j);
+#pragma unroll
+                for (int w = 0; w < VW; ++w) ev[e][w] = __builtin_nontemporal_load(a.vals + j * VW + w);
+            }
+        }
+    };
+    auto stage = [&](int buf, int cnt, const T (&ev)[2][VW], const int (&ec)[2]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int jl = e * 64 + lane;
+            if (jl < cnt) {
+                sc[wave][buf][jl] = ec[e];
+#pragma unroll
+                for (int w = 0; w < VW; ++w) sv[wave][buf][jl * VW + w] = ev[e][w];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // LDS of one wave executes in order; compiler ordering only
+    };
+
+    int s = sb + wl;
+    if (s < se) {
+        int p_cur = load_ptr(s);
+        int s_n = s + W;
+        int p_nxt = s_n < se ? load_ptr(s_n) : 0;
+        int tb = __builtin_amdgcn_readlane(p_cur, 0), te = __builtin_amdgcn_readlane(p_cur, 16);
+        int buf = 0;
+        {
+            T ev[2][VW]; int ec[2];
+            fetch(tb, te, 0, ev, ec);
+            stage(0, min(kRmCap, te - tb), ev, ec);
+        }
+        while (true) {
+            const bool has_n = s_n < se;
+            int tbn = 0, ten = 0;
+            T evn[2][VW]; int ecn[2];
+            if (has_n) {                      // next strip's entries: on their way while this strip is multiplied
+                tbn = __builtin_amdgcn_readlane(p_nxt, 0);
+                ten = __builtin_amdgcn_readlane(p_nxt, 16);
+                fetch(tbn, ten, 0, evn, ecn);
+            }
+            const int s_nn = s_n + W;
+            const int p_nn = s_nn < se ? load_ptr(s_nn) : 0;
+
+            // ------------------------------------------------------------------ strip s
+            const int rowbase = s * 16, cnt_total = te - tb;
+            // local row of accumulator slot i: f64 (4x4x4): 4 i + (l >> 4); f32 (16x16x4): 4 (l >> 4) + i
+            auto lrow = [&](int i) -> int { return F64 ? 4 * i + kq : 4 * kq + i; };
+            RV xo[4];
+            if (FUSE_DOT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = min(rowbase + lrow(i), a.n - 1);
+                    xo[i] = ld_rowvec<T, NH>(a.x + (long long)row * RC + NH * m);
+                }
+            }
+            // row bounds relative to tb.  f32: lane's A-row is m; f64: quad q's A-row is 4q + (l & 3)
+            int s_r[F64 ? 4 : 1], e_r[F64 ? 4 : 1], qs[4], qe[4];
+            if constexpr (F64) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s_r[q] = __shfl(p_cur, 4 * q + (lane & 3), 64) - tb;
+                    e_r[q] = __shfl(p_cur, 4 * q + (lane & 3) + 1, 64) - tb;
+                    qs[q] = __builtin_amdgcn_readlane(p_cur, 4 * q) - tb;
+                    qe[q] = __builtin_amdgcn_readlane(p_cur, 4 * q + 4) - tb;
+                }
+            } else {
+                s_r[0] = __shfl(p_cur, m, 64) - tb;
+                e_r[0] = __shfl(p_cur, m + 1, 64) - tb;
+            }
+            f32x4 acc16[F64 ? 1 : NH];
+            double acc4[F64 ? 4 : 1][NH];
+            if constexpr (F64) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) acc4[q][h] = 0.;
+            } else {
+#pragma unroll
+                for (int h = 0; h < NH; ++h) acc16[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+
+            for (int r0 = 0; r0 < cnt_total; r0 += kRmCap) {          // rounds (one for <= 8 non-zeros per row)
+                if (r0 > 0) {
+                    T ev[2][VW]; int ec[2];
+                    fetch(tb, te, r0, ev, ec);
+                    stage(buf, min(kRmCap, cnt_total - r0), ev, ec);
+                }
+                const int cnt = min(kRmCap, cnt_total - r0);
+                const int steps = (cnt + 3) >> 2, nb = (steps + UB - 1) / UB, per = (steps + nb - 1) / nb;
+                for (int b = 0; b < nb; ++b) {
+                    const int k0 = b * per, nst = min(per, steps - k0);
+                    RV bv[UB];
+                    // all gathers of the batch are issued back to back, branch-free (slots past the batch re-read its
+                    // last entry: an L1 hit, never consumed)
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int jl = min(4 * (k0 + min(u, nst - 1)) + kq, cnt - 1);
+                        const int c = sc[wave][buf][jl];
+                        bv[u] = ld_rowvec<T, NH>(a.x + (long long)c * RC + NH * m);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        if (u < nst) {                                 // wave-uniform
+                            const int jl0 = 4 * (k0 + u), jl = jl0 + kq, jlc = min(jl, cnt - 1), jr = r0 + jl;
+                            const bool live = jl < cnt;
+                            if constexpr (F64) {
+                                const double v = sv[wave][buf][jlc];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    if (r0 + jl0 < qe[q] && r0 + jl0 + 4 > qs[q]) {      // K-step touches quad q (wave-uniform)
+                                        const double av = (live && jr >= s_r[q] && jr < e_r[q]) ? v : 0.;
+#pragma unroll
+                                        for (int h = 0; h < NH; ++h) acc4[q][h] = mfma_f64_4(av, bv[u].v[h], acc4[q][h]);
+                                    }
+                                }
+                            } else {
+                                const bool mine = live && jr >= s_r[0] && jr < e_r[0];
+                                if constexpr (CPLX) {
+                                    const float vr = sv[wave][buf][2 * jlc], vi = sv[wave][buf][2 * jlc + 1];
+                                    const float ar = mine ? vr : 0.f, ai = mine ? vi : 0.f;
+#pragma unroll
+                                    for (int h = 0; h < NH; ++h) {
+                                        acc16[h] = mfma_f32_16(ar, bv[u].v[h], acc16[h]);
+                                        // (ar + i ai)(xr + i xi): the re column gets -ai xi, the im column +ai xr (cmplx.h:20-25)
+                                        const float xs = (h & 1) ? bv[u].v[h - 1] : -bv[u].v[h + 1];
+                                        acc16[h] = mfma_f32_16(ai, xs, acc16[h]);
+                                    }
+                                } else {
+                                    const float av = mine ? sv[wave][buf][jlc] : 0.f;
+#pragma unroll
+                                    for (int h = 0; h < NH; ++h) acc16[h] = mfma_f32_16(av, bv[u].v[h], acc16[h]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- store the strip: every store instruction of the wave covers 4 whole rows of Y
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rowbase + lrow(i);
+                RV out;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    if constexpr (F64) out.v[h] = acc4[i][h];
+                    else out.v[h] = acc16[h][i];
+                }
+                if (row < a.n) {
+                    st_rowvec<YNT, T, NH>(a.y + (long long)row * RC + NH * m, out);
+                    if (FUSE_DOT) {
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            dsum[h] += (double)(xo[i].v[h] * out.v[h]);
+                            if constexpr (CPLX) dcross[h] += (double)(xo[i].v[h] * out.v[h ^ 1]);
+                        }
+                    }
+                }
+            }
+            // ------------------------------------------------------------------ install the next strip
+            if (!has_n) break;
+            stage(buf ^ 1, min(kRmCap, ten - tbn), evn, ecn);
+            buf ^= 1;
+            p_cur = p_nxt; p_nxt = p_nn;
+            tb = tbn; te = ten;
+            s = s_n; s_n = s_nn;
+        }
+    }
+    if (FUSE_DOT) {
+        // per-lane column sums -> per-wave (lanes with equal m) -> per work-group, fixed order
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            dsum[h] += __shfl_xor(dsum[h], 16, 64);
+            dsum[h] += __shfl_xor(dsum[h], 32, 64);
+            if constexpr (CPLX) {
+                dcross[h] += __shfl_xor(dcross[h], 16, 64);
+                dcross[h] += __shfl_xor(dcross[h], 32, 64);
+            }
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                red[wave][NH * m + h] = dsum[h];
+                red[wave][RC + NH * m + h] = dcross[h];
+            }
+        }
+        __syncthreads();
+        if constexpr (CPLX) {
+            if (t < RC / 2) {
+                auto tot = [&](int c) { return ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]; };
+                const double re = tot(2 * t) - tot(2 * t + 1);                     // unconjugated (complex/vdot.cl:15)
+                const double im = tot(RC + 2 * t) + tot(RC + 2 * t + 1);
+                double *p = a.partials + 2 * ((long long)t * a.nwg + blockIdx.x);
+                p[0] = re; p[1] = im;
+            }
+        } else {
+            if (t < RC) a.partials[(long long)t * a.nwg + blockIdx.x] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// fp64 form: v_mfma_f64_4x4x4_4b, software-pipelined across strips.
+// A strip's 16 rows are 4 QUADS of 4 rows.  A quad's non-zeros are staged QUAD-ALIGNED in the wave's LDS area: quad q owns
+// slots [q QS, (q+1) QS), QS = 4 TQ, so a K-step (4 consecutive slots) never straddles two quads and every LDS address of
+// the multiply phase is "static offset + lane part".  The A operand is staged already selected: sval[i][slot] holds the
+// value if the slot's non-zero lies in row i of its quad, else 0 (tail slots of a quad's last K-step: 0 in all four), so
+// a lane's operand for MFMA (q, t) is ONE ds_read_b64 of sval[l & 3][q QS + 4t + (l >> 4)] -- no compares, no selects.
+// (The first version tested row ranges per K-step and quad in the multiply loop: 80 guarded blocks per strip, ~2 us of
+// issue per strip and wave, 187 us per SpMM.)  TQ = K-steps per quad and round, a template parameter chosen from the
+// matrix (5: <= 20 non-zeros per 4 rows, the 5-point stencil; 8: anything, longer quads take more rounds).
+// Pipeline per wave, strip k current:   stage(k+1) -> fetch entries(k+2), pointers(k+3) -> gathers(k+1) -> multiply(k)
+// -> store(k): the gathers of two strips are in flight, and nothing a strip waits for is younger (vmcnt is in order) than
+// the loads it does not need yet.  Strips past the wave's last alias it (redundant, discarded) so the loop is branch-free.
+// -------------------------------------------------------------------------------------------------
+template <int NH, int TQ, bool FUSE_DOT>
+__global__ __launch_bounds__(256, 2) void spmm_rm_f64_kernel(SpmmRmArgs<double> a) {
+    // two strips' gathers in flight need 2 x 4 TQ x 2 NH registers; 32 right-hand sides with 8 K-steps per quad do not fit
+    // 256 VGPRs twice over: that instance keeps one strip in flight (PIPE = false)
+    constexpr bool PIPE = NH * TQ <= 10;
+    constexpr int RC = 16 * NH, QS = 4 * TQ, SLOTS = 4 * QS, EPL = (SLOTS + 63) / 64, VS = SLOTS + 4;   // VS: bank-conflict-free row stride
+    using RV = RowVec<double, NH>;
+    __shared__ int scol[4][2][SLOTS];
+    __shared__ double sval[4][2][4 * VS];
+    __shared__ double red[4][RC];
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 15, kq = lane >> 4;
+    const int xcd = blockIdx.x & 7, W = ((int)gridDim.x >> 3) * 4, wl = ((int)blockIdx.x >> 3) * 4 + wave;
+    const int sb = (int)((long long)xcd * a.strips / 8), se = (int)((long long)(xcd + 1) * a.strips / 8);
+
+    double dsum[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) dsum[h] = 0.;
+
+    auto load_ptr = [&](int s) -> int {
+        const int row = s * 16 + (lane < 16 ? lane : 16);
+        return a.ptr[row < a.n ? row : a.n];
+    };
+    struct Quads { int tb, Q1, Q2, Q3, Q4; };                 // quad starts relative to the strip's first entry (uniform)
+    auto quads = [&](int p) -> Quads {
+        Quads g;
+        g.tb = __builtin_amdgcn_readlane(p, 0);
+        g.Q1 = __builtin_amdgcn_readlane(p, 4) - g.tb;  g.Q2 = __builtin_amdgcn_readlane(p, 8) - g.tb;
+        g.Q3 = __builtin_amdgcn_readlane(p, 12) - g.tb; g.Q4 = __builtin_amdgcn_readlane(p, 16) - g.tb;
+        return g;
+    };
+    // slot idx = e 64 + lane of the staging area <-> (quad, position); entry j of the strip it holds in round r
+    auto slot_entry = [&](const Quads &g, int idx, int r, int &q, int &Qq, int &Qn) -> int {
+        q = idx / QS;
+        Qq = q == 0 ? 0 : q == 1 ? g.Q1 : q == 2 ? g.Q2 : g.Q3;
+        Qn = q == 0 ? g.Q1 : q == 1 ? g.Q2 : q == 2 ? g.Q3 : g.Q4;
+        return Qq + r + (idx - q * QS);
+    };
+    auto fetch = [&](int p, int r, double (&ev)[EPL], int (&ec)[EPL]) {
+        const Quads g = quads(p);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int q, Qq, Qn;
+            const int idx = e * 64 + lane, j = slot_entry(g, idx, r, q, Qq, Qn);
+            if (idx < SLOTS && j < Qn) {
+                ec[e] = __builtin_nontemporal_load(a.cols + (long long)g.tb + j);
+                ev[e] = __builtin_nontemporal_load(a.vals + (long long)g.tb + j);
+            }
+        }
+    };
+    auto stage = [&](int buf, int p, int r, int safe_col, const double (&ev)[EPL], const int (&ec)[EPL]) {
+        const Quads g = quads(p);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int q, Qq, Qn;
+            const int idx = e * 64 + lane, j = slot_entry(g, idx, r, q, Qq, Qn);
+            // row of the entry inside its quad: rows 4q+1 .. 4q+3 start at R1 <= R2 <= R3 (all lanes shuffle: outside the branch)
+            const int qc = idx < SLOTS ? q : 0;
+            const int R1 = __shfl(p, 4 * qc + 1, 64) - g.tb, R2 = __shfl(p, 4 * qc + 2, 64) - g.tb, R3 = __shfl(p, 4 * qc + 3, 64) - g.tb;
+            if (idx < SLOTS) {
+                const int lenr = min(max(Qn - Qq - r, 0), QS), padded = max(4, (lenr + 3) & ~3);
+                const bool live = j < Qn;
+                if (live || idx - q * QS < padded) {
+                    const int ri = live ? (j >= R1) + (j >= R2) + (j >= R3) : -1;
+                    scol[wave][buf][idx] = live ? ec[e] : safe_col;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sval[wave][buf][k * VS + idx] = (k == ri) ? ev[e] : 0.;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // one wave's LDS ops execute in order; compiler ordering only
+    };
+    auto steps_of = [&](const Quads &g, int q, int r) -> int {      // K-steps of quad q in round r (uniform)
+        const int len = (q == 0 ? g.Q1 : q == 1 ? g.Q2 - g.Q1 : q == 2 ? g.Q3 - g.Q2 : g.Q4 - g.Q3) - r;
+        return min(max((len + 3) >> 2, 0), TQ);
+    };
+    // the gathers of one round: 4 TQ loads of NH doubles per lane, each instruction = 4 whole X rows; branch-free
+    auto issue = [&](int buf, int p, int r, RV (&bv)[4][TQ]) {
+        const Quads g = quads(p);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int st = steps_of(g, q, r);
+#pragma unroll
+            for (int u = 0; u < TQ; ++u) {
+                const int uc = max(0, min(u, st - 1));
+                const int c = scol[wave][buf][q * QS + 4 * uc + kq];
+                bv[q][u] = ld_rowvec<double, NH>(a.x + (long long)c * RC + NH * m);
+            }
+        }
+    };
+    auto multiply = [&](int buf, int p, int r, const RV (&bv)[4][TQ], double (&acc)[4][NH]) {
+        const Quads g = quads(p);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int st = steps_of(g, q, r);
+#pragma unroll
+            for (int u = 0; u < TQ; ++u) {
+                if (u < st) {                                        // wave-uniform
+                    const double av = sval[wave][buf][(lane & 3) * VS + q * QS + 4 * u + kq];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) acc[q][h] = mfma_f64_4(av, bv[q][u].v[h], acc[q][h]);
+                }
+            }
+        }
+    };
+
+    const int s0 = sb + wl;
+    if (s0 < se) {
+        auto clampS = [&](int s) -> int { return s < se ? s : se - 1; };
+        int s_cur = s0, s_nxt = s0 + W, s_nn = s0 + 2 * W;
+        int p_cur = load_ptr(s_cur), p_nxt = load_ptr(clampS(s_nxt)), p_nn = load_ptr(clampS(s_nn));
+        int buf = 0;
+        double evN[EPL]; int ecN[EPL];
+        RV bvA[4][TQ], bvB[PIPE ? 4 : 1][PIPE ? TQ : 1];
+        {
+            double ev[EPL]; int ec[EPL];
+            fetch(p_cur, 0, ev, ec);
+            stage(0, p_cur, 0, min(s_cur * 16, a.n - 1), ev, ec);
+        }
+        fetch(p_nxt, 0, evN, ecN);
+        if constexpr (PIPE) issue(0, p_cur, 0, bvA);
+
+        // one pipeline step: strip s_cur is multiplied out of bvC while the next strip's gathers go into bvN
+        auto step = [&](RV (&bvC)[4][TQ], auto &bvN) -> bool {
+            const int rowbase = s_cur * 16;
+            RV xo[4];
+            if (FUSE_DOT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xo[i] = ld_rowvec<double, NH>(a.x + (long long)min(rowbase + 4 * i + kq, a.n - 1) * RC + NH * m);
+            }
+            if constexpr (!PIPE) issue(buf, p_cur, 0, bvC);
+            stage(buf ^ 1, p_nxt, 0, min(clampS(s_nxt) * 16, a.n - 1), evN, ecN);
+            const int p_n3 = load_ptr(clampS(s_nn + W));
+            fetch(p_nn, 0, evN, ecN);
+            if constexpr (PIPE) issue(buf ^ 1, p_nxt, 0, bvN);
+
+            double acc[4][NH];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) acc[q][h] = 0.;
+            multiply(buf, p_cur, 0, bvC, acc);
+            {   // quads longer than one round (more than 4 TQ non-zeros in 4 rows): further rounds, not pipelined
+                const Quads g = quads(p_cur);
+                const int maxlen = max(max(g.Q1, g.Q2 - g.Q1), max(g.Q3 - g.Q2, g.Q4 - g.Q3));
+                for (int r = QS; r < maxlen; r += QS) {
+                    double ev[EPL]; int ec[EPL];
+                    fetch(p_cur, r, ev, ec);
+                    stage(buf, p_cur, r, min(rowbase, a.n - 1), ev, ec);
+                    issue(buf, p_cur, r, bvC);
+                    multiply(buf, p_cur, r, bvC, acc);
+                }
+            }
+            // store: lane (i = l >> 4 in D) holds row 4q + (l >> 4), columns NH m .. NH m + NH - 1: 4 whole rows per instruction
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = rowbase + 4 * q + kq;
+                RV out;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) out.v[h] = acc[q][h];
+                if (row < a.n) {
+                    *reinterpret_cast<RV *>(a.y + (long long)row * RC + NH * m) = out;
+                    if (FUSE_DOT) {
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) dsum[h] += xo[q].v[h] * out.v[h];
+                    }
+                }
+            }
+            if (s_nxt >= se) return false;
+            s_cur = s_nxt; s_nxt = s_nn; s_nn += W;
+            p_cur = p_nxt; p_nxt = p_nn; p_nn = p_n3;
+            buf ^= 1;
+            return true;
+        };
+        if constexpr (PIPE) {
+            while (true) {
+                if (!step(bvA, bvB)) break;
+                if (!step(bvB, bvA)) break;
+            }
+        } else {
+            while (step(bvA, bvA)) {}
+        }
+    }
+    if (FUSE_DOT) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            dsum[h] += __shfl_xor(dsum[h], 16, 64);
+            dsum[h] += __shfl_xor(dsum[h], 32, 64);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) red[wave][NH * m + h] = dsum[h];
+        }
+        __syncthreads();
+        if (t < RC) a.partials[(long long)t * a.nwg + blockIdx.x] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    }
+}
+
+// =================================================================================================
+// Vector kernels on the row-major block: T = float | double | float2 | double2, R right-hand sides, element (i, r) at
+// i*R + r.  A thread's 16-byte packs always fall on the same columns (the grid stride is a multiple of R), so the
+// per-column scalars are loaded once and the per-column dot partials accumulate in registers.  Column sums: lanes with
+// equal columns meet by xor-shuffles, the 4 waves through LDS, one partial per work-group and column (fixed order).
+// =================================================================================================
+template <typename A> CG_DEV A shfl_xor_acc(A v, int off);
+template <> CG_DEV double shfl_xor_acc<double>(double v, int off) { return __shfl_xor(v, off, 64); }
+template <> CG_DEV double2 shfl_xor_acc<double2>(double2 v, int off) { return make_double2(__shfl_xor(v.x, off, 64), __shfl_xor(v.y, off, 64)); }
+
+template <typename T, int BLOCK>
+CG_DEV void rm_column_partials(typename VT<T>::acc (&acc)[Pack<T>::N], int R, typename VT<T>::acc *partials, typename VT<T>::acc *red /* [4][R] */) {
+    using A = typename VT<T>::acc;
+    constexpr int E = Pack<T>::N;
+    const int groups = R / E;                                   // distinct column groups among the lanes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = groups; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc[k] = vadd(acc[k], shfl_xor_acc<A>(acc[k], off));
+    if (lane < groups)
+#pragma unroll
+        for (int k = 0; k < E; ++k) red[wave * R + lane * E + k] = acc[k];
+    __syncthreads();
+    if ((int)threadIdx.x < R) {
+        const int c = threadIdx.x;
+        A tot = red[c];
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; ++w) tot = vadd(tot, red[w * R + c]);
+        partials[(long long)c * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+// partials of a.b per column (setup: r.r)
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rm_dot_kernel(long long total, int R, const T *__restrict__ a, const T *__restrict__ b,
+                                                        typename VT<T>::acc *__restrict__ partials) {
+    using A = typename VT<T>::acc;
+    constexpr int E = Pack<T>::N;
+    __shared__ A red[(BLOCK / 64) * 64];
+    A acc[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) acc[k] = vzero<A>();
+    const long long npack = total / E, stride = (long long)gridDim.x * BLOCK;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < npack; i += stride) {
+        const Pack<T> pa = ld_pack(a + i * E), pb = ld_pack(b + i * E);
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc[k] = vadd(acc[k], to_acc(vmul(pa.v[k], pb.v[k])));
+    }
+    rm_column_partials<T, BLOCK>(acc, R, partials, red);
+}
+
+// r -= alpha[c] q ; partials of r.r per column      (reference axpy.cl with aSign = 0 + vdot.cl; clcg.c:345-374)
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rm_axpy_dot_kernel(long long total, int R, const T *__restrict__ q, T *__restrict__ rv,
+                                                             const T *__restrict__ alpha, typename VT<T>::acc *__restrict__ partials) {
+    using A = typename VT<T>::acc;
+    constexpr int E = Pack<T>::N;
+    __shared__ A red[(BLOCK / 64) * 64];
+    const int c0 = (int)(((long long)threadIdx.x * E) % R);
+    T al[E];
+    A acc[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) { al[k] = alpha[c0 + k]; acc[k] = vzero<A>(); }
+    const long long npack = total / E, stride = (long long)gridDim.x * BLOCK;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < npack; i += stride) {
+        const Pack<T> pq = ld_pack(q + i * E);
+        Pack<T> pr = ld_pack(rv + i * E);
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            pr.v[k] = vsub(pr.v[k], vmul(al[k], pq.v[k]));
+            acc[k] = vadd(acc[k], to_acc(vmul(pr.v[k], pr.v[k])));
+        }
+        st_pack(rv + i * E, pr);
+    }
+    rm_column_partials<T, BLOCK>(acc, R, partials, red);
+}
+
+// x += alpha[c] d ; d = beta[c] d + r                (axpy.cl with aSign = 1, aypx.cl; clcg.c:338-342,415)
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rm_aypx_x_kernel(long long total, int R, const T *__restrict__ rv, T *__restrict__ d,
+                                                           T *__restrict__ xs, const T *__restrict__ alpha, const T *__restrict__ beta) {
+    constexpr int E = Pack<T>::N;
+    const int c0 = (int)(((long long)threadIdx.x * E) % R);
+    T al[E], bt[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) { al[k] = alpha[c0 + k]; bt[k] = beta[c0 + k]; }
+    const long long npack = total / E, stride = (long long)gridDim.x * BLOCK;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < npack; i += stride) {
+        const Pack<T> pr = ld_pack(rv + i * E);
+        Pack<T> pd = ld_pack(d + i * E), px = ld_pack(xs + i * E);
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            px.v[k] = vadd(px.v[k], vmul(al[k], pd.v[k]));
+            pd.v[k] = vadd(vmul(bt[k], pd.v[k]), pr.v[k]);
+        }
+        st_pack(xs + i * E, px);
+        st_pack(d + i * E, pd);
+    }
+}
+
+// =================================================================================================
+// Host side
+// =================================================================================================
+static int rm_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return CGAMD_OK;
+}
+
+// real columns of the row-major block (0 = this type / width has no matrix-core path)
+static int rm_real_columns(int dtype, int nrhs) {
+    if (dtype == CGAMD_C128) return 0;
+    if (dtype == CGAMD_C64) return (nrhs == 16 || nrhs == 32) ? 2 * nrhs : 0;     // a lane must hold whole (re, im) pairs
+    if (dtype == CGAMD_F64) return (nrhs == 16 || nrhs == 32) ? nrhs : 0;         // 64 fp64 columns: a strip's gathers exceed the registers
+    return (nrhs == 16 || nrhs == 32 || nrhs == 64) ? nrhs : 0;
+}
+bool spmm_rm_supported(int dtype, int nrhs) { return rm_real_columns(dtype, nrhs) != 0; }
+
+// work-groups of the sweep (a multiple of 8; 4 waves each).  The sweep only keeps its locality if every work-group of the
+// grid is resident from the start (a queued work-group would run its interleaved strips after the others have moved on),
+// so the grid is the kernel's resident capacity: `spmm_wgs` per XCD (default 64 = 2 per CU, the kernels are built for 2
+// waves per SIMD: 256 strips = 4096 rows open per XCD), never more waves than strips.
+int spmm_rm_grid(int n) {
+    const int strips = (n + 15) / 16;
+    const int cap = g_tune.spmm_wgs > 0 ? g_tune.spmm_wgs : 64;
+    int per_xcd = ((strips + 7) / 8 + 3) / 4;
+    if (per_xcd > cap) per_xcd = cap;
+    if (per_xcd < 1) per_xcd = 1;
+    return 8 * per_xcd;
+}
+
+template <typename T, int NH, bool CPLX>
+static int spmm_rm_launch(int n, long long nnz, const void *vals, const int *ptr, const int *cols, const void *x, void *y,
+                          void *partials, int max_quad, hipStream_t st) {
+    SpmmRmArgs<T> a;
+    a.n = n; a.strips = (n + 15) / 16; a.nwg = spmm_rm_grid(n); a.ynt = 0; a.nnz = nnz;
+    a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
+    a.x = static_cast<const T *>(x); a.y = static_cast<T *>(y); a.partials = static_cast<double *>(partials);
+    const dim3 g(a.nwg), b(256);
+    if constexpr (sizeof(T) == 8) {
+        // K-steps per quad and round: 5 when no 4 consecutive rows hold more than 20 non-zeros (5-point stencils), else 8
+        const bool tq5 = max_quad > 0 && max_quad <= 20 && g_tune.spmm_tq != 8;
+        if (partials) {
+            if (tq5) hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, 5, true>), g, b, 0, st, a);
+            else hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, 8, true>), g, b, 0, st, a);
+        } else {
+            if (tq5) hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, 5, false>), g, b, 0, st, a);
+            else hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, 8, false>), g, b, 0, st, a);
+        }
+        return rm_check_launch("spmm_rm_f64");
+    } else {
+        if (partials) hipLaunchKernelGGL((spmm_rm_mfma_kernel<T, NH, CPLX, true, false>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((spmm_rm_mfma_kernel<T, NH, CPLX, false, false>), g, b, 0, st, a);
+        return rm_check_launch("spmm_rm_mfma");
+    }
+}
+
+int launch_spmm_rm(int dtype, int n, long long nnz, const void *vals, const int *ptr, const int *cols, const void *x, void *y,
+                   int nrhs, void *partials, int max_quad, hipStream_t st) {
+    if (n <= 0) return CGAMD_OK;
+    const int rc = rm_real_columns(dtype, nrhs);
+    if (!rc) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: needs f64 with 16 or 32 right-hand sides, f32 with 16, 32 or 64, or complex64 with 16 or 32");
+#define CG_RM(T, NH, C) return spmm_rm_launch<T, NH, C>(n, nnz, vals, ptr, cols, x, y, partials, max_quad, st)
+    if (dtype == CGAMD_F64) { if (rc == 16) CG_RM(double, 1, false); CG_RM(double, 2, false); }
+    if (dtype == CGAMD_F32) { if (rc == 16) CG_RM(float, 1, false); if (rc == 32) CG_RM(float, 2, false); CG_RM(float, 4, false); }
+    if (rc == 32) CG_RM(float, 2, true);      // complex64, 16 right-hand sides
+    CG_RM(float, 4, true);
+#undef CG_RM
+}
+
+// grid of the row-major vector kernels: <= 2048 work-groups, ~4 packs per thread
+int rm_vec_grid(long long total_elems, int dtype) {
+    const long long per_block = (long long)kBlock * (16 / (long long)dtype_size(dtype)) * 4;
+    long long g = (total_elems + per_block - 1) / per_block;
+    const long long cap = g_tune.vec_grid > 0 ? g_tune.vec_grid : kMaxGrid;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static bool rm_vec_ok(int dtype, int nrhs, std::initializer_list<const void *> ptrs) {
+    for (const void *p : ptrs)
+        if (!aligned16(p)) return false;
+    const int e = 16 / (int)dtype_size(dtype);
+    return nrhs >= e && nrhs <= 64 && (nrhs & (nrhs - 1)) == 0;      // 256 E is a multiple of R; columns per pack divide R
+}
+
+#define CG_RM_DISPATCH(dtype, FN, ...)                                      \
+    switch (dtype) {                                                        \
+    case CGAMD_F32: return FN<float>(__VA_ARGS__);                          \
+    case CGAMD_F64: return FN<double>(__VA_ARGS__);                         \
+    case CGAMD_C64: return FN<float2>(__VA_ARGS__);                         \
+    case CGAMD_C128: return FN<double2>(__VA_ARGS__);                       \
+    default: return fail(CGAMD_ERR_INVALID, "bad dtype");                   \
+    }
+
+template <typename T> static int rm_dot_impl(long long total, int R, const void *a, const void *b, void *partials, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((rm_dot_kernel<T, kBlock>), dim3(grid), dim3(kBlock), 0, st, total, R, (const T *)a, (const T *)b,
+                       (typename VT<T>::acc *)partials);
+    return rm_check_launch("rm_dot");
+}
+int launch_rm_dot(int dtype, int n, int nrhs, const void *a, const void *b, void *partials, int grid, hipStream_t st) {
+    if (!rm_vec_ok(dtype, nrhs, {a, b})) return fail(CGAMD_ERR_INVALID, "rm_dot: unsupported width or misaligned vectors");
+    CG_RM_DISPATCH(dtype, rm_dot_impl, (long long)n * nrhs, nrhs, a, b, partials, grid, st);
+}
+template <typename T> static int rm_axpy_dot_impl(long long total, int R, const void *q, void *r, const void *alpha, void *partials, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((rm_axpy_dot_kernel<T, kBlock>), dim3(grid), dim3(kBlock), 0, st, total, R, (const T *)q, (T *)r, (const T *)alpha,
+                       (typename VT<T>::acc *)partials);
+    return rm_check_launch("rm_axpy_dot");
+}
+int launch_rm_axpy_dot(int dtype, int n, int nrhs, const void *q, void *r, const void *alpha, void *partials, int grid, hipStream_t st) {
+    if (!rm_vec_ok(dtype, nrhs, {q, r})) return fail(CGAMD_ERR_INVALID, "rm_axpy_dot: unsupported width or misaligned vectors");
+    CG_RM_DISPATCH(dtype, rm_axpy_dot_impl, (long long)n * nrhs, nrhs, q, r, alpha, partials, grid, st);
+}
+template <typename T> static int rm_aypx_x_impl(long long total, int R, const void *r, void *d, void *x, const void *alpha, const void *beta, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((rm_aypx_x_kernel<T, kBlock>), dim3(grid), dim3(kBlock), 0, st, total, R, (const T *)r, (T *)d, (T *)x, (const T *)alpha,
+                       (const T *)beta);
+    return rm_check_launch("rm_aypx_x");
+}
+int launch_rm_aypx_x(int dtype, int n, int nrhs, const void *r, void *d, void *x, const void *alpha, const void *beta, int grid, hipStream_t st) {
+    if (!rm_vec_ok(dtype, nrhs, {r, d, x})) return fail(CGAMD_ERR_INVALID, "rm_aypx_x: unsupported width or misaligned vectors");
+    CG_RM_DISPATCH(dtype, rm_aypx_x_impl, (long long)n * nrhs, nrhs, r, d, x, alpha, beta, grid, st);
+}
+
+}  // namespace cgamd

@@ -8,6 +8,8 @@
 //   axpy2_dot  x += alpha d ; r -= alpha q ; partials of r.r (clcg.c:338-374)
 //   aypx_beta  beta = delta_new/delta_old ; history ; d = beta d + r   (clcg.c:376-415; beta in the prologue)
 // CGAMD_UNFUSED replays the reference's own op structure (spmv, vdot, axpy, axpy, vdot, aypx).
+// 16 / 32 right-hand sides (f64, complex64; f32 also 64): the block is kept ROW-MAJOR inside the handle and the
+// product runs on the matrix cores (rowmajor.hip); the reference's RHS-major layout is converted in set_rhs / get_x.
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -38,6 +40,11 @@ struct cgamd_solver {
     int U = 8;
     bool graph_failed = false;
     bool defer_x = true;    // x += alpha d in the aypx launch (fixed at creation: captured graphs depend on it)
+    // row-major multi-RHS path (rowmajor.hip): x, r, d, q, b hold [n][nrhs]; rm_ok is decided at creation, `rm` per set_rhs
+    bool rm_ok = false, rm = false;
+    int rm_nwg = 0, rm_vgrid = 0;
+    // event hooks around the SpMV launch of enqueue_iteration (cgamd_solver_iterate_timed)
+    hipEvent_t *ev_pair = nullptr;
 };
 
 static void destroy_graphs(cgamd_solver *s) {
@@ -66,18 +73,38 @@ static int validate_csr_host(int n, long long nnz, const int *ptr, const int *co
     return CGAMD_OK;
 }
 
+// the SpMV (SpMM) launch of the iteration, bracketed by the caller's event pair when one is installed
+static int enqueue_spmv(cgamd_solver *s, hipStream_t st) {
+    const int dt = s->dtype, n = s->n, nr = s->nrhs;
+    if (s->ev_pair) CG_HIP(hipEventRecord(s->ev_pair[0], st));
+    int rc;
+    if (s->rm) rc = launch_spmm_rm(dt, n, s->nnz, s->vals, s->ptr, s->cols, s->d, s->q, nr, s->part_dq, s->plan.max_quad, st);
+    else if (s->flags & CGAMD_UNFUSED) rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, nullptr, nullptr, st);
+    else rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st);
+    if (rc) return rc;
+    if (s->ev_pair) CG_HIP(hipEventRecord(s->ev_pair[1], st));
+    return CGAMD_OK;
+}
+
 static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
     const int dt = s->dtype, n = s->n, nr = s->nrhs;
     int rc;
+    if (s->rm) {      // row-major block: SpMM on the matrix cores (+ d.q partials), alpha, r update (+ r.r), beta, x and d updates
+        if ((rc = enqueue_spmv(s, st))) return rc;
+        if ((rc = launch_cg_alpha(dt, s->part_dq, s->rm_nwg, nr, s->sc, st))) return rc;
+        if ((rc = launch_rm_axpy_dot(dt, n, nr, s->q, s->r, s->sc.alpha, s->part_rr, s->rm_vgrid, st))) return rc;
+        if ((rc = launch_cg_beta(dt, s->part_rr, s->rm_vgrid, nr, s->sc, st))) return rc;
+        return launch_rm_aypx_x(dt, n, nr, s->r, s->d, s->x, s->sc.alpha, s->sc.beta, s->rm_vgrid, st);
+    }
     if (s->mdiag) {   // preconditioned recurrence (helmFE_var.py:560-585); delta holds rho = r.z
-        if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
+        if ((rc = enqueue_spmv(s, st))) return rc;
         if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
         if ((rc = launch_pcg_axpy2_dot2(dt, false, n, s->d, s->x, s->q, s->r, s->mdiag, n, s->sc.alpha, nr, s->part_rz, s->part_rr,
                                         s->vgrid, st))) return rc;
         return launch_pcg_aypx_beta(dt, n, s->r, s->d, s->mdiag, n, s->part_rz, s->part_rr, s->vgrid, nr, s->sc, s->rho2, s->x, st);
     }
     if (!(s->flags & CGAMD_UNFUSED)) {
-        if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st))) return rc;
+        if ((rc = enqueue_spmv(s, st))) return rc;
         const bool fold = fold_alpha_ok(s->plan.n_partials);      // small system: alpha in the next launch's prologue
         if (!fold && (rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
         if (s->defer_x) {     // r -= alpha q (+ r.r) ; then beta, x += alpha d, d = beta d + r : 3 + 5 vector passes
@@ -91,7 +118,7 @@ static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
         if (rc) return rc;
         return launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
     }
-    if ((rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, nullptr, nullptr, st))) return rc;
+    if ((rc = enqueue_spmv(s, st))) return rc;
     if ((rc = launch_dot_partials(dt, n, s->d, s->q, n, nr, s->part_rr, s->vgrid, st))) return rc;
     if ((rc = launch_cg_alpha(dt, s->part_rr, s->vgrid, nr, s->sc, st))) return rc;
     if ((rc = launch_axpy(dt, n, s->d, s->x, n, s->sc.alpha, 1, nr, st))) return rc;
@@ -150,6 +177,11 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     s->plan = make_spmv_plan(size);
     s->vgrid = vec_grid(size, dtype);
     s->defer_x = g_tune.defer_x != 0;
+    s->rm_ok = nRHS > 1 && g_tune.spmm_rowmajor != 0 && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS);
+    if (s->rm_ok) {
+        s->rm_nwg = spmm_rm_grid(size);
+        s->rm_vgrid = rm_vec_grid((long long)size * nRHS, dtype);
+    }
     int rc = CGAMD_OK;
     if (flags & CGAMD_MATRIX_ON_DEVICE) {
         s->vals = const_cast<void *>(aValues);
@@ -183,12 +215,12 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
             s->x = base; s->r = base + pitch; s->d = base + 2 * pitch; s->q = base + 3 * pitch; s->b = base + 4 * pitch;
         }
     }
-    if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * (size_t)std::max(s->plan.grid, s->plan.row_blocks) * nRHS, "partials_dq");
-    if (!rc) rc = dmalloc(&s->part_rr, acc_size(dtype) * (size_t)s->vgrid * nRHS, "partials_rr");
+    if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * (size_t)std::max(std::max(s->plan.grid, s->plan.row_blocks), s->rm_nwg) * nRHS, "partials_dq");
+    if (!rc) rc = dmalloc(&s->part_rr, acc_size(dtype) * (size_t)std::max(s->vgrid, s->rm_vgrid) * nRHS, "partials_rr");
     if (!rc) rc = dmalloc(&s->sc.alpha, vs * nRHS, "alpha");
     if (!rc) rc = dmalloc(&s->sc.beta, vs * nRHS, "beta");
     if (!rc) rc = dmalloc(&s->sc.delta, vs * nRHS, "delta");
-    if (!rc) rc = dmalloc((void **)&s->sc.iter, 16, "iter");
+    if (!rc) rc = dmalloc((void **)&s->sc.iter, 64, "iter");
     if (!rc) rc = dmalloc(&s->sc.stage, acc_size(dtype) * 32 * (size_t)nRHS, "alpha stage");
     if (!rc) rc = dmalloc((void **)&s->sc.ticket, sizeof(unsigned) * (size_t)nRHS, "alpha tickets");
     if (!rc && hipMemset(s->sc.ticket, 0, sizeof(unsigned) * (size_t)nRHS) != hipSuccess) rc = fail(CGAMD_ERR_HIP, "hipMemset(alpha tickets)");
@@ -233,10 +265,34 @@ int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_
     hipStream_t st = s->ctx->stream;
     const size_t vbytes = (size_t)s->n * s->nrhs * dtype_size(s->dtype);
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const bool rm = s->rm_ok && !s->mdiag;      // the preconditioned recurrence keeps the RHS-major kernels
+    if (rm != s->rm) destroy_graphs(s);         // captured launch sequences belong to one layout
+    s->rm = rm;
+    int rc;
+    if (rm) {
+        // caller's blocks are RHS-major [nrhs][n] (reference spmv.cl:25,48); the handle keeps [n][nrhs]: q is the staging area
+        CG_HIP(hipMemcpyAsync(s->q, b, vbytes, kind, st));
+        if ((rc = launch_transpose(s->dtype, s->nrhs, s->n, s->q, s->b, st))) return rc;
+        if (x0) {
+            CG_HIP(hipMemcpyAsync(s->q, x0, vbytes, kind, st));
+            if ((rc = launch_transpose(s->dtype, s->nrhs, s->n, s->q, s->x, st))) return rc;
+        } else {
+            CG_HIP(hipMemsetAsync(s->x, 0, vbytes, st));
+        }
+        // r = b - A x0 ; d = r ; delta0 = r.r   (clcg.c:255-292)
+        if ((rc = launch_spmm_rm(s->dtype, s->n, s->nnz, s->vals, s->ptr, s->cols, s->x, s->q, s->nrhs, nullptr, s->plan.max_quad, st))) return rc;
+        if ((rc = launch_sub(s->dtype, s->n * s->nrhs, s->b, s->q, s->r, (long long)s->n * s->nrhs, 1, st))) return rc;
+        CG_HIP(hipMemcpyAsync(s->d, s->r, vbytes, hipMemcpyDeviceToDevice, st));
+        if ((rc = launch_rm_dot(s->dtype, s->n, s->nrhs, s->r, s->r, s->part_rr, s->rm_vgrid, st))) return rc;
+        if ((rc = launch_cg_delta0(s->dtype, s->part_rr, s->rm_vgrid, s->nrhs, s->sc, st))) return rc;
+        if (!on_device) CG_HIP(hipStreamSynchronize(st));
+        s->rhs_set = true;
+        s->iters = 0;
+        return CGAMD_OK;
+    }
     CG_HIP(hipMemcpyAsync(s->b, b, vbytes, kind, st));
     if (x0) CG_HIP(hipMemcpyAsync(s->x, x0, vbytes, kind, st));
     else CG_HIP(hipMemsetAsync(s->x, 0, vbytes, st));
-    int rc;
     // r = b - A x0 ; d = r ; delta0 = r.r   (clcg.c:255-292)
     if ((rc = launch_spmv(s->dtype, s->plan, s->n, s->nnz, s->vals, s->ptr, s->cols, s->x, s->n, s->q, s->n, s->nrhs,
                           nullptr, nullptr, st))) return rc;
@@ -300,53 +356,52 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
         while (left > 0) { CG_HIP(hipGraphLaunch(s->g1, st)); --left; }
     } else {
         for (; left > 0; --left)
-            if (int rc = enqueue_iteration(s, st)) return rc;
+            if (int rc = enqueue_iteration(s, st)) {
+                s->iters += nIterations - left + 1;      // the device counter may have advanced for the broken iteration too
+                return rc;
+            }
     }
     s->iters += nIterations;
     return CGAMD_OK;
 }
 
-// nIterations plain-launch iterations with a HIP event pair around every SpMV launch, on the solver's stream:
-// the in-loop duration of the dominant kernel (bench.py's roofline).  Synchronises.
+// nIterations plain-launch iterations of the SAME launch sequence cgamd_solver_iterate replays (enqueue_iteration), with a
+// HIP event pair around every SpMV launch on the solver's stream: the in-loop duration of the dominant kernel
+// (bench.py's roofline).  Synchronises.
 int cgamd_solver_iterate_timed(cgamd_solver *s, int nIterations, float *spmv_ms_avg, float *iter_ms_avg) {
     if (!s || !spmv_ms_avg) return fail(CGAMD_ERR_INVALID, "iterate_timed: null argument");
     if (!s->rhs_set) return fail(CGAMD_ERR_STATE, "iterate_timed: call set_rhs first");
-    if (nIterations < 1 || (s->flags & CGAMD_UNFUSED) || s->mdiag)
-        return fail(CGAMD_ERR_INVALID, "iterate_timed: needs >= 1 iteration of the fused, unpreconditioned loop");
+    if (nIterations < 1) return fail(CGAMD_ERR_INVALID, "iterate_timed: needs >= 1 iteration");
     CG_HIP(hipSetDevice(s->ctx->device));
     if (int rc = ensure_history(s, s->iters + nIterations + 1)) return rc;
     hipStream_t st = s->ctx->stream;
-    const int dt = s->dtype, n = s->n, nr = s->nrhs;
     std::vector<hipEvent_t> ev((size_t)2 * nIterations + 2, nullptr);
-    for (auto &e : ev) CG_HIP(hipEventCreate(&e));
-    int rc = CGAMD_OK;
-    CG_HIP(hipEventRecord(ev[(size_t)2 * nIterations], st));
-    for (int i = 0; i < nIterations && !rc; ++i) {
-        CG_HIP(hipEventRecord(ev[(size_t)2 * i], st));
-        rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st);
-        CG_HIP(hipEventRecord(ev[(size_t)2 * i + 1], st));
-        if (!rc) rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st);
-        if (s->defer_x) {
-            if (!rc) rc = launch_axpy_dot(dt, n, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
-            if (!rc) rc = launch_aypx_beta_x(dt, n, s->r, s->d, s->x, n, s->part_rr, s->vgrid, nr, s->sc, st, s->plan.vec_nt);
-        } else {
-            if (!rc) rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
-            if (!rc) rc = launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
-        }
+    int rc = CGAMD_OK, done = 0;
+    hipError_t e = hipSuccess;
+    for (auto &x : ev)
+        if (e == hipSuccess) e = hipEventCreate(&x);
+    if (e == hipSuccess) e = hipEventRecord(ev[(size_t)2 * nIterations], st);
+    for (int i = 0; i < nIterations && e == hipSuccess && !rc; ++i) {
+        s->ev_pair = &ev[(size_t)2 * i];
+        rc = enqueue_iteration(s, st);
+        ++done;
     }
-    CG_HIP(hipEventRecord(ev[(size_t)2 * nIterations + 1], st));
-    CG_HIP(hipStreamSynchronize(st));
+    s->ev_pair = nullptr;
+    s->iters += done;       // whatever was enqueued counts, also on the error paths below
+    if (e == hipSuccess && !rc) e = hipEventRecord(ev[(size_t)2 * nIterations + 1], st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     double sum = 0.0;
-    for (int i = 0; i < nIterations && !rc; ++i) {
+    float total = 0.f;
+    for (int i = 0; i < nIterations && e == hipSuccess && !rc; ++i) {
         float ms = 0.f;
-        CG_HIP(hipEventElapsedTime(&ms, ev[(size_t)2 * i], ev[(size_t)2 * i + 1]));
+        e = hipEventElapsedTime(&ms, ev[(size_t)2 * i], ev[(size_t)2 * i + 1]);
         sum += ms;
     }
-    float total = 0.f;
-    CG_HIP(hipEventElapsedTime(&total, ev[(size_t)2 * nIterations], ev[(size_t)2 * nIterations + 1]));
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (e == hipSuccess && !rc) e = hipEventElapsedTime(&total, ev[(size_t)2 * nIterations], ev[(size_t)2 * nIterations + 1]);
+    for (auto &x : ev)
+        if (x) (void)hipEventDestroy(x);
     if (rc) return rc;
-    s->iters += nIterations;
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("iterate_timed: ") + hipGetErrorString(e));
     *spmv_ms_avg = (float)(sum / nIterations);
     if (iter_ms_avg) *iter_ms_avg = total / nIterations;
     return CGAMD_OK;
@@ -356,7 +411,12 @@ int cgamd_solver_get_x(cgamd_solver *s, void *x, int on_device) {
     if (!s || !x) return fail(CGAMD_ERR_INVALID, "get_x: null argument");
     CG_HIP(hipSetDevice(s->ctx->device));
     const size_t vbytes = (size_t)s->n * s->nrhs * dtype_size(s->dtype);
-    CG_HIP(hipMemcpyAsync(x, s->x, vbytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->ctx->stream));
+    const void *src = s->x;
+    if (s->rm) {    // back to the caller's RHS-major layout; q is dead between iterations (recomputed first thing in the next)
+        if (int rc = launch_transpose(s->dtype, s->n, s->nrhs, s->x, s->q, s->ctx->stream)) return rc;
+        src = s->q;
+    }
+    CG_HIP(hipMemcpyAsync(x, src, vbytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->ctx->stream));
     if (!on_device) CG_HIP(hipStreamSynchronize(s->ctx->stream));
     return CGAMD_OK;
 }
@@ -402,14 +462,11 @@ int cgamd_solver_spmv(cgamd_solver *s, const void *x, void *y, int fused_dot) {
 
 int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS) {
     if (!s || !x || !y) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: null argument");
-    if (nRHS != 16 && nRHS != 32) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: nRHS must be 16 or 32");
-    if (s->dtype != CGAMD_F32 && s->dtype != CGAMD_F64) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: real value types only");
-    if (!aligned16(s->vals) || !aligned16(s->cols)) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: matrix arrays must be 16-byte aligned");
-    if (s->plan.max_span <= 0 || (size_t)s->plan.max_span * (dtype_size(s->dtype) + 4) > (size_t)kMaxSpmmSliceBytes)
-        return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: a 256-row slice of this matrix does not fit LDS; use cgamd_spmv");
     CG_HIP(hipSetDevice(s->ctx->device));
-    return launch_spmm_mfma(s->dtype, s->plan, s->n, s->nnz, s->vals, s->ptr, s->cols, x, y, nRHS, s->ctx->stream);
+    return launch_spmm_rm(s->dtype, s->n, s->nnz, s->vals, s->ptr, s->cols, x, y, nRHS, nullptr, s->plan.max_quad, s->ctx->stream);
 }
+
+int cgamd_solver_layout(cgamd_solver *s) { return s ? (s->rm ? 1 : 0) : -CGAMD_ERR_INVALID; }
 
 long long cgamd_solver_spmv_bytes(cgamd_solver *s) {
     if (!s) return 0;

@@ -136,10 +136,14 @@ int cgamd_solver_solve(cgamd_solver *s, const void *b, void *x, int nIterations,
 /* the solver's SpMV (optionally fused with the d.q partial reduction) on caller vectors -- bench/profiling */
 int cgamd_solver_spmv(cgamd_solver *s, const void *x, void *y, int fused_dot);
 /* SpMM on the matrix cores (BASELINE config 4, "MFMA tall-B tile path"): Y[size][nRHS] = A * X[size][nRHS] with
- * the right-hand-side block in ROW-MAJOR layout (element i of RHS r at [i*nRHS + r]), nRHS = 16 or 32, f32/f64.
- * cgamd_transpose converts between the reference's RHS-major blocks ([nRHS][size]) and this layout:
- * out[c*rows + r] = in[r*cols + c]. */
+ * the right-hand-side block in ROW-MAJOR layout (element i of RHS r at [i*nRHS + r]); f64 with nRHS = 16 or 32, f32 with 16, 32
+ * or 64, complex64 with 16 or 32; any CSR matrix.  Solvers created with such a width keep their vectors in this layout
+ * internally and run this kernel in the CG loop (cgamd_solver_layout() == 1); set_rhs / get_x / solve still take and
+ * return the reference's RHS-major blocks.  cgamd_transpose converts between the two: out[c*rows + r] = in[r*cols + c]. */
 int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS);
+/* 0: the handle's vectors (cgamd_solver_vector) are RHS-major [nRHS][size]; 1: row-major [size][nRHS] (decided by the
+ * last cgamd_solver_set_rhs) */
+int cgamd_solver_layout(cgamd_solver *s);
 int cgamd_transpose(cgamd_ctx *ctx, int dtype, int rows, int cols, const void *in, void *out);
 /* algorithmic HBM bytes of one SpMV / one CG iteration of this solver (SURVEY §8d formulae: 14 vector passes for the
  * reference's op structure, 11 for its "fused minimum"; the default loop here moves 10) */
