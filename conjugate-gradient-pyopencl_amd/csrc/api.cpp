@@ -45,6 +45,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmm_rb") g_tune.spmm_rb = value;
     else if (k == "spmm_wgs") g_tune.spmm_wgs = value;
     else if (k == "spmm_tq") g_tune.spmm_tq = value;
+    else if (k == "spmm_nq") g_tune.spmm_nq = value;
     else if (k == "spmm_rowmajor") g_tune.spmm_rowmajor = value;
     else if (k == "spmv_lds_pad") g_tune.spmv_lds_pad = value;
     else if (k == "spmv_policy") g_tune.spmv_policy = value;

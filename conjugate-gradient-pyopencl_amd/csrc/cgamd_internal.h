@@ -59,11 +59,12 @@ struct Tuning {
     int spmv_nt = -1;       // non-temporal matrix loads: 1 on, 0 off, -1 auto = on unless the matrix fits the 256 MB Infinity
                             // Cache (below that the re-used matrix is served from the cache; finalize_spmv_plan)
     int spmv_unroll = 0;    // row walk: LDS reads + gathers in flight per lane (4 or 8; 0 = 8, or 4 for 16-byte values)
-    int spmm_ynt = 0;       // experiment: SpMM stores y non-temporally
+    int spmm_ynt = -1;      // SpMM y stores: 0 plain, 1 non-temporal, 2 write-through sc1 (row-major kernel; -1 = default: 2 there, 0 RHS-major)
     int spmm_group = 0;     // SpMM: right-hand sides per register group (0 = equal-width groups of at most 8, 4 for complex128)
     int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = all in one launch)
     int spmm_wgs = 0;       // row-major SpMM sweep: work-groups per XCD (0 = 64: 256 strips of 16 rows open per XCD)
     int spmm_tq = 0;        // fp64 row-major SpMM: 8 = always the generic 8-K-steps-per-quad instance (experiment)
+    int spmm_nq = 0;        // fp64 row-major SpMM: 2 = 8-row strips where they fit (experiment; default 16-row strips)
     int spmm_rowmajor = 1;  // solvers with 16/32/64 right-hand sides (f32, f64; complex64: 16/32) keep the block row-major
                             // and multiply on the matrix cores (0 = RHS-major VALU kernel as for every other width)
     int vec_skew = 0;       // bytes added to the pitch between the solver's vectors (multiple of 16)
@@ -147,8 +148,9 @@ int launch_pack(int dtype, int count, const int *index, const void *v, void *out
 // ---- row-major multi-RHS path (rowmajor.hip): the RHS block is X[n][nrhs], element (i, r) at i*nrhs + r ----------------
 // Y = A X on the matrix cores (+ per-RHS d.q partials [nrhs][spmm_rm_grid(n)] in accumulator precision when partials != 0,
 // the dot being x.y); f64 with 16 / 32 right-hand sides, f32 with 16 / 32 / 64, complex64 with 16 / 32; any CSR matrix
-bool spmm_rm_supported(int dtype, int nrhs);
-int spmm_rm_grid(int n);
+bool spmm_rm_supported(int dtype, int nrhs, int n);
+// work-groups (= fused-dot partials per RHS) the launch will use for this problem
+int spmm_rm_grid(int dtype, int nrhs, int n, int max_quad, bool dot);
 // max_quad: most non-zeros in 4 consecutive rows (SpmvPlan::max_quad; 0 = unknown), picks the fp64 kernel's K-steps per quad
 int launch_spmm_rm(int dtype, int n, long long nnz, const void *vals, const int *ptr, const int *cols, const void *x, void *y,
                    int nrhs, void *partials, int max_quad, hipStream_t st);

@@ -1724,7 +1724,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     a.partials = static_cast<typename VT<T>::acc *>(partials);
     a.row_blocks = plan.row_blocks;
     a.rb_list = rb_list; a.rb_count = rb_count;
-    a.ynt = g_tune.spmm_ynt;
+    a.ynt = g_tune.spmm_ynt > 0;
     const bool vec = aligned16(vals) && aligned16(cols);
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;

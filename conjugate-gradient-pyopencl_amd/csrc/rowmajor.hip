@@ -55,6 +55,15 @@ template <bool NT, typename T, int NH> CG_DEV void st_rowvec(T *p, const RowVec<
     }
 }
 
+// 16-byte store with an explicit cache policy: 0 plain, 1 non-temporal, 2 sc1 (write-through; the line does not stay in
+// the XCD's L2 -- MI355X_MICROARCH.md "stores of each flavour")
+CG_DEV void st16_policy(void *p, const void *src, int policy) {
+    const u32x4 d = *reinterpret_cast<const u32x4 *>(src);
+    if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+    else if (policy == 1) __builtin_nontemporal_store(d, reinterpret_cast<u32x4 *>(p));
+    else *reinterpret_cast<u32x4 *>(p) = d;
+}
+
 CG_DEV f32x4 mfma_f32_16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 CG_DEV double mfma_f64_4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
@@ -313,14 +322,15 @@ __global__ __launch_bounds__(256, 2) void spmm_rm_mfma_kernel(SpmmRmArgs<T> a) {
 // matrix (5: <= 20 non-zeros per 4 rows, the 5-point stencil; 8: anything, longer quads take more rounds).
 // Pipeline per wave, strip k current:   stage(k+1) -> fetch entries(k+2), pointers(k+3) -> gathers(k+1) -> multiply(k)
 // -> store(k): the gathers of two strips are in flight, and nothing a strip waits for is younger (vmcnt is in order) than
-// the loads it does not need yet.  Strips past the wave's last alias it (redundant, discarded) so the loop is branch-free.
+// the loads it does not need yet.  (Tried and dropped: touching the next-but-one strip's new X rows with one dword load per
+// cache line a step early -- 122 -> 149 us and +33 % read traffic; profiles/r2_experiments/spmm_ab8.log.)  Strips past the wave's last alias it (redundant, discarded) so the loop is branch-free.
 // -------------------------------------------------------------------------------------------------
-template <int NH, int TQ, bool FUSE_DOT>
-__global__ __launch_bounds__(256, 2) void spmm_rm_f64_kernel(SpmmRmArgs<double> a) {
-    // two strips' gathers in flight need 2 x 4 TQ x 2 NH registers; 32 right-hand sides with 8 K-steps per quad do not fit
-    // 256 VGPRs twice over: that instance keeps one strip in flight (PIPE = false)
-    constexpr bool PIPE = NH * TQ <= 10;
-    constexpr int RC = 16 * NH, QS = 4 * TQ, SLOTS = 4 * QS, EPL = (SLOTS + 63) / 64, VS = SLOTS + 4;   // VS: bank-conflict-free row stride
+template <int NH, int TQ, int NQ, bool FUSE_DOT>
+__global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmRmArgs<double> a) {
+    // NQ quads = 4 NQ rows per strip (a.strips counts strips of that height).  Two strips' gathers in flight need
+    // 2 x NQ TQ x 2 NH registers; where that exceeds the budget the instance keeps one strip in flight (PIPE = false)
+    constexpr bool PIPE = NH * TQ * NQ <= 40;
+    constexpr int ROWS = 4 * NQ, RC = 16 * NH, QS = 4 * TQ, SLOTS = NQ * QS, EPL = (SLOTS + 63) / 64, VS = SLOTS + 4;   // VS: bank-conflict-free row stride
     using RV = RowVec<double, NH>;
     __shared__ int scol[4][2][SLOTS];
     __shared__ double sval[4][2][4 * VS];
@@ -335,22 +345,24 @@ __global__ __launch_bounds__(256, 2) void spmm_rm_f64_kernel(SpmmRmArgs<double> 
     for (int h = 0; h < NH; ++h) dsum[h] = 0.;
 
     auto load_ptr = [&](int s) -> int {
-        const int row = s * 16 + (lane < 16 ? lane : 16);
+        const int row = s * ROWS + (lane < ROWS ? lane : ROWS);
         return a.ptr[row < a.n ? row : a.n];
     };
-    struct Quads { int tb, Q1, Q2, Q3, Q4; };                 // quad starts relative to the strip's first entry (uniform)
+    struct Quads { int tb, Q[NQ + 1]; };                      // quad starts relative to the strip's first entry (uniform)
     auto quads = [&](int p) -> Quads {
         Quads g;
         g.tb = __builtin_amdgcn_readlane(p, 0);
-        g.Q1 = __builtin_amdgcn_readlane(p, 4) - g.tb;  g.Q2 = __builtin_amdgcn_readlane(p, 8) - g.tb;
-        g.Q3 = __builtin_amdgcn_readlane(p, 12) - g.tb; g.Q4 = __builtin_amdgcn_readlane(p, 16) - g.tb;
+        g.Q[0] = 0;
+#pragma unroll
+        for (int q = 1; q <= NQ; ++q) g.Q[q] = __builtin_amdgcn_readlane(p, 4 * q) - g.tb;
         return g;
     };
     // slot idx = e 64 + lane of the staging area <-> (quad, position); entry j of the strip it holds in round r
     auto slot_entry = [&](const Quads &g, int idx, int r, int &q, int &Qq, int &Qn) -> int {
         q = idx / QS;
-        Qq = q == 0 ? 0 : q == 1 ? g.Q1 : q == 2 ? g.Q2 : g.Q3;
-        Qn = q == 0 ? g.Q1 : q == 1 ? g.Q2 : q == 2 ? g.Q3 : g.Q4;
+        Qq = 0; Qn = g.Q[1];
+#pragma unroll
+        for (int k = 1; k < NQ; ++k) { Qq = q == k ? g.Q[k] : Qq; Qn = q == k ? g.Q[k + 1] : Qn; }
         return Qq + r + (idx - q * QS);
     };
     auto fetch = [&](int p, int r, double (&ev)[EPL], int (&ec)[EPL]) {
@@ -374,50 +386,51 @@ __global__ __launch_bounds__(256, 2) void spmm_rm_f64_kernel(SpmmRmArgs<double> 
             // row of the entry inside its quad: rows 4q+1 .. 4q+3 start at R1 <= R2 <= R3 (all lanes shuffle: outside the branch)
             const int qc = idx < SLOTS ? q : 0;
             const int R1 = __shfl(p, 4 * qc + 1, 64) - g.tb, R2 = __shfl(p, 4 * qc + 2, 64) - g.tb, R3 = __shfl(p, 4 * qc + 3, 64) - g.tb;
-            if (idx < SLOTS) {
-                const int lenr = min(max(Qn - Qq - r, 0), QS), padded = max(4, (lenr + 3) & ~3);
+            if (idx < SLOTS) {       // every slot is written every round: a live entry, or zeros + a harmless column
                 const bool live = j < Qn;
-                if (live || idx - q * QS < padded) {
-                    const int ri = live ? (j >= R1) + (j >= R2) + (j >= R3) : -1;
-                    scol[wave][buf][idx] = live ? ec[e] : safe_col;
+                const int ri = live ? (j >= R1) + (j >= R2) + (j >= R3) : -1;
+                scol[wave][buf][idx] = live ? ec[e] : safe_col;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) sval[wave][buf][k * VS + idx] = (k == ri) ? ev[e] : 0.;
-                }
+                for (int k = 0; k < 4; ++k) sval[wave][buf][k * VS + idx] = (k == ri) ? ev[e] : 0.;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // one wave's LDS ops execute in order; compiler ordering only
     };
     auto steps_of = [&](const Quads &g, int q, int r) -> int {      // K-steps of quad q in round r (uniform)
-        const int len = (q == 0 ? g.Q1 : q == 1 ? g.Q2 - g.Q1 : q == 2 ? g.Q3 - g.Q2 : g.Q4 - g.Q3) - r;
-        return min(max((len + 3) >> 2, 0), TQ);
+        return min(max((g.Q[q + 1] - g.Q[q] - r + 3) >> 2, 0), TQ);
     };
-    // the gathers of one round: 4 TQ loads of NH doubles per lane, each instruction = 4 whole X rows; branch-free
-    auto issue = [&](int buf, int p, int r, RV (&bv)[4][TQ]) {
-        const Quads g = quads(p);
+    // the gathers of one round: NQ TQ loads of NH doubles per lane, each instruction = 4 whole X rows.  Branch-free, LDS
+    // offsets are immediates (slots past a quad's last K-step hold `safe_col`: an L1 hit that the multiply never consumes),
+    // addresses are uniform base + 32-bit byte offset (the launcher guarantees the block is < 4 GiB)
+    const char *xbase = reinterpret_cast<const char *>(a.x) + NH * m * sizeof(double);
+    auto issue = [&](int buf, RV (&bv)[NQ][TQ]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int st = steps_of(g, q, r);
+        for (int q = 0; q < NQ; ++q) {
 #pragma unroll
             for (int u = 0; u < TQ; ++u) {
-                const int uc = max(0, min(u, st - 1));
-                const int c = scol[wave][buf][q * QS + 4 * uc + kq];
-                bv[q][u] = ld_rowvec<double, NH>(a.x + (long long)c * RC + NH * m);
+                const unsigned c = (unsigned)scol[wave][buf][q * QS + 4 * u + kq];
+                bv[q][u] = *reinterpret_cast<const RV *>(xbase + (size_t)(c * (unsigned)(RC * sizeof(double))));
             }
         }
     };
-    auto multiply = [&](int buf, int p, int r, const RV (&bv)[4][TQ], double (&acc)[4][NH]) {
+    // K-step u of all quads before K-step u + 1: consecutive MFMAs go to NQ NH different accumulators, so none waits
+    // for its predecessor's result (with the quad loop outside, each accumulator chain stalled the next issue:
+    // SQ_WAIT_INST_ANY 38 % of the wave cycles)
+    auto multiply = [&](int buf, int p, int r, const RV (&bv)[NQ][TQ], double (&acc)[NQ][NH]) {
         const Quads g = quads(p);
+        int st[NQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int st = steps_of(g, q, r);
+        for (int q = 0; q < NQ; ++q) st[q] = steps_of(g, q, r);
 #pragma unroll
-            for (int u = 0; u < TQ; ++u) {
-                if (u < st) {                                        // wave-uniform
-                    const double av = sval[wave][buf][(lane & 3) * VS + q * QS + 4 * u + kq];
+        for (int u = 0; u < TQ; ++u) {
+            double av[NQ];
 #pragma unroll
-                    for (int h = 0; h < NH; ++h) acc[q][h] = mfma_f64_4(av, bv[q][u].v[h], acc[q][h]);
-                }
-            }
+            for (int q = 0; q < NQ; ++q) av[q] = sval[wave][buf][(lane & 3) * VS + q * QS + 4 * u + kq];
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    if (u < st[q]) acc[q][h] = mfma_f64_4(av[q], bv[q][u].v[h], acc[q][h]);     // wave-uniform guard
         }
     };
 
@@ -427,56 +440,61 @@ __global__ __launch_bounds__(256, 2) void spmm_rm_f64_kernel(SpmmRmArgs<double> 
         int s_cur = s0, s_nxt = s0 + W, s_nn = s0 + 2 * W;
         int p_cur = load_ptr(s_cur), p_nxt = load_ptr(clampS(s_nxt)), p_nn = load_ptr(clampS(s_nn));
         int buf = 0;
-        double evN[EPL]; int ecN[EPL];
-        RV bvA[4][TQ], bvB[PIPE ? 4 : 1][PIPE ? TQ : 1];
+        double evN[EPL]; int ecN[EPL];                           // entries of the next strip, fetched one step ahead
+        RV bvA[NQ][TQ], bvB[PIPE ? NQ : 1][PIPE ? TQ : 1];
         {
             double ev[EPL]; int ec[EPL];
             fetch(p_cur, 0, ev, ec);
-            stage(0, p_cur, 0, min(s_cur * 16, a.n - 1), ev, ec);
+            stage(0, p_cur, 0, min(s_cur * ROWS, a.n - 1), ev, ec);
         }
         fetch(p_nxt, 0, evN, ecN);
-        if constexpr (PIPE) issue(0, p_cur, 0, bvA);
+        if constexpr (PIPE) issue(0, bvA);
 
         // one pipeline step: strip s_cur is multiplied out of bvC while the next strip's gathers go into bvN
-        auto step = [&](RV (&bvC)[4][TQ], auto &bvN) -> bool {
-            const int rowbase = s_cur * 16;
-            RV xo[4];
+        auto step = [&](RV (&bvC)[NQ][TQ], auto &bvN) -> bool {
+            const int rowbase = s_cur * ROWS;
+            RV xo[NQ];
             if (FUSE_DOT) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xo[i] = ld_rowvec<double, NH>(a.x + (long long)min(rowbase + 4 * i + kq, a.n - 1) * RC + NH * m);
+                for (int i = 0; i < NQ; ++i)
+                    xo[i] = *reinterpret_cast<const RV *>(xbase + (size_t)((unsigned)min(rowbase + 4 * i + kq, a.n - 1) * (unsigned)(RC * sizeof(double))));
             }
-            if constexpr (!PIPE) issue(buf, p_cur, 0, bvC);
-            stage(buf ^ 1, p_nxt, 0, min(clampS(s_nxt) * 16, a.n - 1), evN, ecN);
+            if constexpr (!PIPE) issue(buf, bvC);
+            stage(buf ^ 1, p_nxt, 0, min(clampS(s_nxt) * ROWS, a.n - 1), evN, ecN);
             const int p_n3 = load_ptr(clampS(s_nn + W));
             fetch(p_nn, 0, evN, ecN);
-            if constexpr (PIPE) issue(buf ^ 1, p_nxt, 0, bvN);
+            if constexpr (PIPE) issue(buf ^ 1, bvN);
 
-            double acc[4][NH];
+            double acc[NQ][NH];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int h = 0; h < NH; ++h) acc[q][h] = 0.;
             multiply(buf, p_cur, 0, bvC, acc);
             {   // quads longer than one round (more than 4 TQ non-zeros in 4 rows): further rounds, not pipelined
                 const Quads g = quads(p_cur);
-                const int maxlen = max(max(g.Q1, g.Q2 - g.Q1), max(g.Q3 - g.Q2, g.Q4 - g.Q3));
+                int maxlen = 0;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) maxlen = max(maxlen, g.Q[q + 1] - g.Q[q]);
                 for (int r = QS; r < maxlen; r += QS) {
                     double ev[EPL]; int ec[EPL];
                     fetch(p_cur, r, ev, ec);
                     stage(buf, p_cur, r, min(rowbase, a.n - 1), ev, ec);
-                    issue(buf, p_cur, r, bvC);
+                    issue(buf, bvC);
                     multiply(buf, p_cur, r, bvC, acc);
                 }
             }
             // store: lane (i = l >> 4 in D) holds row 4q + (l >> 4), columns NH m .. NH m + NH - 1: 4 whole rows per instruction
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int row = rowbase + 4 * q + kq;
                 RV out;
 #pragma unroll
                 for (int h = 0; h < NH; ++h) out.v[h] = acc[q][h];
                 if (row < a.n) {
-                    *reinterpret_cast<RV *>(a.y + (long long)row * RC + NH * m) = out;
+                    char *yp = reinterpret_cast<char *>(a.y) + NH * m * sizeof(double) + (size_t)((unsigned)row * (unsigned)(RC * sizeof(double)));
+                    if constexpr (NH == 2) st16_policy(yp, &out, a.ynt);     // wave-uniform policy
+                    else *reinterpret_cast<RV *>(yp) = out;
                     if (FUSE_DOT) {
 #pragma unroll
                         for (int h = 0; h < NH; ++h) dsum[h] += xo[q].v[h] * out.v[h];
@@ -629,41 +647,78 @@ static int rm_real_columns(int dtype, int nrhs) {
     if (dtype == CGAMD_F64) return (nrhs == 16 || nrhs == 32) ? nrhs : 0;         // 64 fp64 columns: a strip's gathers exceed the registers
     return (nrhs == 16 || nrhs == 32 || nrhs == 64) ? nrhs : 0;
 }
-bool spmm_rm_supported(int dtype, int nrhs) { return rm_real_columns(dtype, nrhs) != 0; }
+// the kernels address X and Y with 32-bit byte offsets: the block must stay below 4 GiB
+bool spmm_rm_supported(int dtype, int nrhs, int n) {
+    return rm_real_columns(dtype, nrhs) != 0 && (unsigned long long)n * nrhs * dtype_size(dtype) < (1ULL << 32);
+}
 
-// work-groups of the sweep (a multiple of 8; 4 waves each).  The sweep only keeps its locality if every work-group of the
+// Work-groups of the sweep (a multiple of 8; 4 waves each).  The sweep only keeps its locality if every work-group of the
 // grid is resident from the start (a queued work-group would run its interleaved strips after the others have moved on),
-// so the grid is the kernel's resident capacity: `spmm_wgs` per XCD (default 64 = 2 per CU, the kernels are built for 2
-// waves per SIMD: 256 strips = 4096 rows open per XCD), never more waves than strips.
-int spmm_rm_grid(int n) {
-    const int strips = (n + 15) / 16;
-    const int cap = g_tune.spmm_wgs > 0 ? g_tune.spmm_wgs : 64;
+// so the grid is the instance's resident capacity (occupancy query x 32 CUs per XCD; `spmm_wgs` overrides), never more
+// waves than strips.
+struct RmConfig { int rows, tq, nq, wgs_per_cu; const void *fn; };
+template <typename K> static int rm_blocks_per_cu(K kernel) {
+    int per = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 256, 0) != hipSuccess || per < 1) per = 1;
+    return per > 8 ? 8 : per;
+}
+// which instance runs (dtype, nrhs, matrix) and how many rows a strip has
+template <int NH> static void rm_f64_instance(int max_quad, bool dot, int *rows, int *per_cu, int *tq, int *nq) {
+    // K-steps per quad and round: 5 when no 4 consecutive rows hold more than 20 non-zeros (5-point stencils), else 8.
+    // 8-row strips (NQ = 2: half the registers, four waves per SIMD) are an experiment knob: in-process A/B at N = 1M x 32
+    // (profiles/r2_experiments/spmm_ab9.log, spmm_ab10.log) 3 % faster than 16-row strips only with 96 of the 128
+    // resident work-groups per XCD, 13 % slower with all of them, and slower inside CG (the fused-dot instance spills)
+    const bool tq5 = max_quad > 0 && max_quad <= 20 && g_tune.spmm_tq != 8;
+    const bool nq2 = tq5 && g_tune.spmm_nq == 2;
+    *tq = tq5 ? 5 : 8; *nq = nq2 ? 2 : 4; *rows = 4 * *nq;
+    if (tq5 && nq2) *per_cu = dot ? rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 2, true>) : rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 2, false>);
+    else if (tq5) *per_cu = dot ? rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 4, true>) : rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 4, false>);
+    else *per_cu = dot ? rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 8, 4, true>) : rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 8, 4, false>);
+}
+static int rm_grid_for(int n, int rows, int per_cu) {
+    const int strips = (n + rows - 1) / rows;
+    const int cap = g_tune.spmm_wgs > 0 ? g_tune.spmm_wgs : 32 * per_cu;
     int per_xcd = ((strips + 7) / 8 + 3) / 4;
     if (per_xcd > cap) per_xcd = cap;
     if (per_xcd < 1) per_xcd = 1;
     return 8 * per_xcd;
+}
+int spmm_rm_grid(int dtype, int nrhs, int n, int max_quad, bool dot) {
+    int rows = 16, per_cu = 2, tq, nq;
+    if (dtype == CGAMD_F64) {
+        if (nrhs == 16) rm_f64_instance<1>(max_quad, dot, &rows, &per_cu, &tq, &nq);
+        else rm_f64_instance<2>(max_quad, dot, &rows, &per_cu, &tq, &nq);
+    }
+    return rm_grid_for(n, rows, per_cu);
 }
 
 template <typename T, int NH, bool CPLX>
 static int spmm_rm_launch(int n, long long nnz, const void *vals, const int *ptr, const int *cols, const void *x, void *y,
                           void *partials, int max_quad, hipStream_t st) {
     SpmmRmArgs<T> a;
-    a.n = n; a.strips = (n + 15) / 16; a.nwg = spmm_rm_grid(n); a.ynt = 0; a.nnz = nnz;
+    a.n = n; a.nnz = nnz;
+    a.ynt = g_tune.spmm_ynt >= 0 ? g_tune.spmm_ynt : 2;      // Y stores write-through (sc1): the lines do not displace X in L2
     a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
     a.x = static_cast<const T *>(x); a.y = static_cast<T *>(y); a.partials = static_cast<double *>(partials);
-    const dim3 g(a.nwg), b(256);
+    const dim3 b(256);
     if constexpr (sizeof(T) == 8) {
-        // K-steps per quad and round: 5 when no 4 consecutive rows hold more than 20 non-zeros (5-point stencils), else 8
-        const bool tq5 = max_quad > 0 && max_quad <= 20 && g_tune.spmm_tq != 8;
-        if (partials) {
-            if (tq5) hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, 5, true>), g, b, 0, st, a);
-            else hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, 8, true>), g, b, 0, st, a);
-        } else {
-            if (tq5) hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, 5, false>), g, b, 0, st, a);
-            else hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, 8, false>), g, b, 0, st, a);
-        }
+        int rows, per_cu, tq, nq;
+        rm_f64_instance<NH>(max_quad, partials != nullptr, &rows, &per_cu, &tq, &nq);
+        a.strips = (n + rows - 1) / rows;
+        a.nwg = rm_grid_for(n, rows, per_cu);
+        const dim3 g(a.nwg);
+#define CG_F64(TQ, NQ)                                                                                   \
+    do {                                                                                                  \
+        if (partials) hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, TQ, NQ, true>), g, b, 0, st, a);         \
+        else hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, TQ, NQ, false>), g, b, 0, st, a);                 \
+    } while (0)
+        if (tq == 5 && nq == 2) CG_F64(5, 2); else if (tq == 5) CG_F64(5, 4); else CG_F64(8, 4);
+#undef CG_F64
         return rm_check_launch("spmm_rm_f64");
     } else {
+        a.strips = (n + 15) / 16;
+        a.nwg = rm_grid_for(n, 16, 2);
+        const dim3 g(a.nwg);
         if (partials) hipLaunchKernelGGL((spmm_rm_mfma_kernel<T, NH, CPLX, true, false>), g, b, 0, st, a);
         else hipLaunchKernelGGL((spmm_rm_mfma_kernel<T, NH, CPLX, false, false>), g, b, 0, st, a);
         return rm_check_launch("spmm_rm_mfma");
@@ -674,6 +729,7 @@ int launch_spmm_rm(int dtype, int n, long long nnz, const void *vals, const int 
                    int nrhs, void *partials, int max_quad, hipStream_t st) {
     if (n <= 0) return CGAMD_OK;
     const int rc = rm_real_columns(dtype, nrhs);
+    if (rc && !spmm_rm_supported(dtype, nrhs, n)) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: the right-hand-side block must be smaller than 4 GiB");
     if (!rc) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: needs f64 with 16 or 32 right-hand sides, f32 with 16, 32 or 64, or complex64 with 16 or 32");
 #define CG_RM(T, NH, C) return spmm_rm_launch<T, NH, C>(n, nnz, vals, ptr, cols, x, y, partials, max_quad, st)
     if (dtype == CGAMD_F64) { if (rc == 16) CG_RM(double, 1, false); CG_RM(double, 2, false); }

@@ -177,11 +177,8 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     s->plan = make_spmv_plan(size);
     s->vgrid = vec_grid(size, dtype);
     s->defer_x = g_tune.defer_x != 0;
-    s->rm_ok = nRHS > 1 && g_tune.spmm_rowmajor != 0 && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS);
-    if (s->rm_ok) {
-        s->rm_nwg = spmm_rm_grid(size);
-        s->rm_vgrid = rm_vec_grid((long long)size * nRHS, dtype);
-    }
+    s->rm_ok = nRHS > 1 && g_tune.spmm_rowmajor != 0 && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS, size);
+    if (s->rm_ok) s->rm_vgrid = rm_vec_grid((long long)size * nRHS, dtype);
     int rc = CGAMD_OK;
     if (flags & CGAMD_MATRIX_ON_DEVICE) {
         s->vals = const_cast<void *>(aValues);
@@ -215,7 +212,8 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
             s->x = base; s->r = base + pitch; s->d = base + 2 * pitch; s->q = base + 3 * pitch; s->b = base + 4 * pitch;
         }
     }
-    if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * (size_t)std::max(std::max(s->plan.grid, s->plan.row_blocks), s->rm_nwg) * nRHS, "partials_dq");
+    // the row-major SpMM writes one d.q partial per work-group of its sweep: at most 8 XCDs x 32 CUs x 8 work-groups
+    if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * (size_t)std::max(std::max(s->plan.grid, s->plan.row_blocks), s->rm_ok ? 2048 : 0) * nRHS, "partials_dq");
     if (!rc) rc = dmalloc(&s->part_rr, acc_size(dtype) * (size_t)std::max(s->vgrid, s->rm_vgrid) * nRHS, "partials_rr");
     if (!rc) rc = dmalloc(&s->sc.alpha, vs * nRHS, "alpha");
     if (!rc) rc = dmalloc(&s->sc.beta, vs * nRHS, "beta");
@@ -227,6 +225,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) rc = ensure_history(s, 1024);
     if (!rc) rc = compute_spmv_plan(s->ptr, s->cols, size, s->sc.iter, ctx->stream, &s->plan);
     if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, size, nnz, s->vals, s->cols);
+    if (!rc && s->rm_ok) s->rm_nwg = spmm_rm_grid(dtype, nRHS, size, s->plan.max_quad, true);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(ctx->stream);  // host matrix arrays may go away after return
         if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("solver_create sync: ") + hipGetErrorString(e));

@@ -79,7 +79,7 @@ def main():
                 res[cfg]["cg_it_s"].append(40 / (time.perf_counter() - t0))
             s.close()
             for k, v in pairs:      # back to defaults (0 = auto for every knob used here except spmm_rowmajor)
-                pkg._lib.check(lib.cgamd_tune(k.encode(), 1 if k == "spmm_rowmajor" else 0))
+                pkg._lib.check(lib.cgamd_tune(k.encode(), {"spmm_rowmajor": 1, "spmm_ynt": -1}.get(k, 0)))
     for cfg in args.cfgs:
         us = min(res[cfg]["spmm_us"])
         out = {"cfg": cfg, "n": n, "nnz": nnz, "dtype": args.dtype, "nrhs": nrhs, "spmm_us_min": round(us, 1),
