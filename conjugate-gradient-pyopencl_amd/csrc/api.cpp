@@ -39,6 +39,8 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmv_chunk_kb") g_tune.spmv_chunk_kb = value;
     else if (k == "spmv_slice_kb") g_tune.spmv_slice_kb = value;
     else if (k == "fold_alpha") g_tune.fold_alpha = value;
+    else if (k == "two_launch") g_tune.two_launch = value;
+    else if (k == "spmm_wide_max") g_tune.spmm_wide_max = value;
     else if (k == "defer_x") g_tune.defer_x = value;
     else if (k == "alpha_two_level") g_tune.alpha_two_level = value;
     else if (k == "spmv_unroll") g_tune.spmv_unroll = value;

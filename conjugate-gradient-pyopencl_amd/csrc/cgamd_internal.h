@@ -37,6 +37,7 @@ struct SpmvPlan {
     int max_span = 0;    // largest 4-aligned nnz span of a kBlock-row slice (0 = unknown -> generic kernel)
     int kind = 0;        // kernel chosen by finalize_spmv_plan (0 generic, 5 row-block, 6 its SpMM form, 7 chunked row-block)
     int chunk_span[3] = {0, 0, 0};   // largest 4-aligned span of a 128 / 64 / 32-row slice
+    bool wide = false;   // kind 6 only: small system, one work-group per (row block, RHS) runs the single-RHS kernel
     int max_quad = 0;    // most non-zeros in 4 consecutive rows starting at a multiple of 4 (row-major SpMM: K-steps per quad)
     int lpr = 1;         // kind 7: lanes per row (2, 4, 8) = chunks per 256-row block
     int n_partials = 0;  // fused-dot partials per RHS written by that kernel
@@ -75,6 +76,8 @@ struct Tuning {
     int alpha_two_level = 1; // cg_alpha over >= 16384 partials: 32 work-groups + last-arrival combine (0 = one work-group)
     int defer_x = 1;        // fused loop: x += alpha d rides in the aypx launch (10 vector passes per iteration instead of 11)
     int fold_alpha = 1;     // small systems (<= 2048 d.q partials): alpha in the prologue of axpy2_dot, three launches per iteration
+    int two_launch = 1;     // ... and beta / d = beta d + r inside the next SpMV launch: two launches per iteration
+    int spmm_wide_max = -1; // multi-RHS, RHS-major: largest row_blocks x nRHS for the one-work-group-per-RHS form (-1 = 4096, 0 = never)
     int spmv_slice_kb = 0;  // largest 256-row LDS slice the one-lane-per-row kernel accepts, in KB (0 = kMaxSliceBytes)
     int spmv_chunk_kb = 0;  // chunked row-block kernel: preferred LDS chunk in KB (0 = kChunkBytes); smaller -> more lanes per row
     int spmv_chunked = 1;   // rows too dense for the row-block kernel: chunked row-block kernel (0 = generic kernel)
@@ -127,6 +130,14 @@ int launch_aypx_beta_x(int dtype, int n, const void *x, void *y, void *xs, long 
                        const CgScalars &sc, hipStream_t st, int vec_nt = 3);
 // small systems: alpha = delta / sum(part_dq) in the prologue (three-launch iteration); fold_alpha_ok says when
 bool fold_alpha_ok(int n_partials);
+// two-launch iteration (kernels.hip "Two-launch iteration"): the SpMV launch computes beta and d_new = beta d_old + r on the
+// fly; d_old / d_new are different buffers.  fused2_ok: the plan's row-block kernels apply and the system is small enough
+bool fused2_ok(const SpmvPlan &plan, int dtype, int nrhs, const void *vals, const int *cols);
+int launch_spmv_fused(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
+                      const void *d_old, void *d_new, const void *r, void *q, int nrhs, void *part_dq, const void *part_rr, int P,
+                      const CgScalars &sc, hipStream_t st);
+// delta / beta / history[iter] of the last iteration of an iterate() call of that loop
+int launch_cg_tail(int dtype, const void *part_rr, int P, int nrhs, const CgScalars &sc, hipStream_t st);
 int launch_axpy2_dot_alpha(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *part_dq,
                            int P, const CgScalars &sc, int nrhs, void *partials, int grid, hipStream_t st);
 // delta[r] = sum partials ; history[0][r] = delta[r] ; *iter = 0

@@ -61,6 +61,12 @@ CG_DEV double2 vsel(bool c, double2 a, double2 b) { return make_double2(c ? a.x 
 // c + a*b
 template <typename T> CG_DEV T vfma(T a, T b, T c) { return vadd(c, vmul(a, b)); }
 
+// y = a*y + x of the search-direction update (reference aypx.cl:9, complex/aypx.cl:11).  The two-launch loop recomputes
+// this value for every gathered column inside the SpMV launch and must get the bits the element-wise kernels store: the
+// library is compiled with -ffp-contract=off (csrc/Makefile), so every expression is evaluated as written -- one rounding
+// per multiply and per add, like the CPU oracle -- whatever code surrounds it.
+template <typename T> CG_DEV T vaypx(T a, T y, T x) { return vadd(vmul(a, y), x); }
+
 // widening to the accumulator type used by reductions and scalar math
 CG_DEV double to_acc(float a) { return (double)a; }
 CG_DEV double to_acc(double a) { return a; }

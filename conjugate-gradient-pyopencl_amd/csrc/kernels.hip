@@ -371,6 +371,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     }
     const int r0 = rb * BLOCK;
     const int row = r0 + t;
+    // blockIdx.y = right-hand side ("wide" multi-RHS form for small systems, where round trips, not bytes, are the cost:
+    // every right-hand side gets its own work-groups and re-stages the slice out of L2, instead of one work-group walking
+    // the right-hand sides in groups -- the reference's sub-domain shape, 16k rows x 9: SpMM 10.0 -> see DESIGN.md)
+    const T *xr = a.x + (long long)blockIdx.y * a.ldx;
+    T *yr = a.y + (long long)blockIdx.y * a.ldy;
     // The work-group's lifetime is a chain of dependent memory round trips; keep it at three: {row pointers}
     // -> {matrix slice} -> {x gather}.  The per-row pointers are loaded here, branch-free (clamped row), together
     // with the slice bounds, and only consumed after the barrier.
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
             av[j] = sv[idx];
         }
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) xv[j] = a.x[cj[j]];
+        for (int j = 0; j < UNROLL; ++j) xv[j] = xr[cj[j]];
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
             const T nxt = vfma(av[j], xv[j], sum);
@@ -404,12 +409,12 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     }
     A dot1 = vzero<A>();
     if (row < a.n) {
-        a.y[row] = sum;
-        if (FUSE_DOT) dot1 = to_acc(vmul(a.dvec[row], sum));
+        yr[row] = sum;
+        if (FUSE_DOT) dot1 = to_acc(vmul(a.dvec[row + (long long)blockIdx.y * a.ldx], sum));
     }
     if (FUSE_DOT) {
         const A tot = block_sum<BLOCK>(dot1, red);
-        if (t == 0) a.partials[rb] = tot;
+        if (t == 0) a.partials[(long long)blockIdx.y * a.row_blocks + rb] = tot;
     }
 }
 
@@ -566,6 +571,125 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowblock_kernel(SpmvArgs<T> a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Two-launch iteration for small systems (at most kFoldAlphaMax d.q partials per RHS), where launches, not bytes, are
+// what an iteration costs (the reference's own sub-domain shape, 16k rows x 9 right-hand sides, is pure launch latency):
+//   launch 1  spmv_fused_kernel   beta from the r.r partials of the PREVIOUS iteration (every work-group, same fixed order
+//                                 -> bit-identical), d_new = beta d_old + r for its own rows, q = A d_new with
+//                                 d_new[col] = beta d_old[col] + r[col] recomputed for every gathered column (vaypx: the
+//                                 same bits the stored d_new holds), d_new.q partials.  Work-group 0 records delta,
+//                                 beta and history[iter] of the previous iteration.
+//   launch 2  axpy2_dot_alpha     alpha from the d.q partials, x += alpha d_new, r -= alpha q, r.r partials, iter += 1
+// i.e. the reference's aypx (clcg.c:415) moves to the head of the NEXT iteration's SpMV launch, where it costs a second
+// gather (L2 hits at these sizes) instead of a launch.  d_old and d_new are different buffers (ping-pong): a work-group
+// may not overwrite entries of d its neighbours still gather.  The first iteration runs with beta = 0 (d_1 = r_0).
+// cg_tail_kernel (same summation order) records delta / beta / history of the LAST iteration of an iterate() call.
+// -------------------------------------------------------------------------------------------------
+template <typename T> struct FusedArgs {
+    const T *r;                     // residual (RHS-major like x)
+    T *dnew;                        // search direction of this iteration (x = previous one)
+    const typename VT<T>::acc *part_rr;
+    int P;                          // r.r partials per RHS
+    T *delta, *beta, *history;
+    int history_cap;
+    const int *iter;
+};
+
+template <typename T, int BLOCK, bool NT, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void spmv_fused_kernel(SpmvArgs<T> a, FusedArgs<T> f) {
+    using A = typename VT<T>::acc;
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    T *sv = reinterpret_cast<T *>(dyn_smem);
+    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));
+    __shared__ A red[BLOCK / kWave];
+    __shared__ T beta_s;
+    const int t = threadIdx.x, rhs = blockIdx.y;              // one right-hand side per work-group ("wide" form)
+    const int rb = rowblock_of(blockIdx.x, a.row_blocks, a.cycle);
+    if (rb < 0) return;
+    const int r0 = rb * BLOCK, row = r0 + t;
+    const T *dr = a.x + (long long)rhs * a.ldx, *rr = f.r + (long long)rhs * a.ldx;
+    const int rclamp = min(row, a.n - 1);
+    const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
+    const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
+    const int cfirst = p0 & ~3;
+    const T d_own = dr[rclamp], r_own = rr[rclamp];
+    stage_slice<T, BLOCK, NT, -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);       // slice loads in flight behind the prologue
+    {   // beta of this right-hand side: fixed order (thread-strided, wave tree, 4 wave sums) = aypx_beta_kernel's
+        const int it = *f.iter;
+        A acc = vzero<A>();
+        if (it > 0) {
+            const A *p = f.part_rr + (long long)rhs * f.P;
+            for (int i = t; i < f.P; i += BLOCK) acc = vadd(acc, p[i]);
+        }
+        const A tot = block_sum<BLOCK>(acc, red);
+        if (t == 0) {
+            T b = vzero<T>();
+            if (it > 0) {
+                const T dnT = from_acc<T>(tot);
+                const T dold = f.history[(long long)(it - 1) * a.nrhs + rhs];
+                b = from_acc<T>(acc_div(to_acc(dnT), to_acc(dold)));
+                if (blockIdx.x == 0) {
+                    f.beta[rhs] = b;
+                    f.delta[rhs] = dnT;
+                    if (it < f.history_cap) f.history[(long long)it * a.nrhs + rhs] = dnT;
+                }
+            }
+            beta_s = b;
+        }
+        __syncthreads();                                                            // also the barrier the staged slice needs
+    }
+    const T bt = beta_s;
+    const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
+    T sum = vzero<T>();
+    for (int k = s; k < e; k += UNROLL) {
+        T dv[UNROLL], rv[UNROLL], av[UNROLL];
+        int cj[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int idx = min(k + j, e - 1);
+            cj[j] = sc[idx];
+            av[j] = sv[idx];
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) { dv[j] = dr[cj[j]]; rv[j] = rr[cj[j]]; }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const T nxt = vfma(av[j], vaypx(bt, dv[j], rv[j]), sum);
+            sum = vsel(k + j < e, nxt, sum);
+        }
+    }
+    A dot1 = vzero<A>();
+    if (row < a.n) {
+        const T dn = vaypx(bt, d_own, r_own);
+        f.dnew[row + (long long)rhs * a.ldx] = dn;
+        a.y[row + (long long)rhs * a.ldy] = sum;
+        dot1 = to_acc(vmul(dn, sum));
+    }
+    const A tot = block_sum<BLOCK>(dot1, red);
+    if (t == 0) a.partials[(long long)rhs * a.row_blocks + rb] = tot;
+}
+
+// delta / beta / history of the iteration whose r.r partials are on the device (end of an iterate() call of the two-launch
+// loop): exactly what work-group 0 of the next spmv_fused launch would record, in the same summation order
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void cg_tail_kernel(FusedArgs<T> f, int nrhs) {
+    using A = typename VT<T>::acc;
+    __shared__ A red[BLOCK / kWave];
+    const int it = *f.iter, r = blockIdx.x;
+    if (it <= 0) return;
+    A acc = vzero<A>();
+    const A *p = f.part_rr + (long long)r * f.P;
+    for (int i = threadIdx.x; i < f.P; i += BLOCK) acc = vadd(acc, p[i]);
+    const A tot = block_sum<BLOCK>(acc, red);
+    if (threadIdx.x == 0) {
+        const T dnT = from_acc<T>(tot);
+        const T dold = f.history[(long long)(it - 1) * nrhs + r];
+        f.beta[r] = from_acc<T>(acc_div(to_acc(dnT), to_acc(dold)));
+        f.delta[r] = dnT;
+        if (it < f.history_cap) f.history[(long long)it * nrhs + r] = dnT;
+    }
+}
+
 // [rows][cols] -> [cols][rows]: RHS-major (the reference ABI, nRHS x N) <-> row-major (N x nRHS)
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, const T *__restrict__ in, T *__restrict__ out) {
@@ -670,7 +794,7 @@ __global__ __launch_bounds__(BLOCK) void axpy2_dot_kernel(int n, const T *__rest
 // prologue of this launch -- every work-group adds the SpMV's d.q partials in the same fixed order, so all hold the
 // bit-identical alpha = delta / d.q (clcg.c:317-327); work-group 0 records alpha and advances the iteration counter
 // (nothing else in this launch reads either).  Saves the cg_alpha launch: 18.8 -> ~14 us per iteration at 250k rows.
-constexpr int kFoldAlphaMax = 2048;
+constexpr int kFoldAlphaMax = 2048;     // N <= 524k rows; beyond, the separate cg_alpha launch is cheaper than every work-group summing
 template <typename T, int BLOCK, bool VEC>
 __global__ __launch_bounds__(BLOCK) void axpy2_dot_alpha_kernel(int n, const T *__restrict__ d, T *__restrict__ x,
                                                                 const T *__restrict__ q, T *__restrict__ rv, long long ld,
@@ -813,7 +937,7 @@ __global__ __launch_bounds__(BLOCK) void ewise_kernel(int n, const T *__restrict
     auto f = [&](T xv, T yv, T bv) -> T {
         if (OP == 0) return vadd(yv, vmul(al, xv));
         if (OP == 1) return vsub(yv, vmul(al, xv));
-        if (OP == 2) return vadd(vmul(al, yv), xv);
+        if (OP == 2) return vaypx(al, yv, xv);
         return vsub(xv, bv);
     };
     if (VEC) {
@@ -876,12 +1000,12 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_kernel(int n, const T *__rest
             const Pack<T> px = ld_pack(x + i * E);
             Pack<T> py = ld_pack(y + i * E);
 #pragma unroll
-            for (int k = 0; k < E; ++k) py.v[k] = vadd(vmul(al, py.v[k]), px.v[k]);
+            for (int k = 0; k < E; ++k) py.v[k] = vaypx(al, py.v[k], px.v[k]);
             st_pack(y + i * E, py);
         }
         i0 += npack * E;
     }
-    for (long long i = i0; i < n; i += stride) y[i] = vadd(vmul(al, y[i]), x[i]);
+    for (long long i = i0; i < n; i += stride) y[i] = vaypx(al, y[i], x[i]);
 }
 
 // the same with the deferred x += alpha d (ten-vector-pass iteration): xs = solution vector, alpha of THIS iteration
@@ -927,7 +1051,7 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_x_kernel(int n, const T *__re
 #pragma unroll
             for (int k = 0; k < E; ++k) {
                 ps.v[k] = vadd(ps.v[k], vmul(al, py.v[k]));
-                py.v[k] = vadd(vmul(bt, py.v[k]), px.v[k]);
+                py.v[k] = vaypx(bt, py.v[k], px.v[k]);
             }
             if (VNT & 1) st_pack_nt(xs + i * E, ps); else st_pack(xs + i * E, ps);
             st_pack(y + i * E, py);
@@ -937,7 +1061,7 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_x_kernel(int n, const T *__re
     for (long long i = i0; i < n; i += stride) {
         const T dv = y[i];
         xs[i] = vadd(xs[i], vmul(al, dv));
-        y[i] = vadd(vmul(bt, dv), x[i]);
+        y[i] = vaypx(bt, dv, x[i]);
     }
 }
 
@@ -1534,7 +1658,7 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_p2p_kernel(int n, const T *x,
 #pragma unroll
             for (int k = 0; k < E; ++k) {
                 ps.v[k] = vadd(ps.v[k], vmul(al, py.v[k]));
-                py.v[k] = vadd(vmul(bt, py.v[k]), px.v[k]);
+                py.v[k] = vaypx(bt, py.v[k], px.v[k]);
             }
             if (VNT & 1) st_pack_nt(xs + i * E, ps); else st_pack(xs + i * E, ps);
             st_pack(y + i * E, py);
@@ -1544,7 +1668,7 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_p2p_kernel(int n, const T *x,
     for (long long i = i0; i < n; i += stride) {
         const T dv = y[i];
         xs[i] = vadd(xs[i], vmul(al, dv));
-        y[i] = vadd(vmul(bt, dv), x[i]);
+        y[i] = vaypx(bt, dv, x[i]);
     }
 }
 
@@ -1729,12 +1853,12 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
     dim3 grid(plan.grid), block(kBlock);
-    const int variant = (vec && nrhs == 1 && plan.kind == 5) ? 5 : 0;
+    const int variant = (vec && ((nrhs == 1 && plan.kind == 5) || (nrhs > 1 && plan.kind == 6 && plan.wide))) ? 5 : 0;
     if (variant == 5) {
         a.cap = (plan.max_span + 3) & ~3;
         a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
         const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + (size_t)g_tune.spmv_lds_pad;
-        dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : rowblock_grid(plan.row_blocks, a.cycle));
+        dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : rowblock_grid(plan.row_blocks, a.cycle), nrhs);
         if (rb_list && rb_count <= 0) return CGAMD_OK;
         const bool nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
         // value stream interleaved across the lanes in 16-byte chunks (stage_slice_ilv): "spmv_ilv" 1/0, -1 = auto
@@ -1900,6 +2024,10 @@ void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nn
     }
     if (kind != 5 && kind != 7) kind = 0;
     if (kind == 5 && nrhs > 1) kind = 6;      // SpMM form of the row-block kernel
+    // small multi-RHS systems are bound by round trips per work-group, not by bytes: one work-group per (row block, RHS)
+    // runs the single-RHS kernel ("wide" form) instead of one work-group walking the right-hand sides in register groups
+    plan->wide = kind == 6 && (long long)plan->row_blocks * nrhs <= (g_tune.spmm_wide_max >= 0 ? g_tune.spmm_wide_max : 4096) &&
+                 (size_t)plan->max_span * (dtype_size(dtype) + 4) <= (size_t)kMaxSliceBytes;
     plan->kind = kind;
     plan->n_partials = kind ? plan->row_blocks : plan->grid;
 }
@@ -2154,6 +2282,58 @@ int launch_aypx_beta(int dtype, int n, const void *x, void *y, long long ld, con
     if (n <= 0) return CGAMD_OK;
     const bool v = vec_ok(dtype, ld, nrhs, {x, y});
     CG_DISPATCH(dtype, aypx_beta_impl, n, x, y, ld, partials, P, nrhs, sc, v, st);
+}
+
+// ---- two-launch iteration: SpMV fused with the previous iteration's beta / aypx ---------------------------------
+bool fused2_ok(const SpmvPlan &plan, int dtype, int nrhs, const void *vals, const int *cols) {
+    (void)dtype;
+    if (g_tune.two_launch == 0 || !fold_alpha_ok(plan.n_partials)) return false;
+    if (!aligned16(vals) || !aligned16(cols)) return false;
+    // measured (profiles/r2/configs_two_launch.log): the second gather pays for the saved launch up to a few hundred
+    // thousand rows; at N = 1M (3907 row blocks) the three/four-launch loops are faster
+    return nrhs == 1 ? plan.kind == 5 : (plan.kind == 6 && plan.wide);
+}
+template <typename T>
+static int spmv_fused_impl(const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
+                           const void *d_old, void *d_new, const void *r, void *q, int nrhs, void *part_dq, const void *part_rr, int P,
+                           const CgScalars &sc, hipStream_t st) {
+    using A = typename VT<T>::acc;
+    SpmvArgs<T> a;
+    a.n = n; a.nrhs = nrhs; a.nnz = nnz;
+    a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
+    a.x = static_cast<const T *>(d_old); a.ldx = n;
+    a.y = static_cast<T *>(q); a.ldy = n;
+    a.dvec = nullptr; a.partials = static_cast<A *>(part_dq);
+    a.row_blocks = plan.row_blocks; a.rb_list = nullptr; a.rb_count = 0; a.ynt = 0;
+    a.cap = (plan.max_span + 3) & ~3;
+    a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
+    FusedArgs<T> f;
+    f.r = static_cast<const T *>(r); f.dnew = static_cast<T *>(d_new);
+    f.part_rr = static_cast<const A *>(part_rr); f.P = P;
+    f.delta = (T *)sc.delta; f.beta = (T *)sc.beta; f.history = (T *)sc.history; f.history_cap = sc.history_cap; f.iter = sc.iter;
+    const dim3 g(rowblock_grid(plan.row_blocks, a.cycle), nrhs), b(kBlock);
+    const bool nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
+    const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
+    constexpr int U = sizeof(T) > 8 ? 4 : 8;
+    if (nt) hipLaunchKernelGGL((spmv_fused_kernel<T, kBlock, true, U>), g, b, lds, st, a, f);
+    else hipLaunchKernelGGL((spmv_fused_kernel<T, kBlock, false, U>), g, b, lds, st, a, f);
+    return check_launch("spmv_fused");
+}
+int launch_spmv_fused(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
+                      const void *d_old, void *d_new, const void *r, void *q, int nrhs, void *part_dq, const void *part_rr, int P,
+                      const CgScalars &sc, hipStream_t st) {
+    CG_DISPATCH(dtype, spmv_fused_impl, plan, n, nnz, vals, ptr, cols, d_old, d_new, r, q, nrhs, part_dq, part_rr, P, sc, st);
+}
+template <typename T> static int cg_tail_impl(const void *part_rr, int P, int nrhs, const CgScalars &sc, hipStream_t st) {
+    using A = typename VT<T>::acc;
+    FusedArgs<T> f;
+    f.r = nullptr; f.dnew = nullptr; f.part_rr = static_cast<const A *>(part_rr); f.P = P;
+    f.delta = (T *)sc.delta; f.beta = (T *)sc.beta; f.history = (T *)sc.history; f.history_cap = sc.history_cap; f.iter = sc.iter;
+    hipLaunchKernelGGL((cg_tail_kernel<T, kBlock>), dim3(nrhs), dim3(kBlock), 0, st, f, nrhs);
+    return check_launch("cg_tail");
+}
+int launch_cg_tail(int dtype, const void *part_rr, int P, int nrhs, const CgScalars &sc, hipStream_t st) {
+    CG_DISPATCH(dtype, cg_tail_impl, part_rr, P, nrhs, sc, st);
 }
 
 // ---- diagonally preconditioned CG -----------------------------------------------------------------

@@ -35,8 +35,9 @@ struct cgamd_solver {
     CgScalars sc;
     bool rhs_set = false;
     int iters = 0;  // iterations enqueued since set_rhs
-    hipGraphExec_t g1 = nullptr, gU = nullptr;
-    hipGraph_t g1g = nullptr, gUg = nullptr;
+    // captured iteration sequences, per parity of the iteration count they start at (the two-launch loop ping-pongs d)
+    hipGraphExec_t g1[2] = {nullptr, nullptr}, gU[2] = {nullptr, nullptr};
+    hipGraph_t g1g[2] = {nullptr, nullptr}, gUg[2] = {nullptr, nullptr};
     int U = 8;
     bool graph_failed = false;
     bool defer_x = true;    // x += alpha d in the aypx launch (fixed at creation: captured graphs depend on it)
@@ -45,15 +46,20 @@ struct cgamd_solver {
     int rm_nwg = 0, rm_vgrid = 0;
     // event hooks around the SpMV launch of enqueue_iteration (cgamd_solver_iterate_timed)
     hipEvent_t *ev_pair = nullptr;
+    // two-launch loop (small systems): d of iteration k lives in dbuf[k & 1] (dbuf[0] = d, the initial r); decided at creation
+    bool fused2 = false;
+    void *d2 = nullptr;
 };
 
 static void destroy_graphs(cgamd_solver *s) {
-    if (s->g1) (void)hipGraphExecDestroy(s->g1);
-    if (s->gU) (void)hipGraphExecDestroy(s->gU);
-    if (s->g1g) (void)hipGraphDestroy(s->g1g);
-    if (s->gUg) (void)hipGraphDestroy(s->gUg);
-    s->g1 = s->gU = nullptr;
-    s->g1g = s->gUg = nullptr;
+    for (int p = 0; p < 2; ++p) {
+        if (s->g1[p]) (void)hipGraphExecDestroy(s->g1[p]);
+        if (s->gU[p]) (void)hipGraphExecDestroy(s->gU[p]);
+        if (s->g1g[p]) (void)hipGraphDestroy(s->g1g[p]);
+        if (s->gUg[p]) (void)hipGraphDestroy(s->gUg[p]);
+        s->g1[p] = s->gU[p] = nullptr;
+        s->g1g[p] = s->gUg[p] = nullptr;
+    }
 }
 
 static int dmalloc(void **p, size_t bytes, const char *what) {
@@ -74,11 +80,18 @@ static int validate_csr_host(int n, long long nnz, const int *ptr, const int *co
 }
 
 // the SpMV (SpMM) launch of the iteration, bracketed by the caller's event pair when one is installed
-static int enqueue_spmv(cgamd_solver *s, hipStream_t st) {
+static void *dbuf(cgamd_solver *s, int k) { return (s->fused2 && (k & 1)) ? s->d2 : s->d; }
+static bool fused2_now(const cgamd_solver *s) { return s->fused2 && !s->rm && !s->mdiag && !(s->flags & CGAMD_UNFUSED); }
+
+// k = iterations already enqueued since set_rhs (the iteration being enqueued is number k + 1)
+static int enqueue_spmv(cgamd_solver *s, int k, hipStream_t st) {
     const int dt = s->dtype, n = s->n, nr = s->nrhs;
     if (s->ev_pair) CG_HIP(hipEventRecord(s->ev_pair[0], st));
     int rc;
-    if (s->rm) rc = launch_spmm_rm(dt, n, s->nnz, s->vals, s->ptr, s->cols, s->d, s->q, nr, s->part_dq, s->plan.max_quad, st);
+    if (fused2_now(s))
+        rc = launch_spmv_fused(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, dbuf(s, k), dbuf(s, k + 1), s->r, s->q, nr, s->part_dq,
+                               s->part_rr, s->vgrid, s->sc, st);
+    else if (s->rm) rc = launch_spmm_rm(dt, n, s->nnz, s->vals, s->ptr, s->cols, s->d, s->q, nr, s->part_dq, s->plan.max_quad, st);
     else if (s->flags & CGAMD_UNFUSED) rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, nullptr, nullptr, st);
     else rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st);
     if (rc) return rc;
@@ -86,25 +99,29 @@ static int enqueue_spmv(cgamd_solver *s, hipStream_t st) {
     return CGAMD_OK;
 }
 
-static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
+static int enqueue_iteration(cgamd_solver *s, int k, hipStream_t st) {
     const int dt = s->dtype, n = s->n, nr = s->nrhs;
     int rc;
+    if (fused2_now(s)) {   // two launches: [beta, d = beta d + r, q = A d, d.q] and [alpha, x += alpha d, r -= alpha q, r.r]
+        if ((rc = enqueue_spmv(s, k, st))) return rc;
+        return launch_axpy2_dot_alpha(dt, n, dbuf(s, k + 1), s->x, s->q, s->r, n, s->part_dq, s->plan.n_partials, s->sc, nr, s->part_rr, s->vgrid, st);
+    }
     if (s->rm) {      // row-major block: SpMM on the matrix cores (+ d.q partials), alpha, r update (+ r.r), beta, x and d updates
-        if ((rc = enqueue_spmv(s, st))) return rc;
+        if ((rc = enqueue_spmv(s, k, st))) return rc;
         if ((rc = launch_cg_alpha(dt, s->part_dq, s->rm_nwg, nr, s->sc, st))) return rc;
         if ((rc = launch_rm_axpy_dot(dt, n, nr, s->q, s->r, s->sc.alpha, s->part_rr, s->rm_vgrid, st))) return rc;
         if ((rc = launch_cg_beta(dt, s->part_rr, s->rm_vgrid, nr, s->sc, st))) return rc;
         return launch_rm_aypx_x(dt, n, nr, s->r, s->d, s->x, s->sc.alpha, s->sc.beta, s->rm_vgrid, st);
     }
     if (s->mdiag) {   // preconditioned recurrence (helmFE_var.py:560-585); delta holds rho = r.z
-        if ((rc = enqueue_spmv(s, st))) return rc;
+        if ((rc = enqueue_spmv(s, k, st))) return rc;
         if ((rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
         if ((rc = launch_pcg_axpy2_dot2(dt, false, n, s->d, s->x, s->q, s->r, s->mdiag, n, s->sc.alpha, nr, s->part_rz, s->part_rr,
                                         s->vgrid, st))) return rc;
         return launch_pcg_aypx_beta(dt, n, s->r, s->d, s->mdiag, n, s->part_rz, s->part_rr, s->vgrid, nr, s->sc, s->rho2, s->x, st);
     }
     if (!(s->flags & CGAMD_UNFUSED)) {
-        if ((rc = enqueue_spmv(s, st))) return rc;
+        if ((rc = enqueue_spmv(s, k, st))) return rc;
         const bool fold = fold_alpha_ok(s->plan.n_partials);      // small system: alpha in the next launch's prologue
         if (!fold && (rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
         if (s->defer_x) {     // r -= alpha q (+ r.r) ; then beta, x += alpha d, d = beta d + r : 3 + 5 vector passes
@@ -118,7 +135,7 @@ static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
         if (rc) return rc;
         return launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
     }
-    if ((rc = enqueue_spmv(s, st))) return rc;
+    if ((rc = enqueue_spmv(s, k, st))) return rc;
     if ((rc = launch_dot_partials(dt, n, s->d, s->q, n, nr, s->part_rr, s->vgrid, st))) return rc;
     if ((rc = launch_cg_alpha(dt, s->part_rr, s->vgrid, nr, s->sc, st))) return rc;
     if ((rc = launch_axpy(dt, n, s->d, s->x, n, s->sc.alpha, 1, nr, st))) return rc;
@@ -128,12 +145,12 @@ static int enqueue_iteration(cgamd_solver *s, hipStream_t st) {
     return launch_aypx(dt, n, s->r, s->d, n, s->sc.beta, nr, st);
 }
 
-static int capture(cgamd_solver *s, int iters, hipGraph_t *g, hipGraphExec_t *ge) {
+static int capture(cgamd_solver *s, int k0, int iters, hipGraph_t *g, hipGraphExec_t *ge) {
     hipStream_t st = s->ctx->stream;
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
     int rc = CGAMD_OK;
-    for (int i = 0; i < iters && rc == CGAMD_OK; ++i) rc = enqueue_iteration(s, st);
+    for (int i = 0; i < iters && rc == CGAMD_OK; ++i) rc = enqueue_iteration(s, k0 + i, st);
     e = hipStreamEndCapture(st, g);
     if (rc != CGAMD_OK) return rc;
     if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -206,10 +223,11 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
         // stream up to four of them in lock-step, and equal strides between them alias onto the same HBM channels
         const size_t skew = (size_t)(g_tune.vec_skew >= 0 ? g_tune.vec_skew : 0);
         const size_t pitch = ((vbytes + 4095) & ~(size_t)4095) + skew;
-        if (!rc) rc = dmalloc(&s->slab, pitch * 5 + 4096, "vectors");
+        if (!rc) rc = dmalloc(&s->slab, pitch * 6 + 4096, "vectors");
         if (!rc) {
             char *base = static_cast<char *>(s->slab);
             s->x = base; s->r = base + pitch; s->d = base + 2 * pitch; s->q = base + 3 * pitch; s->b = base + 4 * pitch;
+            s->d2 = base + 5 * pitch;
         }
     }
     // the row-major SpMM writes one d.q partial per work-group of its sweep: at most 8 XCDs x 32 CUs x 8 work-groups
@@ -226,6 +244,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) rc = compute_spmv_plan(s->ptr, s->cols, size, s->sc.iter, ctx->stream, &s->plan);
     if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, size, nnz, s->vals, s->cols);
     if (!rc && s->rm_ok) s->rm_nwg = spmm_rm_grid(dtype, nRHS, size, s->plan.max_quad, true);
+    if (!rc) s->fused2 = fused2_ok(s->plan, dtype, nRHS, s->vals, s->cols);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(ctx->stream);  // host matrix arrays may go away after return
         if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("solver_create sync: ") + hipGetErrorString(e));
@@ -341,26 +360,30 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
     CG_HIP(hipSetDevice(s->ctx->device));
     if (int rc = ensure_history(s, s->iters + nIterations + 1)) return rc;
     hipStream_t st = s->ctx->stream;
-    int left = nIterations;
+    int left = nIterations, k = s->iters;
     const bool use_graph = !(s->flags & CGAMD_NO_GRAPH) && !s->graph_failed;
-    if (use_graph) {
-        if (!s->g1 && capture(s, 1, &s->g1g, &s->g1) != CGAMD_OK) { s->graph_failed = true; destroy_graphs(s); }
-        if (!s->graph_failed && left >= s->U && !s->gU && capture(s, s->U, &s->gUg, &s->gU) != CGAMD_OK) {
+    const bool two = fused2_now(s);
+    // graphs start at a fixed parity of the iteration count (d ping-pongs in the two-launch loop; U is even)
+    while (use_graph && !s->graph_failed && left > 0) {
+        const int par = two ? (k & 1) : 0;
+        const bool big = left >= s->U;
+        hipGraphExec_t &ge = big ? s->gU[par] : s->g1[par];
+        if (!ge && capture(s, par, big ? s->U : 1, big ? &s->gUg[par] : &s->g1g[par], &ge) != CGAMD_OK) {
             s->graph_failed = true;
             destroy_graphs(s);
+            break;
         }
+        CG_HIP(hipGraphLaunch(ge, st));
+        left -= big ? s->U : 1;
+        k += big ? s->U : 1;
     }
-    if (use_graph && !s->graph_failed) {
-        while (left >= s->U && s->gU) { CG_HIP(hipGraphLaunch(s->gU, st)); left -= s->U; }
-        while (left > 0) { CG_HIP(hipGraphLaunch(s->g1, st)); --left; }
-    } else {
-        for (; left > 0; --left)
-            if (int rc = enqueue_iteration(s, st)) {
-                s->iters += nIterations - left + 1;      // the device counter may have advanced for the broken iteration too
-                return rc;
-            }
-    }
-    s->iters += nIterations;
+    for (; left > 0; --left, ++k)
+        if (int rc = enqueue_iteration(s, k, st)) {
+            s->iters = k + 1;      // the device counter may have advanced for the broken iteration too
+            return rc;
+        }
+    s->iters = k;
+    if (two && nIterations > 0) return launch_cg_tail(s->dtype, s->part_rr, s->vgrid, s->nrhs, s->sc, st);
     return CGAMD_OK;
 }
 
@@ -382,12 +405,13 @@ int cgamd_solver_iterate_timed(cgamd_solver *s, int nIterations, float *spmv_ms_
     if (e == hipSuccess) e = hipEventRecord(ev[(size_t)2 * nIterations], st);
     for (int i = 0; i < nIterations && e == hipSuccess && !rc; ++i) {
         s->ev_pair = &ev[(size_t)2 * i];
-        rc = enqueue_iteration(s, st);
+        rc = enqueue_iteration(s, s->iters + i, st);
         ++done;
     }
     s->ev_pair = nullptr;
     s->iters += done;       // whatever was enqueued counts, also on the error paths below
     if (e == hipSuccess && !rc) e = hipEventRecord(ev[(size_t)2 * nIterations + 1], st);
+    if (e == hipSuccess && !rc && fused2_now(s)) rc = launch_cg_tail(s->dtype, s->part_rr, s->vgrid, s->nrhs, s->sc, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     double sum = 0.0;
     float total = 0.f;
@@ -436,7 +460,7 @@ int cgamd_solver_history(cgamd_solver *s, void *history, int max_entries) {
 
 void *cgamd_solver_vector(cgamd_solver *s, int which) {
     if (!s) return nullptr;
-    switch (which) { case 0: return s->x; case 1: return s->r; case 2: return s->d; case 3: return s->q; default: return nullptr; }
+    switch (which) { case 0: return s->x; case 1: return s->r; case 2: return dbuf(s, s->iters); case 3: return s->q; default: return nullptr; }
 }
 
 int cgamd_solver_solve(cgamd_solver *s, const void *b, void *x, int nIterations, void *history) {

@@ -104,6 +104,16 @@ if "c4" in which or "c4mfma" in which:
             print(json.dumps({"config": f"C4 SpMM MFMA row-major nrhs={nrhs} N=1M {nm}", "spmm_us": us, "spmm_gbs": sb / us / 1e3,
                               "spmm_pct_of_8tbs": 100 * sb / us / 1e3 / 8000}), flush=True)
         s.close()
+if "asprec" in which:
+    # the reference's own sub-domain solve (as_prec, p_h-PY_C-CL.py:1918-1953): complex64, ~16k rows (helmFE_var(128) has the
+    # pattern and size of local_rect for W_s + 2 ol = 128), n_my = 9 right-hand sides, CGMaxIT = 256 fixed iterations
+    import cg_numpy
+    N = 128
+    hp, hx, hd = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    ip, ix = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
+    da = torch.from_numpy(hd.astype(np.complex64)).to(dev)
+    for nrhs in (9, 1):
+        run(f"as_prec shape: helmFE_var(128) c64 n=16384 nrhs={nrhs}", ip, ix, da, np.complex64, nrhs, iters=2560, reps=30)
 if "report" in which:
     # context only: the one matrix of the upstream report that can be regenerated offline --
     # helm_fem: complex, n = 16 384, nnz = 113 666 = helmFE_var(N=128); the report ran 5000 iterations in fp32 complex and
