@@ -12,10 +12,11 @@ No CPU fallback: importing works anywhere, computing needs the built library and
 from . import _lib, cl, mmio, generators  # noqa: F401
 from ._lib import CgAmdError, LIB_PATH, LEGACY_LIB_PATH  # noqa: F401
 from .cl import (CG, Context, CommandQueue, Device, DeviceBuffer, Solver, conjugate_gradient_multi_gpu,  # noqa: F401
-                 solve_subdomains,
+                 solve_subdomains, solve_rhs_sharded, distribute_workloads_on_devices, distribute_computations_with_threads,
                  get_gpu_devices, initialize_cl_environment, initialize_cl_environment_with_device,
                  load_and_build_kernels)
 
 __all__ = ["cl", "mmio", "generators", "CG", "Solver", "Context", "CommandQueue", "Device", "DeviceBuffer",
-           "conjugate_gradient_multi_gpu", "get_gpu_devices", "initialize_cl_environment",
+           "conjugate_gradient_multi_gpu", "solve_rhs_sharded", "distribute_workloads_on_devices",
+           "distribute_computations_with_threads", "get_gpu_devices", "initialize_cl_environment",
            "initialize_cl_environment_with_device", "load_and_build_kernels", "CgAmdError"]

@@ -21,6 +21,7 @@ Differences a caller can observe (all documented in INTEGRATION.md):
 There is no CPU fallback: without the HIP library or a GPU these functions raise.
 """
 import ctypes
+import threading
 
 import numpy as np
 
@@ -425,15 +426,98 @@ def CG(ctx, queue, kernels, size, non_zeros, a_values, b_values, a_pointers, a_c
     return (x, hist) if return_history else x
 
 
+_device_contexts = {}
+_device_contexts_lock = threading.Lock()
+
+
+def _context_on(device):
+    """a cached Context on `device` (a Device or an index) -- used when a caller names a device that its ctx is not on"""
+    index = device.index if isinstance(device, Device) else int(device)
+    with _device_contexts_lock:
+        ctx = _device_contexts.get(index)
+        if ctx is None or not getattr(ctx, "handle", None):
+            ctx = _device_contexts[index] = Context(index)
+        return ctx
+
+
 def conjugate_gradient_multi_gpu(ctx, queue, kernels, size, non_zeros, a_values, b_values, a_pointers, a_cols, x,
                                  n_rhs, n_iterations, device):
     """reference cl.py:203-360: the per-device worker of the RHS-sharded multi-GPU mode
     (p_h-PY_C-CL-multi-GPU.py:2123-2181).  Each device gets the whole matrix and a slice of the
-    right-hand sides; there is no inter-GPU communication.  Thread-safe per (ctx, queue): ctypes
-    releases the GIL during the call, so one Python thread per device runs concurrently, as in the
-    reference.  (The row-partitioned RCCL solver lives in .dist.)"""
+    right-hand sides; there is no inter-GPU communication.  `device` selects where the solve runs: the reference passes
+    the device its ctx/queue were built for (multi-GPU.py:2136-2137,2160-2163); when ctx lives on another device a cached
+    context on `device` is used instead.  Thread-safe per (ctx, queue): ctypes releases the GIL during the calls, every
+    handle carries its own configuration snapshot and stream, so one Python thread per device runs concurrently, as in
+    the reference.  (The row-partitioned RCCL solver lives in .dist.)"""
+    if device is not None:
+        index = device.index if isinstance(device, Device) else int(device)
+        if index != ctx.device:
+            ctx = _context_on(index)
     return CG(ctx, queue, kernels, size, non_zeros, a_values, b_values, a_pointers, a_cols, x, n_rhs, n_iterations,
               device=device)
+
+
+def distribute_workloads_on_devices(devices, n_subdomain):
+    """reference p_h-PY_C-CL-multi-GPU.py:2123-2142: split n_subdomain right-hand sides over the devices (the first
+    n_subdomain % n_gpus devices take one more) and build one (ctx, queue, kernels) per device.
+    -> {device: (start, end, ctx, queue, kernels)}.  `devices` may name the same physical device several times
+    (distinct Device objects): each entry gets its own context, stream and thread."""
+    n_gpus = len(devices)
+    tasks_per_process, extra_tasks = divmod(n_subdomain, n_gpus)
+    distribution, start = {}, 0
+    for i in range(n_gpus):
+        end = start + tasks_per_process + (1 if i < extra_tasks else 0)
+        ctx, queue = initialize_cl_environment_with_device(devices[i])
+        kernels = load_and_build_kernels(ctx, end - start)
+        distribution[devices[i]] = (start, end, ctx, queue, kernels)
+        start = end
+    return distribution
+
+
+def distribute_computations_with_threads(size, non_zeros, a_values, b_values, a_pointers, a_cols, x_values, n_rhs,
+                                         n_iterations, workloads):
+    """reference p_h-PY_C-CL-multi-GPU.py:2144-2181: one threading.Thread per workload entry; thread `dev` solves the
+    right-hand sides [start, end) with the whole matrix on its device (conjugate_gradient_multi_gpu) and copies its
+    slice of the solution back into x_values under a lock.  Returns x_values.  An exception in a worker is re-raised
+    here after all threads have been joined (the reference lets the thread die silently)."""
+    lock = threading.Lock()
+    errors = []
+
+    def worker(dev):
+        try:
+            start, end, ctx, queue, kernels = workloads[dev]
+            if end <= start:
+                return
+            b = np.ascontiguousarray(b_values[start * size:end * size])
+            x = np.ascontiguousarray(x_values[start * size:end * size])
+            result_x = conjugate_gradient_multi_gpu(ctx, queue, kernels, size, non_zeros, a_values, b, a_pointers, a_cols, x,
+                                                    end - start, n_iterations, dev)
+            with lock:
+                x_values[start * size:end * size] = result_x
+        except BaseException as e:      # noqa: BLE001 -- reported by the joining thread
+            with lock:
+                errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(dev,)) for dev in workloads]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return x_values
+
+
+def solve_rhs_sharded(devices, size, non_zeros, a_values, b_values, a_pointers, a_cols, x_values, n_rhs, n_iterations):
+    """The reference's multi-GPU mode in one call (`UseCG == 6`, p_h-PY_C-CL-multi-GPU.py:1934-1944): matrix replicated,
+    right-hand sides sharded over `devices`, one thread each, no inter-GPU communication."""
+    workloads = distribute_workloads_on_devices(devices, n_rhs)
+    try:
+        return distribute_computations_with_threads(size, non_zeros, a_values, b_values, a_pointers, a_cols, x_values,
+                                                    n_rhs, n_iterations, workloads)
+    finally:
+        for _, _, ctx, _, _ in workloads.values():
+            ctx.close()
 
 
 def cg(size, non_zeros, a_values, b_values, a_pointers, a_cols, x, n_rhs, n_iterations, is_complex):

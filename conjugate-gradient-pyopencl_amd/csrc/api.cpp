@@ -27,6 +27,8 @@ size_t cgamd_dtype_size(int dtype) { return dtype_size(dtype); }
 int cgamd_tune(const char *key, int value) {
     if (!key) return fail(CGAMD_ERR_INVALID, "tune: null key");
     const std::string k(key);
+    bool known = true;
+    tune_set([&](Tuning &g_tune) {
     if (k == "spmv_variant") g_tune.spmv_variant = value;
     else if (k == "spmv_nt") g_tune.spmv_nt = value;
     else if (k == "spmv_grid") g_tune.spmv_grid = value;
@@ -53,7 +55,9 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmv_policy") g_tune.spmv_policy = value;
     else if (k == "vec_nt") g_tune.vec_nt = value;
     else if (k == "vec_skew") g_tune.vec_skew = value & ~15;
-    else return fail(CGAMD_ERR_INVALID, "tune: unknown key " + k);
+    else known = false;
+    });
+    if (!known) return fail(CGAMD_ERR_INVALID, "tune: unknown key " + k);
     return CGAMD_OK;
 }
 
@@ -80,6 +84,7 @@ int cgamd_ctx_create(int device, cgamd_ctx **out) {
     *out = nullptr;
     int n = cgamd_device_count();
     if (n <= 0) return fail(CGAMD_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    thread_hip_setup();
     if (device < 0 || device >= n) return fail(CGAMD_ERR_INVALID, "ctx_create: device index out of range");
     CG_HIP(hipSetDevice(device));
     cgamd_ctx *c = new cgamd_ctx();
@@ -117,6 +122,7 @@ void *cgamd_ctx_stream(cgamd_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int cgamd_ctx_device(cgamd_ctx *c) { return c ? c->device : -1; }
 int cgamd_ctx_synchronize(cgamd_ctx *c) {
     if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    thread_hip_setup();
     CG_HIP(hipSetDevice(c->device));
     CG_HIP(hipStreamSynchronize(c->stream));
     return CGAMD_OK;
@@ -124,6 +130,7 @@ int cgamd_ctx_synchronize(cgamd_ctx *c) {
 
 int cgamd_malloc(cgamd_ctx *c, size_t bytes, void **dptr) {
     if (!c || !dptr) return fail(CGAMD_ERR_INVALID, "malloc: null argument");
+    thread_hip_setup();
     CG_HIP(hipSetDevice(c->device));
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
     if (e != hipSuccess) return fail(CGAMD_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -131,12 +138,14 @@ int cgamd_malloc(cgamd_ctx *c, size_t bytes, void **dptr) {
 }
 int cgamd_free(cgamd_ctx *c, void *dptr) {
     if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    thread_hip_setup();
     CG_HIP(hipSetDevice(c->device));
     if (dptr) CG_HIP(hipFree(dptr));
     return CGAMD_OK;
 }
 int cgamd_memcpy_h2d(cgamd_ctx *c, void *dst, const void *src, size_t bytes) {
     if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    thread_hip_setup();
     CG_HIP(hipSetDevice(c->device));
     CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     CG_HIP(hipStreamSynchronize(c->stream));
@@ -144,6 +153,7 @@ int cgamd_memcpy_h2d(cgamd_ctx *c, void *dst, const void *src, size_t bytes) {
 }
 int cgamd_memcpy_d2h(cgamd_ctx *c, void *dst, const void *src, size_t bytes) {
     if (!c) return fail(CGAMD_ERR_INVALID, "ctx is NULL");
+    thread_hip_setup();
     CG_HIP(hipSetDevice(c->device));
     CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     CG_HIP(hipStreamSynchronize(c->stream));
@@ -167,6 +177,7 @@ static int check_op(cgamd_ctx *c, int dtype, int size, int nRHS, const char *wha
     if (!c) return fail(CGAMD_ERR_INVALID, std::string(what) + ": ctx is NULL");
     if (dtype < 0 || dtype > 3) return fail(CGAMD_ERR_INVALID, std::string(what) + ": bad dtype");
     if (size < 0 || nRHS < 1) return fail(CGAMD_ERR_INVALID, std::string(what) + ": bad size/nRHS");
+    thread_hip_setup();
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return fail(CGAMD_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
     return CGAMD_OK;

@@ -86,7 +86,25 @@ struct Tuning {
     int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)
     int vec_grid = 0;       // vector kernels: 0 = auto
 };
+// g_tune is the process-wide configuration cgamd_tune edits (under a mutex).  Nothing on a compute path reads it
+// directly: every solver / distributed handle copies it at creation (tune_snapshot()), and each C-ABI entry installs the
+// handle's copy for the calling thread (TuneScope) -- launches of a handle always run with the configuration it was
+// created under, whatever other threads set meanwhile (reference threading model: one thread per device, each with its own
+// context and solver, p_h-PY_C-CL-multi-GPU.py:2149-2179).  tune() = the installed copy, or a per-thread snapshot of the
+// global one for handle-less entries.
 extern Tuning g_tune;
+Tuning tune_snapshot();
+const Tuning &tune();
+} // namespace cgamd
+#include <functional>
+namespace cgamd {
+void tune_set(const std::function<void(Tuning &)> &edit);
+void thread_hip_setup();      // once per thread: stream-capture interaction mode "relaxed" (see kernels.hip)
+struct TuneScope {
+    const Tuning *prev;
+    explicit TuneScope(const Tuning *t);
+    ~TuneScope();
+};
 int vec_grid(long long n_elems_per_rhs, int dtype);
 
 // ---- kernel launchers (all asynchronous on `st`) ------------------------------

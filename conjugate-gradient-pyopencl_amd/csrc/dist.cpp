@@ -81,6 +81,7 @@ int need_rccl() {
 }  // namespace
 
 struct cgamd_dist {
+    Tuning tune;            // configuration this handle was created under (installed per call: TuneScope)
     cgamd_ctx *ctx = nullptr;
     int dtype = 0, rank = 0, nranks = 1, n_local = 0, n_halo = 0, flags = 0;
     long long nnz = 0;
@@ -312,6 +313,8 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     CG_HIP(hipSetDevice(ctx->device));
 
     cgamd_dist *d = new cgamd_dist();
+    d->tune = tune_snapshot();
+    TuneScope ts(&d->tune);
     d->ctx = ctx; d->dtype = dtype; d->rank = rank; d->nranks = nranks; d->n_local = n_local; d->n_halo = n_halo;
     d->nnz = nnz_local; d->vals = aValues; d->ptr = aPointers; d->cols = aCols; d->flags = flags;
     d->p2p = (flags & CGAMD_DIST_P2P) != 0;
@@ -411,6 +414,7 @@ int cgamd_dist_destroy(cgamd_dist *d) {
 
 int cgamd_dist_set_rhs(cgamd_dist *d, const void *b_local, const void *x0_local) {
     if (!d || !b_local) return fail(CGAMD_ERR_INVALID, "dist_set_rhs: null argument");
+    TuneScope ts(&d->tune);
     CG_HIP(hipSetDevice(d->ctx->device));
     hipStream_t st = d->ctx->stream;
     const size_t vs = dtype_size(d->dtype), vb = (size_t)d->n_local * vs;
@@ -435,6 +439,7 @@ int cgamd_dist_set_rhs(cgamd_dist *d, const void *b_local, const void *x0_local)
 
 int cgamd_dist_iterate(cgamd_dist *d, int nIterations) {
     if (!d) return fail(CGAMD_ERR_INVALID, "dist_iterate: null handle");
+    TuneScope ts(&d->tune);
     if (!d->rhs_set) return fail(CGAMD_ERR_STATE, "dist_iterate: call dist_set_rhs first");
     if (nIterations < 0) return fail(CGAMD_ERR_INVALID, "dist_iterate: negative iteration count");
     CG_HIP(hipSetDevice(d->ctx->device));
@@ -513,6 +518,7 @@ int cgamd_p2p_mailbox_free(cgamd_ctx *ctx, void *mailbox) {
 
 int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, const int *dst_offset) {
     if (!d || !my_mailbox || !handles) return fail(CGAMD_ERR_INVALID, "dist_attach_p2p: null argument");
+    TuneScope ts(&d->tune);
     if (!d->p2p) return fail(CGAMD_ERR_STATE, "dist_attach_p2p: the handle was not created with CGAMD_DIST_P2P");
     if (d->nranks > 64) return fail(CGAMD_ERR_INVALID, "dist_attach_p2p: at most 64 ranks");
     const int np = (int)d->peer.size();

@@ -24,6 +24,8 @@
 #include "device_mem.h"
 
 #include <algorithm>
+#include <functional>
+#include <mutex>
 
 namespace cgamd {
 
@@ -1815,7 +1817,7 @@ static int check_launch(const char *what) {
 SpmvPlan make_spmv_plan(int n) {
     SpmvPlan p;
     p.row_blocks = (n + kBlock - 1) / kBlock;
-    const int cap = g_tune.spmv_grid > 0 ? g_tune.spmv_grid : kMaxGrid;
+    const int cap = tune().spmv_grid > 0 ? tune().spmv_grid : kMaxGrid;
     int g = p.row_blocks < cap ? p.row_blocks : cap;
     if (g >= 8) g &= ~7;  // xcd_remap needs a multiple of 8
     if (g < 1) g = 1;
@@ -1827,13 +1829,43 @@ SpmvPlan make_spmv_plan(int n) {
 int vec_grid(long long n, int dtype) {
     const long long per_block = (long long)kBlock * (16 / (long long)dtype_size(dtype)) * 4;  // 4 packs per thread
     long long g = (n + per_block - 1) / per_block;
-    const long long cap = g_tune.vec_grid > 0 ? g_tune.vec_grid : kMaxGrid;
+    const long long cap = tune().vec_grid > 0 ? tune().vec_grid : kMaxGrid;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
 }
 
 Tuning g_tune;
+static std::mutex g_tune_mutex;
+static thread_local const Tuning *t_tune = nullptr;
+static thread_local Tuning t_tune_fallback;
+Tuning tune_snapshot() {
+    std::lock_guard<std::mutex> lock(g_tune_mutex);
+    return g_tune;
+}
+void tune_set(const std::function<void(Tuning &)> &edit) {
+    std::lock_guard<std::mutex> lock(g_tune_mutex);
+    edit(g_tune);
+}
+const Tuning &tune() {
+    if (t_tune) return *t_tune;
+    t_tune_fallback = tune_snapshot();      // handle-less entry (stand-alone ops): the global configuration as of now
+    return t_tune_fallback;
+}
+// HIP decides per CALLING thread whether an API call (hipMalloc, a synchronous copy, ...) made while some stream is being
+// captured is an error that invalidates that capture: the default interaction mode of a thread is "global".  The
+// reference's threading model has one thread per device working independently, each capturing its own iteration graphs,
+// so every thread that enters the library switches its own mode to "relaxed" once (a worker's hipMalloc must not kill a
+// sibling's capture: "operation failed due to a previous error during capture").
+void thread_hip_setup() {
+    static thread_local bool done = false;
+    if (done) return;
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    done = true;
+}
+TuneScope::TuneScope(const Tuning *t) : prev(t_tune) { t_tune = t; thread_hip_setup(); }
+TuneScope::~TuneScope() { t_tune = prev; }
 
 template <typename T>
 static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
@@ -1848,7 +1880,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     a.partials = static_cast<typename VT<T>::acc *>(partials);
     a.row_blocks = plan.row_blocks;
     a.rb_list = rb_list; a.rb_count = rb_count;
-    a.ynt = g_tune.spmm_ynt > 0;
+    a.ynt = tune().spmm_ynt > 0;
     const bool vec = aligned16(vals) && aligned16(cols);
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
@@ -1856,13 +1888,13 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     const int variant = (vec && ((nrhs == 1 && plan.kind == 5) || (nrhs > 1 && plan.kind == 6 && plan.wide))) ? 5 : 0;
     if (variant == 5) {
         a.cap = (plan.max_span + 3) & ~3;
-        a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
-        const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + (size_t)g_tune.spmv_lds_pad;
+        a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
+        const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + (size_t)tune().spmv_lds_pad;
         dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : rowblock_grid(plan.row_blocks, a.cycle), nrhs);
         if (rb_list && rb_count <= 0) return CGAMD_OK;
-        const bool nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
+        const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
         // value stream interleaved across the lanes in 16-byte chunks (stage_slice_ilv): "spmv_ilv" 1/0, -1 = auto
-        const bool ilv = g_tune.spmv_ilv >= 0 ? (g_tune.spmv_ilv != 0) : kIlvDefault<T>;
+        const bool ilv = tune().spmv_ilv >= 0 ? (tune().spmv_ilv != 0) : kIlvDefault<T>;
 #define CG_RB(NT, UNR)                                                                                                  \
     do {                                                                                                                \
         if (ilv) {                                                                                                      \
@@ -1874,17 +1906,17 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         }                                                                                                               \
     } while (0)
         // 8 gathers in flight per lane for 4/8-byte values; 4 for complex128 (8 would cost 3 waves/SIMD of occupancy)
-        if (g_tune.spmv_policy >= 0 && sizeof(T) == 8 && !VT<T>::cplx && fuse) {
+        if (tune().spmv_policy >= 0 && sizeof(T) == 8 && !VT<T>::cplx && fuse) {
             // experiment: matrix stream through buffer loads with an explicit cache policy (f64, fused dot only)
 #define CG_POL(P) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, true, true, 8, P>), g5, block, lds, st, a)
-            switch (g_tune.spmv_policy) {
+            switch (tune().spmv_policy) {
             case 0: CG_POL(0); break;   case 1: CG_POL(1); break;   case 2: CG_POL(2); break;   case 3: CG_POL(3); break;
             case 16: CG_POL(16); break; case 17: CG_POL(17); break; case 18: CG_POL(18); break; default: CG_POL(19); break;
             }
 #undef CG_POL
             return check_launch("spmv_rowblock(policy)");
         }
-        const int unroll = g_tune.spmv_unroll ? g_tune.spmv_unroll : (sizeof(T) > 8 ? 4 : 8);
+        const int unroll = tune().spmv_unroll ? tune().spmv_unroll : (sizeof(T) > 8 ? 4 : 8);
         if (unroll == 4) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
         else { if (nt) CG_RB(true, 8); else CG_RB(false, 8); }
 #undef CG_RB
@@ -1893,10 +1925,10 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     if (vec && nrhs == 1 && plan.kind == 7 && !rb_list) {
         const int span = plan.chunk_span[plan.lpr == 2 ? 0 : plan.lpr == 4 ? 1 : 2];
         a.cap = (span + 3) & ~3;
-        a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
+        a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
         const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
         const dim3 g7(rowblock_grid(plan.row_blocks, a.cycle));
-        const bool nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
+        const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
         constexpr int U = sizeof(T) > 8 ? 4 : 8;
 #define CG_CH(NT, L)                                                                                                     \
     do {                                                                                                                  \
@@ -1911,19 +1943,19 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     }
     if (vec && nrhs > 1 && plan.kind == 6) {
         a.cap = (plan.max_span + 3) & ~3;
-        a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
+        a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
         const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave);
         dim3 g6(rowblock_grid(plan.row_blocks, a.cycle));
         constexpr int RBMAX = sizeof(T) <= 8 ? 8 : 4;
         // One launch covers all right-hand sides (groups of RB inside the kernel).  Splitting into one launch per
         // group (cgamd_tune "spmm_rb") re-reads the matrix per group and shrinks the x window per XCD; measured
         // slower at nRHS = 32 (253 vs 220 us) and at nRHS = 9 -- kept as an experiment knob only.
-        const int chunk = (g_tune.spmm_rb > 0 && g_tune.spmm_rb < nrhs) ? g_tune.spmm_rb : nrhs;
-        const bool nt6 = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
+        const int chunk = (tune().spmm_rb > 0 && tune().spmm_rb < nrhs) ? tune().spmm_rb : nrhs;
+        const bool nt6 = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
         // group width: the right-hand sides are cut into ceil(n / RBMAX) groups of (nearly) equal width, so that the last
         // group is not mostly padding -- the reference's own shape, 9 sub-domains, runs as 5 + 4 instead of 8 + 1
         const int ngroups = (chunk + RBMAX - 1) / RBMAX;
-        int rbw = g_tune.spmm_group > 0 ? g_tune.spmm_group : (chunk + ngroups - 1) / ngroups;
+        int rbw = tune().spmm_group > 0 ? tune().spmm_group : (chunk + ngroups - 1) / ngroups;
         if (rbw > RBMAX) rbw = RBMAX;
 #define CG_MM(RBW)                                                                                                         \
     do {                                                                                                                    \
@@ -1993,24 +2025,24 @@ void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nn
     const size_t matrix_bytes = (size_t)nnz * (dtype_size(dtype) + 4) + ((size_t)n + 1) * 4;
     const size_t vector_bytes = (size_t)n * dtype_size(dtype) * (size_t)nrhs;
     const size_t MB = (size_t)1 << 20;
-    plan->nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (matrix_bytes > 256 * MB);
-    if (g_tune.vec_nt >= 0) plan->vec_nt = g_tune.vec_nt;
+    plan->nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (matrix_bytes > 256 * MB);
+    if (tune().vec_nt >= 0) plan->vec_nt = tune().vec_nt;
     else if (!plan->nt) plan->vec_nt = (matrix_bytes + 5 * vector_bytes <= 200 * MB) ? 0 : 3;
     else plan->vec_nt = (matrix_bytes <= 512 * MB) ? 0 : 3;
-    int kind = g_tune.spmv_variant;
+    int kind = tune().spmv_variant;
     const bool vec = aligned16(vals) && aligned16(cols);
     if (!vec || plan->max_span <= 0) kind = 0;
     plan->lpr = 1;
     if (kind == 5 && (size_t)plan->max_span * (dtype_size(dtype) + 4) + acc_size(dtype) * (size_t)nrhs * (kBlock / 64) >
-                         (size_t)(g_tune.spmv_slice_kb > 0 ? g_tune.spmv_slice_kb * 1024 : nrhs > 1 ? kMaxSpmmSliceBytes : kMaxSliceBytes)) {
+                         (size_t)(tune().spmv_slice_kb > 0 ? tune().spmv_slice_kb * 1024 : nrhs > 1 ? kMaxSpmmSliceBytes : kMaxSliceBytes)) {
         kind = 0;
         // denser rows: the chunked form of the row-block kernel (single right-hand side).  Smallest LPR whose chunk slice
         // stays below ~32 KB (27-point stencil fp64: 4 lanes per row 138 us / CG 170 us, 2 lanes 139 / 177, 8 lanes 209;
         // f32: 2 lanes 91 / 117, 4 lanes 94 / 122); rows
         // so dense that even 32 of them exceed that may use up to 48 KB with 8 lanes per row
-        if (nrhs == 1 && g_tune.spmv_chunked != 0) {
+        if (nrhs == 1 && tune().spmv_chunked != 0) {
             const size_t ebytes = dtype_size(dtype) + 4;
-            const size_t want = (size_t)(g_tune.spmv_chunk_kb > 0 ? g_tune.spmv_chunk_kb * 1024 : kChunkBytes);
+            const size_t want = (size_t)(tune().spmv_chunk_kb > 0 ? tune().spmv_chunk_kb * 1024 : kChunkBytes);
             for (int lv = 0; lv < 3 && kind == 0; ++lv)
                 if (plan->chunk_span[lv] > 0 && (size_t)plan->chunk_span[lv] * ebytes <= want) {
                     kind = 7;
@@ -2026,7 +2058,7 @@ void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nn
     if (kind == 5 && nrhs > 1) kind = 6;      // SpMM form of the row-block kernel
     // small multi-RHS systems are bound by round trips per work-group, not by bytes: one work-group per (row block, RHS)
     // runs the single-RHS kernel ("wide" form) instead of one work-group walking the right-hand sides in register groups
-    plan->wide = kind == 6 && (long long)plan->row_blocks * nrhs <= (g_tune.spmm_wide_max >= 0 ? g_tune.spmm_wide_max : 4096) &&
+    plan->wide = kind == 6 && (long long)plan->row_blocks * nrhs <= (tune().spmm_wide_max >= 0 ? tune().spmm_wide_max : 4096) &&
                  (size_t)plan->max_span * (dtype_size(dtype) + 4) <= (size_t)kMaxSliceBytes;
     plan->kind = kind;
     plan->n_partials = kind ? plan->row_blocks : plan->grid;
@@ -2140,7 +2172,7 @@ static int axpy_dot_impl(int n, const void *q, void *r, long long ld, const void
 int launch_axpy_dot(int dtype, int n, const void *q, void *r, long long ld, const void *alpha, int nrhs, void *partials, int grid,
                     hipStream_t st, int vec_nt) {
     const bool vec = vec_ok(dtype, ld, nrhs, {q, r});
-    const int vnt = g_tune.vec_nt >= 0 ? g_tune.vec_nt : vec_nt;
+    const int vnt = tune().vec_nt >= 0 ? tune().vec_nt : vec_nt;
     CG_DISPATCH(dtype, axpy_dot_impl, n, q, r, ld, alpha, nrhs, partials, grid, vec, vnt, st);
 }
 template <typename T>
@@ -2172,10 +2204,10 @@ int launch_aypx_beta_x(int dtype, int n, const void *x, void *y, void *xs, long 
                        const CgScalars &sc, hipStream_t st, int vec_nt) {
     if (n <= 0) return CGAMD_OK;
     const bool v = vec_ok(dtype, ld, nrhs, {x, y, xs});
-    const int vnt = g_tune.vec_nt >= 0 ? g_tune.vec_nt : vec_nt;
+    const int vnt = tune().vec_nt >= 0 ? tune().vec_nt : vec_nt;
     CG_DISPATCH(dtype, aypx_beta_x_impl, n, x, y, xs, ld, partials, P, nrhs, sc, v, vnt, st);
 }
-bool fold_alpha_ok(int n_partials) { return g_tune.fold_alpha != 0 && n_partials <= kFoldAlphaMax; }
+bool fold_alpha_ok(int n_partials) { return tune().fold_alpha != 0 && n_partials <= kFoldAlphaMax; }
 int launch_axpy2_dot_alpha(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *part_dq,
                            int P, const CgScalars &sc, int nrhs, void *partials, int grid, hipStream_t st) {
     const bool vec = vec_ok(dtype, ld, nrhs, {d, x, q, r});
@@ -2184,7 +2216,7 @@ int launch_axpy2_dot_alpha(int dtype, int n, const void *d, void *x, const void 
 int launch_axpy2_dot(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *alpha,
                      int nrhs, void *partials, int grid, hipStream_t st, int vec_nt) {
     const bool vec = vec_ok(dtype, ld, nrhs, {d, x, q, r});
-    const int vnt = g_tune.vec_nt >= 0 ? g_tune.vec_nt : vec_nt;
+    const int vnt = tune().vec_nt >= 0 ? tune().vec_nt : vec_nt;
     CG_DISPATCH(dtype, axpy2_impl, n, d, x, q, r, ld, alpha, nrhs, partials, grid, vec, vnt, st);
 }
 
@@ -2198,7 +2230,7 @@ int launch_cg_delta0(int dtype, const void *partials, int grid, int nrhs, const 
 }
 template <typename T> static int alpha_impl(const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
     using A = typename VT<T>::acc;
-    if (s.stage && s.ticket && grid >= 16384 && g_tune.alpha_two_level != 0)
+    if (s.stage && s.ticket && grid >= 16384 && tune().alpha_two_level != 0)
         hipLaunchKernelGGL((cg_alpha2_kernel<T>), dim3(kAlphaParts, nrhs), dim3(kScalarBlock), 0, st, static_cast<const A *>(partials),
                            grid, nrhs, (const T *)s.delta, (T *)s.alpha, s.iter, (A *)s.stage, s.ticket);
     else
@@ -2287,7 +2319,7 @@ int launch_aypx_beta(int dtype, int n, const void *x, void *y, long long ld, con
 // ---- two-launch iteration: SpMV fused with the previous iteration's beta / aypx ---------------------------------
 bool fused2_ok(const SpmvPlan &plan, int dtype, int nrhs, const void *vals, const int *cols) {
     (void)dtype;
-    if (g_tune.two_launch == 0 || !fold_alpha_ok(plan.n_partials)) return false;
+    if (tune().two_launch == 0 || !fold_alpha_ok(plan.n_partials)) return false;
     if (!aligned16(vals) || !aligned16(cols)) return false;
     // measured (profiles/r2/configs_two_launch.log): the second gather pays for the saved launch up to a few hundred
     // thousand rows; at N = 1M (3907 row blocks) the three/four-launch loops are faster
@@ -2306,13 +2338,13 @@ static int spmv_fused_impl(const SpmvPlan &plan, int n, long long nnz, const voi
     a.dvec = nullptr; a.partials = static_cast<A *>(part_dq);
     a.row_blocks = plan.row_blocks; a.rb_list = nullptr; a.rb_count = 0; a.ynt = 0;
     a.cap = (plan.max_span + 3) & ~3;
-    a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
+    a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
     FusedArgs<T> f;
     f.r = static_cast<const T *>(r); f.dnew = static_cast<T *>(d_new);
     f.part_rr = static_cast<const A *>(part_rr); f.P = P;
     f.delta = (T *)sc.delta; f.beta = (T *)sc.beta; f.history = (T *)sc.history; f.history_cap = sc.history_cap; f.iter = sc.iter;
     const dim3 g(rowblock_grid(plan.row_blocks, a.cycle), nrhs), b(kBlock);
-    const bool nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
+    const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
     const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
     constexpr int U = sizeof(T) > 8 ? 4 : 8;
     if (nt) hipLaunchKernelGGL((spmv_fused_kernel<T, kBlock, true, U>), g, b, lds, st, a, f);
@@ -2403,7 +2435,7 @@ static int spmv_p2p_impl(const SpmvPlan &plan, int n, long long nnz, const void 
     a.partials = static_cast<typename VT<T>::acc *>(partials);
     a.row_blocks = plan.row_blocks; a.rb_list = halo_flag; a.rb_count = plan.row_blocks;
     a.cap = (plan.max_span + 3) & ~3;
-    a.cycle = g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1;
+    a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
     g.x = p2p_args(e);
     g.halo = static_cast<const T *>(e.my_halo);
     g.n_local = e.n_local; g.rotate = rotate; g.push_chunks = p2p_push_chunks(e);
@@ -2411,7 +2443,7 @@ static int spmv_p2p_impl(const SpmvPlan &plan, int n, long long nnz, const void 
     const int grid = rowblock_grid(plan.row_blocks, a.cycle);
     if (grid < e.n_peers * g.push_chunks) return fail(CGAMD_ERR_STATE, "spmv_p2p: fewer work-groups than push chunks");
     const dim3 gd(grid), block(kBlock);
-    const bool nt = g_tune.spmv_nt >= 0 ? (g_tune.spmv_nt != 0) : (plan.nt != 0);
+    const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
     constexpr int U = sizeof(T) > 8 ? 4 : 8;
     if (nt) hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, true, U>), gd, block, lds, st, g);
     else hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, false, U>), gd, block, lds, st, g);
@@ -2424,7 +2456,7 @@ int launch_spmv_p2p(int dtype, const SpmvPlan &plan, int n, long long nnz, const
     CG_DISPATCH(dtype, spmv_p2p_impl, plan, n, nnz, vals, ptr, cols, d_ext, q, partials, halo_flag, rotate, e, st);
 }
 // work-groups the four-launch SpMV runs (they carry the push chunks)
-int spmv_p2p_grid(const SpmvPlan &plan) { return rowblock_grid(plan.row_blocks, g_tune.spmv_cycle > 0 ? g_tune.spmv_cycle : 1); }
+int spmv_p2p_grid(const SpmvPlan &plan) { return rowblock_grid(plan.row_blocks, tune().spmv_cycle > 0 ? tune().spmv_cycle : 1); }
 
 // Every work-group of aypx_beta_p2p_kernel spins until all ranks' r.r slots have arrived, and this rank's own slot is
 // published by work-group 0 of the same launch: the launch is only safe if the whole grid is resident at once (a queued
@@ -2463,7 +2495,7 @@ int launch_aypx_beta_p2p(int dtype, int n, const void *x, void *y, void *xs, con
     if (n <= 0) return CGAMD_OK;
     if (nranks > 64) return fail(CGAMD_ERR_INVALID, "p2p all-reduce: at most 64 ranks");
     const bool v = vec_ok(dtype, n, 1, {x, y, xs});
-    const int vnt = g_tune.vec_nt >= 0 ? g_tune.vec_nt : vec_nt;
+    const int vnt = tune().vec_nt >= 0 ? tune().vec_nt : vec_nt;
     CG_DISPATCH(dtype, aypx_beta_p2p_impl, n, x, y, xs, partials, P, mailbox, rank, nranks, which, epoch, sc, v, vnt, st);
 }
 

@@ -668,8 +668,8 @@ template <int NH> static void rm_f64_instance(int max_quad, bool dot, int *rows,
     // 8-row strips (NQ = 2: half the registers, four waves per SIMD) are an experiment knob: in-process A/B at N = 1M x 32
     // (profiles/r2_experiments/spmm_ab9.log, spmm_ab10.log) 3 % faster than 16-row strips only with 96 of the 128
     // resident work-groups per XCD, 13 % slower with all of them, and slower inside CG (the fused-dot instance spills)
-    const bool tq5 = max_quad > 0 && max_quad <= 20 && g_tune.spmm_tq != 8;
-    const bool nq2 = tq5 && g_tune.spmm_nq == 2;
+    const bool tq5 = max_quad > 0 && max_quad <= 20 && tune().spmm_tq != 8;
+    const bool nq2 = tq5 && tune().spmm_nq == 2;
     *tq = tq5 ? 5 : 8; *nq = nq2 ? 2 : 4; *rows = 4 * *nq;
     if (tq5 && nq2) *per_cu = dot ? rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 2, true>) : rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 2, false>);
     else if (tq5) *per_cu = dot ? rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 4, true>) : rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 4, false>);
@@ -677,7 +677,7 @@ template <int NH> static void rm_f64_instance(int max_quad, bool dot, int *rows,
 }
 static int rm_grid_for(int n, int rows, int per_cu) {
     const int strips = (n + rows - 1) / rows;
-    const int cap = g_tune.spmm_wgs > 0 ? g_tune.spmm_wgs : 32 * per_cu;
+    const int cap = tune().spmm_wgs > 0 ? tune().spmm_wgs : 32 * per_cu;
     int per_xcd = ((strips + 7) / 8 + 3) / 4;
     if (per_xcd > cap) per_xcd = cap;
     if (per_xcd < 1) per_xcd = 1;
@@ -697,7 +697,7 @@ static int spmm_rm_launch(int n, long long nnz, const void *vals, const int *ptr
                           void *partials, int max_quad, hipStream_t st) {
     SpmmRmArgs<T> a;
     a.n = n; a.nnz = nnz;
-    a.ynt = g_tune.spmm_ynt >= 0 ? g_tune.spmm_ynt : 2;      // Y stores write-through (sc1): the lines do not displace X in L2
+    a.ynt = tune().spmm_ynt >= 0 ? tune().spmm_ynt : 2;      // Y stores write-through (sc1): the lines do not displace X in L2
     a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
     a.x = static_cast<const T *>(x); a.y = static_cast<T *>(y); a.partials = static_cast<double *>(partials);
     const dim3 b(256);
@@ -743,7 +743,7 @@ int launch_spmm_rm(int dtype, int n, long long nnz, const void *vals, const int 
 int rm_vec_grid(long long total_elems, int dtype) {
     const long long per_block = (long long)kBlock * (16 / (long long)dtype_size(dtype)) * 4;
     long long g = (total_elems + per_block - 1) / per_block;
-    const long long cap = g_tune.vec_grid > 0 ? g_tune.vec_grid : kMaxGrid;
+    const long long cap = tune().vec_grid > 0 ? tune().vec_grid : kMaxGrid;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;

@@ -19,6 +19,7 @@
 using namespace cgamd;
 
 struct cgamd_solver {
+    Tuning tune;            // configuration this handle was created under (installed per call: TuneScope)
     cgamd_ctx *ctx = nullptr;
     int dtype = 0, n = 0, nrhs = 1, flags = 0;
     long long nnz = 0;
@@ -167,7 +168,10 @@ static int ensure_history(cgamd_solver *s, int entries) {
     if (int rc = dmalloc(&nh, (size_t)cap * s->nrhs * vs, "history")) return rc;
     if (s->sc.history) {
         CG_HIP(hipStreamSynchronize(s->ctx->stream));
-        CG_HIP(hipMemcpy(nh, s->sc.history, (size_t)s->sc.history_cap * s->nrhs * vs, hipMemcpyDeviceToDevice));
+        // on the context's stream, never the legacy NULL stream: work on the NULL stream while ANOTHER thread's stream is
+        // being captured is an error in that thread too ("implicit dependency on the legacy stream")
+        CG_HIP(hipMemcpyAsync(nh, s->sc.history, (size_t)s->sc.history_cap * s->nrhs * vs, hipMemcpyDeviceToDevice, s->ctx->stream));
+        CG_HIP(hipStreamSynchronize(s->ctx->stream));
         CG_HIP(hipFree(s->sc.history));
     }
     s->sc.history = nh;
@@ -190,11 +194,13 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     CG_HIP(hipSetDevice(ctx->device));
     const size_t vs = dtype_size(dtype);
     cgamd_solver *s = new cgamd_solver();
+    s->tune = tune_snapshot();
+    TuneScope ts(&s->tune);
     s->ctx = ctx; s->dtype = dtype; s->n = size; s->nnz = nnz; s->nrhs = nRHS; s->flags = flags;
     s->plan = make_spmv_plan(size);
     s->vgrid = vec_grid(size, dtype);
-    s->defer_x = g_tune.defer_x != 0;
-    s->rm_ok = nRHS > 1 && g_tune.spmm_rowmajor != 0 && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS, size);
+    s->defer_x = tune().defer_x != 0;
+    s->rm_ok = nRHS > 1 && tune().spmm_rowmajor != 0 && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS, size);
     if (s->rm_ok) s->rm_vgrid = rm_vec_grid((long long)size * nRHS, dtype);
     int rc = CGAMD_OK;
     if (flags & CGAMD_MATRIX_ON_DEVICE) {
@@ -221,7 +227,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     {
         // the five vectors live in one slab, each at a 4 KiB-aligned offset plus a per-vector skew: the update kernels
         // stream up to four of them in lock-step, and equal strides between them alias onto the same HBM channels
-        const size_t skew = (size_t)(g_tune.vec_skew >= 0 ? g_tune.vec_skew : 0);
+        const size_t skew = (size_t)(tune().vec_skew >= 0 ? tune().vec_skew : 0);
         const size_t pitch = ((vbytes + 4095) & ~(size_t)4095) + skew;
         if (!rc) rc = dmalloc(&s->slab, pitch * 6 + 4096, "vectors");
         if (!rc) {
@@ -239,7 +245,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) rc = dmalloc((void **)&s->sc.iter, 64, "iter");
     if (!rc) rc = dmalloc(&s->sc.stage, acc_size(dtype) * 32 * (size_t)nRHS, "alpha stage");
     if (!rc) rc = dmalloc((void **)&s->sc.ticket, sizeof(unsigned) * (size_t)nRHS, "alpha tickets");
-    if (!rc && hipMemset(s->sc.ticket, 0, sizeof(unsigned) * (size_t)nRHS) != hipSuccess) rc = fail(CGAMD_ERR_HIP, "hipMemset(alpha tickets)");
+    if (!rc && hipMemsetAsync(s->sc.ticket, 0, sizeof(unsigned) * (size_t)nRHS, ctx->stream) != hipSuccess) rc = fail(CGAMD_ERR_HIP, "hipMemsetAsync(alpha tickets)");
     if (!rc) rc = ensure_history(s, 1024);
     if (!rc) rc = compute_spmv_plan(s->ptr, s->cols, size, s->sc.iter, ctx->stream, &s->plan);
     if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, size, nnz, s->vals, s->cols);
@@ -261,6 +267,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
 
 int cgamd_solver_destroy(cgamd_solver *s) {
     if (!s) return CGAMD_OK;
+    thread_hip_setup();
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     destroy_graphs(s);
@@ -279,6 +286,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
 
 int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_device) {
     if (!s || !b) return fail(CGAMD_ERR_INVALID, "set_rhs: null argument");
+    TuneScope ts(&s->tune);
     CG_HIP(hipSetDevice(s->ctx->device));
     hipStream_t st = s->ctx->stream;
     const size_t vbytes = (size_t)s->n * s->nrhs * dtype_size(s->dtype);
@@ -335,6 +343,7 @@ int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_
 // preconditioner.  The next cgamd_solver_set_rhs starts the preconditioned recurrence; history then holds r.r as before.
 int cgamd_solver_set_preconditioner(cgamd_solver *s, const void *m, int on_device) {
     if (!s) return fail(CGAMD_ERR_INVALID, "set_preconditioner: solver is NULL");
+    TuneScope ts(&s->tune);
     CG_HIP(hipSetDevice(s->ctx->device));
     CG_HIP(hipStreamSynchronize(s->ctx->stream));
     destroy_graphs(s);
@@ -349,12 +358,14 @@ int cgamd_solver_set_preconditioner(cgamd_solver *s, const void *m, int on_devic
     if (!rc && !s->part_rz) rc = dmalloc(&s->part_rz, acc_size(s->dtype) * (size_t)s->vgrid * s->nrhs, "partials_rz");
     if (!rc && !s->rho2) rc = dmalloc(&s->rho2, 2 * vs * (size_t)s->nrhs, "rho");
     if (rc) return rc;
-    CG_HIP(hipMemcpy(s->mdiag, m, (size_t)s->n * vs, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    CG_HIP(hipMemcpyAsync(s->mdiag, m, (size_t)s->n * vs, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->ctx->stream));
+    CG_HIP(hipStreamSynchronize(s->ctx->stream));
     return CGAMD_OK;
 }
 
 int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
     if (!s) return fail(CGAMD_ERR_INVALID, "iterate: solver is NULL");
+    TuneScope ts(&s->tune);
     if (!s->rhs_set) return fail(CGAMD_ERR_STATE, "iterate: call set_rhs first");
     if (nIterations < 0) return fail(CGAMD_ERR_INVALID, "iterate: negative iteration count");
     CG_HIP(hipSetDevice(s->ctx->device));
@@ -392,6 +403,7 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
 // (bench.py's roofline).  Synchronises.
 int cgamd_solver_iterate_timed(cgamd_solver *s, int nIterations, float *spmv_ms_avg, float *iter_ms_avg) {
     if (!s || !spmv_ms_avg) return fail(CGAMD_ERR_INVALID, "iterate_timed: null argument");
+    TuneScope ts(&s->tune);
     if (!s->rhs_set) return fail(CGAMD_ERR_STATE, "iterate_timed: call set_rhs first");
     if (nIterations < 1) return fail(CGAMD_ERR_INVALID, "iterate_timed: needs >= 1 iteration");
     CG_HIP(hipSetDevice(s->ctx->device));
@@ -432,6 +444,7 @@ int cgamd_solver_iterate_timed(cgamd_solver *s, int nIterations, float *spmv_ms_
 
 int cgamd_solver_get_x(cgamd_solver *s, void *x, int on_device) {
     if (!s || !x) return fail(CGAMD_ERR_INVALID, "get_x: null argument");
+    TuneScope ts(&s->tune);
     CG_HIP(hipSetDevice(s->ctx->device));
     const size_t vbytes = (size_t)s->n * s->nrhs * dtype_size(s->dtype);
     const void *src = s->x;
@@ -449,6 +462,7 @@ int cgamd_solver_iterations_done(cgamd_solver *s) { return s ? s->iters : -CGAMD
 int cgamd_solver_history(cgamd_solver *s, void *history, int max_entries) {
     if (!s || !history) { fail(CGAMD_ERR_INVALID, "history: null argument"); return -CGAMD_ERR_INVALID; }
     if (!s->rhs_set) { fail(CGAMD_ERR_STATE, "history: no right-hand side set"); return -CGAMD_ERR_STATE; }
+    thread_hip_setup();
     if (hipSetDevice(s->ctx->device) != hipSuccess) return -CGAMD_ERR_NO_DEVICE;
     const int entries = std::min(std::min(s->iters + 1, s->sc.history_cap), max_entries);
     hipError_t e = hipMemcpyAsync(history, s->sc.history, (size_t)entries * s->nrhs * dtype_size(s->dtype),
@@ -478,6 +492,7 @@ int cgamd_solver_solve(cgamd_solver *s, const void *b, void *x, int nIterations,
 
 int cgamd_solver_spmv(cgamd_solver *s, const void *x, void *y, int fused_dot) {
     if (!s || !x || !y) return fail(CGAMD_ERR_INVALID, "solver_spmv: null argument");
+    TuneScope ts(&s->tune);
     CG_HIP(hipSetDevice(s->ctx->device));
     return launch_spmv(s->dtype, s->plan, s->n, s->nnz, s->vals, s->ptr, s->cols, x, s->n, y, s->n, s->nrhs,
                        fused_dot ? x : nullptr, fused_dot ? s->part_dq : nullptr, s->ctx->stream);
@@ -485,6 +500,7 @@ int cgamd_solver_spmv(cgamd_solver *s, const void *x, void *y, int fused_dot) {
 
 int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS) {
     if (!s || !x || !y) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: null argument");
+    TuneScope ts(&s->tune);
     CG_HIP(hipSetDevice(s->ctx->device));
     return launch_spmm_rm(s->dtype, s->n, s->nnz, s->vals, s->ptr, s->cols, x, y, nRHS, nullptr, s->plan.max_quad, s->ctx->stream);
 }

@@ -144,3 +144,37 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "cg_oracle" not in text and "cg_numpy" not in text and "oracle/" not in text, f
+
+
+def test_two_threads_on_the_handle_api_without_a_gpu(pkg):
+    """CPU side of SURVEY 8b "Threading": error messages are per thread, and the tuning table may be edited from several
+    threads at once (it is copied into every solver at creation; edits are serialised).  No compute call is made."""
+    import threading
+    lib = pkg._lib.load()
+    seen, errors = {}, []
+
+    def worker(k):
+        try:
+            for i in range(300):
+                if k == 0:
+                    rc = lib.cgamd_tune(b"no_such_knob_%d" % k, i)
+                    msg = lib.cgamd_last_error().decode()
+                    assert rc == 1 and "no_such_knob_0" in msg, msg
+                else:
+                    rc = lib.cgamd_ctx_create(-5 - k, ctypes.byref(ctypes.c_void_p()))
+                    msg = lib.cgamd_last_error().decode()
+                    # no GPU here: either "no HIP device" or, with one, "out of range" -- never the other thread's text
+                    assert rc != 0 and "no_such_knob" not in msg, msg
+                assert lib.cgamd_tune(b"vec_grid", 64 * (k + 1)) == 0
+            seen[k] = True
+        except BaseException as e:      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert lib.cgamd_tune(b"vec_grid", 0) == 0
+    assert not errors, errors
+    assert seen == {0: True, 1: True}
