@@ -92,6 +92,9 @@ def load():
         "cgamd_solver_spmv_bytes": (ll, [vp]),
         "cgamd_solver_iter_bytes": (ll, [vp, ci]),
         "cgamd_cg": (ci, [ci, ci, ll, vp, vp, vp, vp, vp, ci, ci, vp, ci]),
+        "cgamd_cg_last_timing": (ci, [ctypes.POINTER(ctypes.c_double)]),
+        "cgamd_cg_release_cache": (ci, []),
+        "cgamd_solver_reload_matrix": (ci, [vp, vp, vp, vp]),
         "cgamd_gen_laplace3d": (ci, [vp, ci, ci, ci, ci, ll, ll, vp, vp, vp, ctypes.POINTER(ll)]),
         "cgamd_gen_poisson2d": (ci, [vp, ci, ci, vp, vp, vp, ctypes.POINTER(ll)]),
         "cgamd_mm_read": (ci, [ctypes.c_char_p, ctypes.POINTER(ci), ctypes.POINTER(ll), ctypes.POINTER(ci),

@@ -1,6 +1,8 @@
 // C ABI: context, memory helpers, the five stand-alone kernels, generators, legacy cg()/connect().
 // The ABI mirrors the reference's Python operator surface (cl.py:16-42) and C entry (clcg.h:3-5).
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -264,20 +266,80 @@ int cgamd_gen_poisson2d(cgamd_ctx *c, int dtype, int N, void *aValues, int *aPoi
 }
 
 // ---- one-call typed solve on host arrays ----------------------------------------------------------
+// Stateless towards the caller (matrix, b, x are host arrays alive for the call only; everything is uploaded every time,
+// as in the reference clcg.c:202-211), but the DEVICE STATE -- context, stream, allocations, SpMV plan, captured graphs --
+// is kept per calling thread and reused when the shape repeats: the reference's caller solves with the same sub-domain
+// matrix once per outer GMRES iteration (p_h-PY_C-CL.py:1948-1950), and rebuilding that state costs as much as the 256
+// iterations themselves (per-call split).
+namespace {
+struct CgCache {
+    cgamd_ctx *ctx = nullptr;
+    cgamd_solver *s = nullptr;
+    int dtype = -1, size = 0, nrhs = 0, device = -1;
+    long long nnz = -1;
+    void release() {
+        if (s) cgamd_solver_destroy(s);
+        if (ctx) cgamd_ctx_destroy(ctx);
+        s = nullptr; ctx = nullptr; dtype = -1;
+    }
+    ~CgCache() { release(); }
+};
+thread_local CgCache t_cg_cache;
+thread_local double t_cg_timing[6] = {0, 0, 0, 0, 0, 0};
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+int cgamd_cg_release_cache(void) { t_cg_cache.release(); return CGAMD_OK; }
+int cgamd_cg_last_timing(double *ms6) {
+    if (!ms6) return fail(CGAMD_ERR_INVALID, "cg_last_timing: null argument");
+    for (int i = 0; i < 6; ++i) ms6[i] = t_cg_timing[i];
+    return CGAMD_OK;
+}
+
 int cgamd_cg(int dtype, int size, long long nnz, const void *aValues, const void *b, const int *aPointers,
              const int *aCols, void *x, int nRHS, int nIterations, void *history, int device) {
     if (size < 0 || nnz < 0 || nRHS < 1 || nIterations < 0) return fail(CGAMD_ERR_INVALID, "cg: bad size argument");
     if (size == 0) return CGAMD_OK;
     if (!aPointers || !b || !x || (nnz > 0 && (!aValues || !aCols))) return fail(CGAMD_ERR_INVALID, "cg: null pointer");
-    cgamd_ctx *ctx = nullptr;
-    if (int rc = cgamd_ctx_create(device, &ctx)) return rc;
-    cgamd_solver *s = nullptr;
-    int rc = cgamd_solver_create(ctx, dtype, size, nnz, aValues, aPointers, aCols, nRHS, 0, &s);
-    if (rc == CGAMD_OK) rc = cgamd_solver_solve(s, b, x, nIterations, history);
-    std::string keep = g_err;
-    if (s) cgamd_solver_destroy(s);
-    cgamd_ctx_destroy(ctx);
-    if (rc != CGAMD_OK) g_err = keep;
+    static const bool no_cache = [] { const char *e = getenv("CGAMD_CG_NO_CACHE"); return e && e[0] == '1'; }();
+    CgCache local, &c = no_cache ? local : t_cg_cache;
+    double t[6];
+    t[0] = now_ms();
+    const bool hit = c.s && c.dtype == dtype && c.size == size && c.nnz == nnz && c.nrhs == nRHS && c.device == device;
+    int rc = CGAMD_OK;
+    double t_upload = 0.0;
+    if (hit) {
+        const double u0 = now_ms();
+        rc = cgamd_solver_reload_matrix(c.s, aValues, aPointers, aCols);
+        t_upload = now_ms() - u0;
+    } else {
+        c.release();
+        rc = cgamd_ctx_create(device, &c.ctx);
+        // creation uploads the matrix as part of building the handle: not separable, all of it is counted as device state
+        if (rc == CGAMD_OK) rc = cgamd_solver_create(c.ctx, dtype, size, nnz, aValues, aPointers, aCols, nRHS, 0, &c.s);
+        if (rc == CGAMD_OK) { c.dtype = dtype; c.size = size; c.nnz = nnz; c.nrhs = nRHS; c.device = device; }
+    }
+    t[1] = now_ms();
+    if (rc == CGAMD_OK) rc = cgamd_solver_set_rhs(c.s, b, x, 0);      // x is in/out: initial guess (clcg.c:210)
+    t[2] = now_ms();
+    if (rc == CGAMD_OK) rc = cgamd_solver_iterate(c.s, nIterations);
+    if (rc == CGAMD_OK) rc = cgamd_ctx_synchronize(c.ctx);
+    t[3] = now_ms();
+    if (rc == CGAMD_OK) rc = cgamd_solver_get_x(c.s, x, 0);
+    if (rc == CGAMD_OK && history) {
+        const int got = cgamd_solver_history(c.s, history, nIterations + 1);
+        if (got < 0) rc = -got;
+    }
+    t[4] = now_ms();
+    t_cg_timing[0] = t[1] - t[0] - t_upload; t_cg_timing[1] = t_upload; t_cg_timing[2] = t[2] - t[1];
+    t_cg_timing[3] = t[3] - t[2]; t_cg_timing[4] = t[4] - t[3]; t_cg_timing[5] = hit ? 1.0 : 0.0;
+    if (rc != CGAMD_OK) {       // never keep a handle in an unknown state
+        std::string keep = g_err;
+        c.release();
+        g_err = keep;
+    }
     return rc;
 }
 

@@ -26,11 +26,13 @@ struct cgamd_solver {
     void *vals = nullptr;
     int *ptr = nullptr, *cols = nullptr;
     bool own_matrix = false;
+    std::vector<int> ptr_host;   // own_matrix: the row pointers as uploaded (cgamd_solver_reload_matrix compares against them)
     SpmvPlan plan;
     int vgrid = 1;
     void *x = nullptr, *r = nullptr, *d = nullptr, *q = nullptr, *b = nullptr;
     void *slab = nullptr;   // backing store of x, r, d, q, b
     void *part_dq = nullptr, *part_rr = nullptr;
+    size_t part_dq_cap = 0;      // entries per RHS
     // diagonal preconditioner (cgamd_solver_set_preconditioner): z = mdiag .* r; r.z partials; rho parity buffer
     void *mdiag = nullptr, *part_rz = nullptr, *rho2 = nullptr;
     CgScalars sc;
@@ -221,6 +223,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
         if (!rc) {
             hipError_t e = hipMemcpyAsync(s->ptr, aPointers, (size_t)(size + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("upload aPointers: ") + hipGetErrorString(e));
+            else s->ptr_host.assign(aPointers, aPointers + size + 1);
         }
     }
     const size_t vbytes = (size_t)size * nRHS * vs;
@@ -237,7 +240,8 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
         }
     }
     // the row-major SpMM writes one d.q partial per work-group of its sweep: at most 8 XCDs x 32 CUs x 8 work-groups
-    if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * (size_t)std::max(std::max(s->plan.grid, s->plan.row_blocks), s->rm_ok ? 2048 : 0) * nRHS, "partials_dq");
+    s->part_dq_cap = (size_t)std::max(std::max(s->plan.grid, s->plan.row_blocks), s->rm_ok ? 2048 : 0);
+    if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * s->part_dq_cap * nRHS, "partials_dq");
     if (!rc) rc = dmalloc(&s->part_rr, acc_size(dtype) * (size_t)std::max(s->vgrid, s->rm_vgrid) * nRHS, "partials_rr");
     if (!rc) rc = dmalloc(&s->sc.alpha, vs * nRHS, "alpha");
     if (!rc) rc = dmalloc(&s->sc.beta, vs * nRHS, "beta");
@@ -262,6 +266,38 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
         return rc;
     }
     *out = s;
+    return CGAMD_OK;
+}
+
+// New matrix VALUES / PATTERN of the same size into an existing handle (host arrays; the handle must own its matrix):
+// what the stateless cg() needs to reuse its cached device state -- allocations, stream, captured graphs -- from one call
+// to the next.  The pattern-dependent plan is recomputed only when the row pointers differ from the ones uploaded before.
+int cgamd_solver_reload_matrix(cgamd_solver *s, const void *aValues, const int *aPointers, const int *aCols) {
+    if (!s || !aPointers || (s->nnz > 0 && (!aValues || !aCols))) return fail(CGAMD_ERR_INVALID, "reload_matrix: null argument");
+    if (!s->own_matrix) return fail(CGAMD_ERR_STATE, "reload_matrix: the handle borrows a device matrix");
+    TuneScope ts(&s->tune);
+    CG_HIP(hipSetDevice(s->ctx->device));
+    if (int rc = validate_csr_host(s->n, s->nnz, aPointers, aCols)) return rc;
+    hipStream_t st = s->ctx->stream;
+    const size_t vs = dtype_size(s->dtype);
+    s->rhs_set = false;
+    if (s->nnz) {
+        CG_HIP(hipMemcpyAsync(s->vals, aValues, (size_t)s->nnz * vs, hipMemcpyHostToDevice, st));
+        CG_HIP(hipMemcpyAsync(s->cols, aCols, (size_t)s->nnz * 4, hipMemcpyHostToDevice, st));
+    }
+    const bool same_ptr = s->ptr_host.size() == (size_t)s->n + 1 && memcmp(s->ptr_host.data(), aPointers, ((size_t)s->n + 1) * 4) == 0;
+    if (!same_ptr) {
+        CG_HIP(hipMemcpyAsync(s->ptr, aPointers, ((size_t)s->n + 1) * 4, hipMemcpyHostToDevice, st));
+        s->ptr_host.assign(aPointers, aPointers + s->n + 1);
+        destroy_graphs(s);          // kernel choice, LDS size and partial counts are baked into the captured launches
+        s->plan = make_spmv_plan(s->n);
+        if (int rc = compute_spmv_plan(s->ptr, s->cols, s->n, s->sc.iter, st, &s->plan)) return rc;
+        finalize_spmv_plan(&s->plan, s->dtype, s->nrhs, s->n, s->nnz, s->vals, s->cols);
+        if ((size_t)std::max(s->plan.grid, s->plan.row_blocks) > s->part_dq_cap) return fail(CGAMD_ERR_STATE, "reload_matrix: partial buffer too small");
+        if (s->rm_ok) s->rm_nwg = spmm_rm_grid(s->dtype, s->nrhs, s->n, s->plan.max_quad, true);
+        s->fused2 = fused2_ok(s->plan, s->dtype, s->nrhs, s->vals, s->cols);
+    }
+    CG_HIP(hipStreamSynchronize(st));   // the host arrays may go away after return
     return CGAMD_OK;
 }
 

@@ -110,6 +110,10 @@ int cgamd_sub(cgamd_ctx *ctx, int dtype, int size, const void *a, const void *b,
 int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, const void *aValues,
                         const int *aPointers, const int *aCols, int nRHS, int flags, cgamd_solver **out);
 int cgamd_solver_destroy(cgamd_solver *s);
+/* new values / pattern of the SAME size (size, nnz, nRHS, dtype) into a handle that owns its matrix (created from host
+ * arrays): keeps allocations, stream and -- when the row pointers are unchanged -- the plan and the captured graphs.
+ * The next call must be cgamd_solver_set_rhs. */
+int cgamd_solver_reload_matrix(cgamd_solver *s, const void *aValues, const int *aPointers, const int *aCols);
 /* b, x0: nRHS*size values, host (on_device=0) or device (on_device=1) memory; x0 may be NULL (zeros).
  * Computes r = b - A x0, d = r, delta0 = r.r  (reference clcg.c:255-292) and resets the iteration count. */
 int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_device);
@@ -153,6 +157,15 @@ long long cgamd_solver_iter_bytes(cgamd_solver *s, int fused);
 /* one-call typed solve on host arrays: cg() generalised to all four dtypes, with history and status */
 int cgamd_cg(int dtype, int size, long long nnz, const void *aValues, const void *b, const int *aPointers,
              const int *aCols, void *x, int nRHS, int nIterations, void *history, int device);
+/* Wall-clock split of the calling thread's last cgamd_cg() / cg() call, in milliseconds:
+ * [0] device state (context, allocations, plan; or the cache check), [1] matrix upload + validation, [2] right-hand side
+ * upload + setup kernels, [3] iterations (enqueue + wait), [4] solution download, [5] 1.0 when the call reused the
+ * thread's cached device state.  cgamd_cg keeps one context + handle per calling thread and reuses them when dtype,
+ * size, nonZeros, nRHS and device repeat (the reference rebuilds everything per call, clcg.c:142-214; the call itself
+ * stays stateless: the matrix is re-uploaded every time).  cgamd_cg_release_cache() frees the calling thread's cache;
+ * environment CGAMD_CG_NO_CACHE=1 disables it. */
+int cgamd_cg_last_timing(double *ms6);
+int cgamd_cg_release_cache(void);
 
 /* ---- synthetic matrix generators, written straight into device memory -----
  * 7-point 3-D Laplacian (x fastest), Dirichlet, diag 6 / off-diag -1 (SURVEY §8d "M", "C5").
