@@ -323,23 +323,32 @@ class Solver:
 
 
     def solve_tol(self, b, x0=None, tol=1e-5, maxit=1000, check_every=8):
-        """Tolerance-stopping variant of the reference's NumPy sub-solver (p_h-PY_C-CL.py:1338-1369, UseCG==5):
-        iterate until sqrt(|r.r|) < tol, looking at the device-resident history every `check_every`
-        iterations (one small read-back instead of the reference's per-iteration host reductions).
+        """Tolerance-stopping variant of the reference's NumPy sub-solver (p_h-PY_C-CL.py:1338-1369, UseCG==5), which breaks
+        at the first iteration with sqrt(|r.r|) < tol.  The residual history stays on the device and is read back every
+        `check_every` iterations (one small read-back instead of the reference's per-iteration host reductions); when the
+        check overshot the first iteration that met the tolerance, the solve is re-run for exactly that many iterations, so
+        x is the iterate the reference returns and not one from past convergence (where d.q can reach 0 and alpha 0/0).
         Returns (x, iterations_run, history).  Single right-hand side."""
         if self.n_rhs != 1:
             raise ValueError("solve_tol handles one right-hand side")
-        self.set_rhs(b, x0)
-        done = 0
-        while done < maxit:
-            step = min(check_every, maxit - done)
-            self.iterate(step)
-            done += step
-            h = self.history()
-            below = np.nonzero(np.sqrt(np.abs(h[:, 0])) < tol)[0]
-            if below.size or not np.all(np.isfinite(h[-1])):
-                break
-        return self.x(), done, self.history()
+
+        def run(limit, stop_early):
+            self.set_rhs(b, x0)
+            done = 0
+            while done < limit:
+                step = min(check_every, limit - done)
+                self.iterate(step)
+                done += step
+                if stop_early:
+                    h = self.history()
+                    hit = np.nonzero(~(np.sqrt(np.abs(h[1:, 0])) >= tol))[0]        # below tol, or NaN
+                    if hit.size:
+                        return int(hit[0]) + 1
+            return limit
+        its = run(int(maxit), True)
+        if self.iterations_done() != its:
+            run(its, False)
+        return self.x(), its, self.history()
 
     def pcg(self, b, M=None, x0=None, tol=1e-6, maxit=1000, check_every=8):
         """`PCG(A, b, M, x, tol, maxit)` of the reference (helmFE_var.py:546-586) for M = None or a diagonal M: stops when

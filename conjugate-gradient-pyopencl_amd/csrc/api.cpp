@@ -53,8 +53,6 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmm_tq") g_tune.spmm_tq = value;
     else if (k == "spmm_nq") g_tune.spmm_nq = value;
     else if (k == "spmm_rowmajor") g_tune.spmm_rowmajor = value;
-    else if (k == "spmv_lds_pad") g_tune.spmv_lds_pad = value;
-    else if (k == "spmv_policy") g_tune.spmv_policy = value;
     else if (k == "vec_nt") g_tune.vec_nt = value;
     else if (k == "vec_skew") g_tune.vec_skew = value & ~15;
     else known = false;

@@ -47,6 +47,10 @@ struct SpmvPlan {
 SpmvPlan make_spmv_plan(int n);
 // fills plan->max_span / chunk_span from the matrix structure; synchronises `st`; scratch_dev: >= 32 bytes
 int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan);
+// device-resident CSR (and an optional device index list with entries in [0, index_bound)): CGAMD_ERR_INVALID on a bad
+// pointer array or an out-of-range column / index; synchronises `st`; scratch_dev: >= 4 bytes
+int validate_csr_device(int n, long long nnz, int ncols, const int *ptr_dev, const int *cols_dev, const int *index_dev, int n_index,
+                        int index_bound, int *scratch_dev, hipStream_t st);
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols);
 constexpr int kChunkBytes = 32 * 1024;      // kind 7: preferred LDS chunk slice (4-5 work-groups per CU)
 constexpr int kMaxChunkBytes = 48 * 1024;   //         largest accepted, with 8 lanes per row (3 work-groups per CU)
@@ -60,7 +64,7 @@ struct Tuning {
     int spmv_nt = -1;       // non-temporal matrix loads: 1 on, 0 off, -1 auto = on unless the matrix fits the 256 MB Infinity
                             // Cache (below that the re-used matrix is served from the cache; finalize_spmv_plan)
     int spmv_unroll = 0;    // row walk: LDS reads + gathers in flight per lane (4 or 8; 0 = 8, or 4 for 16-byte values)
-    int spmm_ynt = -1;      // SpMM y stores: 0 plain, 1 non-temporal, 2 write-through sc1 (row-major kernel; -1 = default: 2 there, 0 RHS-major)
+    int spmm_ynt = -1;      // row-major SpMM y stores: 0 plain, 1 non-temporal, 2 write-through sc1 (-1 = default: 2)
     int spmm_group = 0;     // SpMM: right-hand sides per register group (0 = equal-width groups of at most 8, 4 for complex128)
     int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = all in one launch)
     int spmm_wgs = 0;       // row-major SpMM sweep: work-groups per XCD (0 = 64: 256 strips of 16 rows open per XCD)
@@ -71,8 +75,6 @@ struct Tuning {
     int vec_skew = 0;       // bytes added to the pitch between the solver's vectors (multiple of 16)
     int vec_nt = -1;        // -1 auto (by working-set size, finalize_spmv_plan); axpy2_dot: bit0 = x loaded/stored non-temporally (touched once per iteration), bit1 = q loaded
                             // non-temporally (its last use): d and r, which are re-read, keep the caches; measured -10..-22 us/iteration
-    int spmv_policy = -1;   // experiment: >= 0 = matrix stream via buffer loads with this cache-policy aux field
-    int spmv_lds_pad = 0;   // experiment: extra dynamic LDS bytes per work-group (lowers occupancy)
     int alpha_two_level = 1; // cg_alpha over >= 16384 partials: 32 work-groups + last-arrival combine (0 = one work-group)
     int defer_x = 1;        // fused loop: x += alpha d rides in the aypx launch (10 vector passes per iteration instead of 11)
     int fold_alpha = 1;     // small systems (<= 2048 d.q partials): alpha in the prologue of axpy2_dot, three launches per iteration

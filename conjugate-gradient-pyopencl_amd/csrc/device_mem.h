@@ -31,10 +31,6 @@ template <typename T> CG_DEV void st_pack_nt(T *p, const Pack<T> &v) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-CG_DEV void st_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
-CG_DEV void st_nt(double *p, double v) { __builtin_nontemporal_store(v, p); }
-CG_DEV void st_nt(float2 *p, float2 v) { f32x2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<f32x2 *>(p)); }
-CG_DEV void st_nt(double2 *p, double2 v) { f64x2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<f64x2 *>(p)); }
 
 // 4 consecutive values by 16-byte loads, register to register (a union of ext-vectors and HIP vector structs
 // sent the complex128 instance through scratch memory: 2x slower).  NT = non-temporal.

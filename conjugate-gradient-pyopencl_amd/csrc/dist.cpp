@@ -355,6 +355,8 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     if (!rc) rc = dalloc(&d->sc.delta, vs, "delta");
     if (!rc) rc = dalloc((void **)&d->sc.iter, 64, "iter");
     if (!rc) rc = ensure_history(d, 1024);
+    if (!rc) rc = validate_csr_device(n_local, nnz_local, n_local + n_halo, d->ptr, d->cols, d->send_index, d->total_send, n_local, d->sc.iter,
+                                      ctx->stream);
     if (!rc) rc = compute_spmv_plan(d->ptr, d->cols, n_local, d->sc.iter, ctx->stream, &d->plan);
     if (!rc) finalize_spmv_plan(&d->plan, dtype, 1, n_local, nnz_local, d->vals, d->cols);
     if (!rc && id128 && !d->p2p) {

@@ -56,7 +56,6 @@ template <typename T> struct SpmvArgs {
     int rb_count;
     int cap;   // row-block kernel: LDS slice capacity in entries (multiple of 4)
     int cycle; // row-block kernel: block-cyclic schedule over the XCDs, cycle length in row blocks (1 = one contiguous eighth per XCD)
-    int ynt;   // SpMM: store y non-temporally (experiment knob "spmm_ynt")
 };
 
 // Row-block schedule shared by the row-block kernels: work-group b runs on XCD b%8 as that XCD's (b/8)-th block.
@@ -207,45 +206,20 @@ template <typename T, bool NT, bool FULL> CG_DEV void load_quad(const T *__restr
     }
 }
 
-// Same 4 entries through raw buffer loads with an explicit cache-policy field AUX (bit0 sc0, bit1 nt, bit4 sc1):
-// experiment knob "spmv_policy" -- which policy keeps the CG vectors resident in L2 / Infinity Cache while the
-// matrix streams through.  Offsets are relative to the slice start (the descriptor's base), so they fit 32 bits.
-template <typename T, int AUX> CG_DEV void load_quad_buf(__amdgpu_buffer_rsrc_t rv, __amdgpu_buffer_rsrc_t rc, int entry,
-                                                         T (&v)[4], int (&c)[4]) {
-    constexpr int NV = sizeof(T) * 4 / 16;
-    union { u32x4 raw[NV]; T w[4]; } uu;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) uu.raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rv, entry * (int)sizeof(T) + 16 * k, 0, AUX);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = uu.w[k];
-    const u32x4 cc = __builtin_amdgcn_raw_buffer_load_b128(rc, entry * 4, 0, AUX);
-    c[0] = (int)cc.x; c[1] = (int)cc.y; c[2] = (int)cc.z; c[3] = (int)cc.w;
-}
-
 // Park the slice [cfirst, p1) of aValues/aCols raw in LDS.  Every lane issues the loads of TWO quads before it
 // waits for either (a plain loop made hipcc wait for quad 1 before issuing quad 2: one more dependent HBM
 // round trip per work-group, and the work-group's lifetime is a chain of such round trips).
-template <typename T, int BLOCK, bool NT, bool FULL, int POL = -1>
+template <typename T, int BLOCK, bool NT, bool FULL>
 CG_DEV void stage_slice_impl(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
                              T *sv, int *sc) {
     const int t = threadIdx.x;
-    __amdgpu_buffer_rsrc_t rv, rc;
-    if (POL >= 0) {
-        rv = __builtin_amdgcn_make_buffer_rsrc((void *)(vals + cfirst), 0, 0x7fffffff, 0x00020000);
-        rc = __builtin_amdgcn_make_buffer_rsrc((void *)(cols + cfirst), 0, 0x7fffffff, 0x00020000);
-    }
     for (long long base = cfirst; base < p1; base += 8 * BLOCK) {
         const long long q0 = base + 4 * t, q1 = q0 + 4 * BLOCK;
         const bool h0 = q0 < p1, h1 = q1 < p1;
         T v0[4], v1[4];
         int c0[4], c1[4];
-        if (POL >= 0 && FULL) {
-            if (h0) load_quad_buf<T, POL < 0 ? 0 : POL>(rv, rc, (int)(q0 - cfirst), v0, c0);
-            if (h1) load_quad_buf<T, POL < 0 ? 0 : POL>(rv, rc, (int)(q1 - cfirst), v1, c1);
-        } else {
-            if (h0) load_quad<T, NT, FULL>(vals, cols, nnz, q0, v0, c0);
-            if (h1) load_quad<T, NT, FULL>(vals, cols, nnz, q1, v1, c1);
-        }
+        if (h0) load_quad<T, NT, FULL>(vals, cols, nnz, q0, v0, c0);
+        if (h1) load_quad<T, NT, FULL>(vals, cols, nnz, q1, v1, c1);
         if (h0) {
             const int o = (int)(q0 - cfirst);
 #pragma unroll
@@ -326,7 +300,7 @@ CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols
     }
     // only the work-group that owns the very end of the matrix can meet a partial quad: block-uniform branch,
     // so the common path carries no per-lane tail handling (whose control flow made hipcc serialise the loads)
-    if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_impl<T, BLOCK, NT, true, POL>(vals, cols, nnz, cfirst, p1, sv, sc);
+    if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_impl<T, BLOCK, NT, true>(vals, cols, nnz, cfirst, p1, sv, sc);
     else stage_slice_impl<T, BLOCK, NT, false>(vals, cols, nnz, cfirst, p1, sv, sc);
 }
 
@@ -550,10 +524,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowblock_kernel(SpmvArgs<T> a) {
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             if (g0 + j < a.nrhs) {       // wave-uniform
-                if (row < a.n) {
-                    if (a.ynt) st_nt(a.y + row + (long long)(g0 + j) * a.ldy, sum[j]);
-                    else a.y[row + (long long)(g0 + j) * a.ldy] = sum[j];
-                }
+                if (row < a.n) a.y[row + (long long)(g0 + j) * a.ldy] = sum[j];
                 if (FUSE_DOT) {
                     const A contrib = (row < a.n) ? to_acc(vmul(a.dvec[row + (long long)(g0 + j) * a.ldx], sum[j])) : vzero<A>();
                     const A w = wave_sum(contrib);
@@ -703,6 +674,21 @@ __global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, cons
     __syncthreads();
     for (int k = ty; k < 32; k += 8)
         if (bx + k < cols && by + tx < rows) out[(long long)(bx + k) * rows + by + tx] = tile[tx][k];
+}
+
+// CSR sanity of a device-resident matrix (CGAMD_MATRIX_ON_DEVICE, cgamd_dist_create): the row-block kernels size LDS
+// from pointer differences and gather x[col] directly, so a bad index from a caller must become CGAMD_ERR_INVALID, not an
+// out-of-bounds access.  flag bits: 1 ptr[0] != 0, 2 not monotone, 4 ptr[n] != nnz, 8 column out of [0, ncols),
+// 16 index list entry out of [0, bound).
+__global__ void csr_validate_kernel(int n, long long nnz, int ncols, const int *__restrict__ ptr, const int *__restrict__ cols,
+                                    const int *__restrict__ index, int n_index, int index_bound, int *flag) {
+    int bad = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x, i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 == 0) bad |= (ptr[0] != 0 ? 1 : 0) | (ptr[n] != nnz ? 4 : 0);
+    for (long long i = i0; i < n; i += stride) bad |= ptr[i + 1] < ptr[i] ? 2 : 0;
+    for (long long j = i0; j < nnz; j += stride) bad |= (cols[j] < 0 || cols[j] >= ncols) ? 8 : 0;
+    for (long long k = i0; k < n_index; k += stride) bad |= (index[k] < 0 || index[k] >= index_bound) ? 16 : 0;
+    if (bad) atomicOr(flag, bad);
 }
 
 // flag[rb] = 1 if any entry of row block rb references a halo column (col >= n_local): the blocks that must wait
@@ -967,7 +953,7 @@ __global__ __launch_bounds__(BLOCK) void ewise_kernel(int n, const T *__restrict
 template <typename T, int BLOCK, bool VEC>
 __global__ __launch_bounds__(BLOCK) void aypx_beta_kernel(int n, const T *__restrict__ x, T *__restrict__ y, long long ld,
                                                           const typename VT<T>::acc *__restrict__ partials, int P,
-                                                          int nrhs, T *delta, T *beta, T *history, const int *iter) {
+                                                          int nrhs, T *delta, T *beta, T *history, int history_cap, const int *iter) {
     using A = typename VT<T>::acc;
     __shared__ A red[BLOCK / kWave];
     __shared__ T beta_s;
@@ -986,7 +972,7 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_kernel(int n, const T *__rest
             if (blockIdx.x == 0) {
                 beta[r] = b;
                 delta[r] = dnT;
-                history[(long long)it * nrhs + r] = dnT;
+                if (it < history_cap) history[(long long)it * nrhs + r] = dnT;
             }
         }
         __syncthreads();
@@ -1015,7 +1001,7 @@ template <typename T, int BLOCK, bool VEC, int VNT>
 __global__ __launch_bounds__(BLOCK) void aypx_beta_x_kernel(int n, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ xs,
                                                             long long ld, const typename VT<T>::acc *__restrict__ partials, int P,
                                                             int nrhs, const T *__restrict__ alpha, T *delta, T *beta, T *history,
-                                                            const int *iter) {
+                                                            int history_cap, const int *iter) {
     using A = typename VT<T>::acc;
     __shared__ A red[BLOCK / kWave];
     __shared__ T beta_s;
@@ -1034,7 +1020,7 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_x_kernel(int n, const T *__re
             if (blockIdx.x == 0) {
                 beta[r] = b;
                 delta[r] = dnT;
-                history[(long long)it * nrhs + r] = dnT;
+                if (it < history_cap) history[(long long)it * nrhs + r] = dnT;
             }
         }
         __syncthreads();
@@ -1139,7 +1125,7 @@ __global__ __launch_bounds__(BLOCK) void pcg_aypx_beta_kernel(int n, const T *__
                                                               const T *__restrict__ m, long long ld,
                                                               const typename VT<T>::acc *__restrict__ part_rz,
                                                               const typename VT<T>::acc *__restrict__ part_rr, int P, int nrhs,
-                                                              T *delta, T *beta, T *history, T *rho2, const int *iter,
+                                                              T *delta, T *beta, T *history, int history_cap, T *rho2, const int *iter,
                                                               T *__restrict__ xs, const T *__restrict__ alpha) {
     using A = typename VT<T>::acc;
     __shared__ A red[BLOCK / kWave];
@@ -1166,7 +1152,7 @@ __global__ __launch_bounds__(BLOCK) void pcg_aypx_beta_kernel(int n, const T *__
                 beta[r] = b;
                 delta[r] = rhoT;                                   // cg_alpha divides this by p.q
                 rho2[(long long)(it & 1) * nrhs + r] = rhoT;
-                history[(long long)it * nrhs + r] = from_acc<T>(acc2);   // r.r: what the stopping test looks at
+                if (it < history_cap) history[(long long)it * nrhs + r] = from_acc<T>(acc2);   // r.r: what the stopping test looks at
             }
         }
         __syncthreads();
@@ -1880,7 +1866,6 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     a.partials = static_cast<typename VT<T>::acc *>(partials);
     a.row_blocks = plan.row_blocks;
     a.rb_list = rb_list; a.rb_count = rb_count;
-    a.ynt = tune().spmm_ynt > 0;
     const bool vec = aligned16(vals) && aligned16(cols);
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
@@ -1889,7 +1874,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     if (variant == 5) {
         a.cap = (plan.max_span + 3) & ~3;
         a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
-        const size_t lds = (size_t)a.cap * (sizeof(T) + 4) + (size_t)tune().spmv_lds_pad;
+        const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
         dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : rowblock_grid(plan.row_blocks, a.cycle), nrhs);
         if (rb_list && rb_count <= 0) return CGAMD_OK;
         const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
@@ -1906,16 +1891,6 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         }                                                                                                               \
     } while (0)
         // 8 gathers in flight per lane for 4/8-byte values; 4 for complex128 (8 would cost 3 waves/SIMD of occupancy)
-        if (tune().spmv_policy >= 0 && sizeof(T) == 8 && !VT<T>::cplx && fuse) {
-            // experiment: matrix stream through buffer loads with an explicit cache policy (f64, fused dot only)
-#define CG_POL(P) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, true, true, 8, P>), g5, block, lds, st, a)
-            switch (tune().spmv_policy) {
-            case 0: CG_POL(0); break;   case 1: CG_POL(1); break;   case 2: CG_POL(2); break;   case 3: CG_POL(3); break;
-            case 16: CG_POL(16); break; case 17: CG_POL(17); break; case 18: CG_POL(18); break; default: CG_POL(19); break;
-            }
-#undef CG_POL
-            return check_launch("spmv_rowblock(policy)");
-        }
         const int unroll = tune().spmv_unroll ? tune().spmv_unroll : (sizeof(T) > 8 ? 4 : 8);
         if (unroll == 4) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
         else { if (nt) CG_RB(true, 8); else CG_RB(false, 8); }
@@ -1994,6 +1969,25 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         else hipLaunchKernelGGL((spmv_stream_kernel<T, kBlock, kQuadsPerThread, false, false>), grid, block, dyn, st, a);
     }
     return check_launch("spmv");
+}
+
+int validate_csr_device(int n, long long nnz, int ncols, const int *ptr_dev, const int *cols_dev, const int *index_dev, int n_index,
+                        int index_bound, int *scratch_dev, hipStream_t st) {
+    CG_HIP(hipMemsetAsync(scratch_dev, 0, sizeof(int), st));
+    long long work = std::max<long long>(nnz, n);
+    int g = (int)std::min<long long>((work + 255) / 256, 4096);
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(csr_validate_kernel, dim3(g), dim3(256), 0, st, n, nnz, ncols, ptr_dev, cols_dev, index_dev, n_index, index_bound, scratch_dev);
+    if (int rc = check_launch("csr_validate")) return rc;
+    int flag = 0;
+    CG_HIP(hipMemcpyAsync(&flag, scratch_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    CG_HIP(hipStreamSynchronize(st));
+    if (flag & 1) return fail(CGAMD_ERR_INVALID, "CSR: aPointers[0] != 0");
+    if (flag & 2) return fail(CGAMD_ERR_INVALID, "CSR: aPointers not monotone");
+    if (flag & 4) return fail(CGAMD_ERR_INVALID, "CSR: aPointers[size] != nonZeros");
+    if (flag & 8) return fail(CGAMD_ERR_INVALID, "CSR: column index out of range");
+    if (flag & 16) return fail(CGAMD_ERR_INVALID, "partition plan: send_index entry out of range");
+    return CGAMD_OK;
 }
 
 int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan) {
@@ -2195,7 +2189,7 @@ static int aypx_beta_x_impl(int n, const void *x, void *y, void *xs, long long l
     dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
     auto *pp = static_cast<const typename VT<T>::acc *>(partials);
 #define CG_AX(V, N) hipLaunchKernelGGL((aypx_beta_x_kernel<T, kBlock, V, N>), g, blk, 0, st, n, (const T *)x, (T *)y, (T *)xs, ld, pp, P, nrhs, \
-                                       (const T *)sc.alpha, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, (const int *)sc.iter)
+                                       (const T *)sc.alpha, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (const int *)sc.iter)
     if (vec && (vnt & 1)) CG_AX(true, 1); else if (vec) CG_AX(true, 0); else CG_AX(false, 0);
 #undef CG_AX
     return check_launch("aypx_beta_x");
@@ -2305,8 +2299,8 @@ static int aypx_beta_impl(int n, const void *x, void *y, long long ld, const voi
                           const CgScalars &sc, bool vec, hipStream_t st) {
     dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
     auto *pp = static_cast<const typename VT<T>::acc *>(partials);
-    if (vec) hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.iter);
-    else hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.iter);
+    if (vec) hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter);
+    else hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter);
     return check_launch("aypx_beta");
 }
 int launch_aypx_beta(int dtype, int n, const void *x, void *y, long long ld, const void *partials, int P, int nrhs,
@@ -2336,7 +2330,7 @@ static int spmv_fused_impl(const SpmvPlan &plan, int n, long long nnz, const voi
     a.x = static_cast<const T *>(d_old); a.ldx = n;
     a.y = static_cast<T *>(q); a.ldy = n;
     a.dvec = nullptr; a.partials = static_cast<A *>(part_dq);
-    a.row_blocks = plan.row_blocks; a.rb_list = nullptr; a.rb_count = 0; a.ynt = 0;
+    a.row_blocks = plan.row_blocks; a.rb_list = nullptr; a.rb_count = 0;
     a.cap = (plan.max_span + 3) & ~3;
     a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
     FusedArgs<T> f;
@@ -2391,8 +2385,8 @@ static int pcg_aypx_impl(int n, const void *r, void *p, const void *m, long long
                          int P, int nrhs, const CgScalars &sc, void *rho2, void *xs, bool vec, hipStream_t st) {
     dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
     using A = typename VT<T>::acc;
-    if (vec) hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
-    else hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
+    if (vec) hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
+    else hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
     return check_launch("pcg_aypx_beta");
 }
 int launch_pcg_aypx_beta(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *part_rz,

@@ -251,6 +251,8 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) rc = dmalloc((void **)&s->sc.ticket, sizeof(unsigned) * (size_t)nRHS, "alpha tickets");
     if (!rc && hipMemsetAsync(s->sc.ticket, 0, sizeof(unsigned) * (size_t)nRHS, ctx->stream) != hipSuccess) rc = fail(CGAMD_ERR_HIP, "hipMemsetAsync(alpha tickets)");
     if (!rc) rc = ensure_history(s, 1024);
+    if (!rc && (flags & CGAMD_MATRIX_ON_DEVICE))      // host matrices were checked before the upload
+        rc = validate_csr_device(size, nnz, size, s->ptr, s->cols, nullptr, 0, 0, s->sc.iter, ctx->stream);
     if (!rc) rc = compute_spmv_plan(s->ptr, s->cols, size, s->sc.iter, ctx->stream, &s->plan);
     if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, size, nnz, s->vals, s->cols);
     if (!rc && s->rm_ok) s->rm_nwg = spmm_rm_grid(dtype, nRHS, size, s->plan.max_quad, true);

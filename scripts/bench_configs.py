@@ -139,6 +139,17 @@ if "report" in which:
                       "cg_it_per_s": 5000 / dt, "us_per_iter": dt / 5000 * 1e6, "gflops_report_model": flops * 5000 / dt / 1e9,
                       "published_2080S_gflops": 2.390}), flush=True)
     s.close()
+if "c5" in which:
+    # BASELINE config 5's system whole on one GPU (N = 99.9M, 8.4 GB of CSR), and one rank's 1/8 z-slab of it
+    ip, ix, da = pkg.generators.laplace3d(ctx, 464, 464, 464, dtype=np.float64)
+    run("C5 3D 7-pt 464^3 N=99.9M f64, one GPU", ip, ix, da, np.float64, 1, iters=40, reps=8)
+    del ip, ix, da
+    torch.cuda.empty_cache()
+if "c5" in which or "c5slab" in which:
+    ip, ix, da = pkg.generators.laplace3d(ctx, 464, 464, 58, dtype=np.float64)
+    run("C5-slab 464x464x58 (one rank of 8) N=12.49M f64, plain solver", ip, ix, da, np.float64, 1, iters=100, reps=20)
+    del ip, ix, da
+    torch.cuda.empty_cache()
 if "m32" in which:
     ip, ix, da = pkg.generators.laplace3d(ctx, 250, 200, 200, dtype=np.float32)
     run("M 3D 7-pt N=10M f32", ip, ix, da, np.float32, 1)

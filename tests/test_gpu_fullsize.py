@@ -167,3 +167,95 @@ def test_mm_cli_roundtrip_on_gpu(pkg, gpu, tmp_path):
     last = [ln for ln in r.stdout.splitlines() if ln.startswith("iteration")][-1]
     got = [float(t) for t in last.split("{")[1].split("}")[0].split()]
     assert np.allclose(got, np.abs(ho[-1]), rtol=1e-5)
+
+
+def test_config5_464cube_on_one_gpu(pkg, gpu):
+    """BASELINE config 5's matrix -- 3-D 7-point stencil 464^3, N = 99 897 344, nnz = 697 989 632 (C5) --
+    whole on ONE GPU (8.4 GB of CSR + 5 GB of vectors fit 288 GB): exact A.1, a random product against the shift-based
+    operator, the residual identity r_k = b - A x_k and delta_k = r_k.r_k of the recurrence.  32-bit indices hold
+    (nnz < 2^31), byte offsets do not: this is also the test of 64-bit addressing in the kernels."""
+    import torch
+    ctx, queue, kernels = gpu
+    nx = ny = nz = 464
+    n = nx * ny * nz
+    dev = torch.device("cuda", 0)
+    indptr, indices, data = pkg.generators.laplace3d(ctx, nx, ny, nz, dtype=np.float64)
+    assert n == 99_897_344 and indices.numel() == 697_989_632 == 7 * n - 6 * nx * nx
+    s = pkg.Solver(ctx, n, indices.numel(), data, indptr, indices, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=np.float64)
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    ones = torch.ones(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    s.spmv(ones, y, fused_dot=True)
+    ctx.synchronize()
+    assert torch.equal(y, _stencil_apply(torch, ones, nx, ny, nz))
+    assert float(y.sum()) == 2.0 * 3 * nx * nx
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 0.5
+    torch.cuda.synchronize()
+    s.spmv(x, y, fused_dot=False)
+    ctx.synchronize()
+    assert float((y - _stencil_apply(torch, x, nx, ny, nz)).abs().max()) < 1e-14 * 12
+    del x, ones
+    b = torch.full((n,), 5.0, dtype=torch.float64, device=dev)     # main.c:44
+    torch.cuda.synchronize()
+    s.set_rhs(b, None, on_device=True)
+    s.iterate(12)
+    xk = s.x(torch.empty(n, dtype=torch.float64, device=dev))
+    ctx.synchronize()
+    hist = s.history()
+    assert hist.shape == (13, 1) and hist[0, 0] == 25.0 * n and np.all(np.isfinite(hist))
+    true_r = b - _stencil_apply(torch, xk, nx, ny, nz)
+    dk = float(torch.dot(true_r, true_r))
+    assert abs(dk - hist[-1, 0]) / hist[-1, 0] < 1e-9
+    s.close()
+
+
+@pytest.mark.parametrize("loop", ["p2p4", "p2p4+graph", "p2p", "rccl", "rccl+graph"])
+def test_config5_rank_slab_through_the_distributed_loops(pkg, gpu, loop):
+    """One rank's share of config 5 (464 x 464 x 58 = 1/8 of 464^3: 12.49M rows, 87.2M non-zeros) through the
+    row-partitioned C loops with the rank as its OWN halo peer (the plane below is routed through halo slots the rank fills
+    from its own first plane: pack / push / wait / in-place halo reads / send-recv to self, the scalar all-reduces), against
+    the plain single-GPU solver on the same slab.  The routed product equals the plain one, so histories must agree to
+    rounding (the partial sums are grouped differently) -- at the size one rank really has on the 8-GPU node."""
+    import torch
+    ctx, queue, kernels = gpu
+    dmod = importlib.import_module("conjugate-gradient-pyopencl_amd.dist")
+    L = pkg._lib
+    lib = L.load()
+    nx, ny, nz = 464, 464, 58
+    n, h = nx * ny * nz, nx * ny
+    dev = torch.device("cuda", 0)
+    indptr, indices, data = pkg.generators.laplace3d(ctx, nx, ny, nz, dtype=np.float64)
+    assert n == 12_487_168
+    b = torch.full((n,), 5.0, dtype=torch.float64, device=dev)
+    iters = 25
+    ref = pkg.Solver(ctx, n, indices.numel(), data, indptr, indices, 1, flags=L.MATRIX_ON_DEVICE, dtype=np.float64)
+    torch.cuda.synchronize()
+    ref.set_rhs(b, None, on_device=True)
+    ref.iterate(iters)
+    x_ref = ref.x(torch.empty(n, dtype=torch.float64, device=dev)).clone()
+    h_ref = ref.history()[:, 0].copy()
+    ref.close()
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]).long())
+    route = (indices < h) & (rows >= h)
+    cols_local = torch.where(route, indices + n, indices).to(torch.int32)
+    del rows, route
+    plan = dmod.HaloPlan(0, 1, 0, n, n, h, cols_local, torch.arange(h), [0], [h], [h], torch.arange(h, dtype=torch.int32, device=dev))
+    flags = L.DIST_GRAPH if loop.endswith("+graph") else 0
+    if loop.startswith("p2p"):
+        if not loop.startswith("p2p4"):
+            flags |= L.DIST_P2P_STAGED | L.DIST_NO_OVERLAP
+        d = dmod.DistSolver(ctx, plan, indptr, data, np.float64, flags=flags, comm="p2p")
+    else:
+        uid = np.zeros(128, dtype=np.uint8)
+        L.check(lib.cgamd_comm_unique_id(L.ptr(uid)))
+        d = dmod.DistSolver(ctx, plan, indptr, data, np.float64, unique_id=uid, flags=flags)
+        assert d.comm_ranks() == 1
+    d.set_rhs(b, None)
+    d.iterate(iters)
+    x = d.x(torch.empty(n, dtype=torch.float64, device=dev))
+    hist = d.history()
+    assert d.p2p_error() == 0
+    d.close()
+    assert np.max(np.abs(hist - h_ref) / np.abs(h_ref)) < 1e-10
+    assert float((x - x_ref).norm() / x_ref.norm()) < 1e-9

@@ -197,6 +197,20 @@ def test_error_reporting_on_gpu(pkg, gpu):
     with pytest.raises(pkg.CgAmdError):
         s.spmm_rowmajor(s.vector("x"), s.vector("r"), 8)                               # nRHS must be 16 or 32
     s.close()
+    # a matrix that is ALREADY on the device is validated there: bad indices are an error, not an out-of-bounds gather
+    ipg, ixg, dag = (pkg.DeviceBuffer(ctx, hostbuf=a) for a in (np.array([0, 2, 4, 6], dtype=np.int32), np.array([0, 1, 1, 7, 0, 2], dtype=np.int32), np.ones(6)))
+    with pytest.raises(pkg.CgAmdError) as e:
+        pkg.Solver(ctx, 3, 6, dag, ipg, ixg, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=np.float64)
+    assert e.value.status == 1 and "column index out of range" in str(e.value)
+    ipb = pkg.DeviceBuffer(ctx, hostbuf=np.array([0, 4, 2, 6], dtype=np.int32))
+    ixok = pkg.DeviceBuffer(ctx, hostbuf=np.array([0, 1, 1, 2, 0, 2], dtype=np.int32))
+    with pytest.raises(pkg.CgAmdError) as e:
+        pkg.Solver(ctx, 3, 6, dag, ipb, ixok, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=np.float64)
+    assert "monotone" in str(e.value)
+    ipc = pkg.DeviceBuffer(ctx, hostbuf=np.array([0, 2, 4, 5], dtype=np.int32))
+    with pytest.raises(pkg.CgAmdError) as e:
+        pkg.Solver(ctx, 3, 6, dag, ipc, ixok, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=np.float64)
+    assert "aPointers[size] != nonZeros" in str(e.value)
 
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
