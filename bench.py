@@ -221,8 +221,9 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
     it_s = args.steps / dt
 
     # ---- dominant kernel: the fused SpMV (+ d.q partials).  Its launch duration is measured live, IN the CG loop:
-    # an instrumented pass of the same K iterations with a HIP event pair around every SpMV launch on the stream
-    # the kernel runs on (plain launches; the timed region above replays the same kernels from a hipGraph).
+    # an instrumented pass of the same K iterations in which every SpMV dispatch carries its own HIP start/stop event
+    # pair (hipExtLaunchKernelGGL on the solver's stream: the kernel's execution time, what rocprofv3's kernel trace
+    # reports; plain launches -- the timed region above replays the same kernels from a hipGraph).
     spmv_ms = None
     if not args.unfused:
         spmv_ms, inst_iter_ms = solver.iterate_timed(args.steps)
@@ -268,7 +269,7 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
         "cg_iter_moved_bytes": moved_bytes,
         "cg_iter_moved_pct_of_8tbs": 100.0 * moved_bytes * it_s / 1e9 / HBM_PEAK_GBS,
         "residual_check": {"delta_0": float(delta0), "delta_last": float(deltak), "iterations": int(hist.shape[0] - 1)},
-        "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel (CSR SpMV fused with d.q partials), in-loop average over the instrumented pass",
+        "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel (CSR SpMV fused with d.q partials), in-loop average over the instrumented pass (HIP events on each dispatch)",
                      "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                      "traffic": pmc_traffic()[0], "traffic_source": pmc_traffic()[1],
                      "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms},

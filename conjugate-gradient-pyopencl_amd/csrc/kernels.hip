@@ -23,6 +23,8 @@
 #include "device_types.h"
 #include "device_mem.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <functional>
 #include <mutex>
@@ -1794,6 +1796,21 @@ template <typename T> __global__ void gen_poisson2d_kernel(int N, T *vals, int *
     default: return fail(CGAMD_ERR_INVALID, "bad dtype");                   \
     }
 
+// cgamd_solver_iterate_timed: the next SpMV launch of this thread carries a start / stop event pair ON THE DISPATCH ITSELF
+// (hipExtLaunchKernelGGL), so the pair measures the kernel's execution like a profiler's kernel trace does -- not the
+// launch gaps and event barriers that hipEventRecord calls around a launch add (about 15 us per launch at N = 10M).
+static thread_local hipEvent_t *t_kernel_events = nullptr;
+void set_kernel_event_pair(hipEvent_t *pair) { t_kernel_events = pair; }
+#define CG_LAUNCH_EV(KERNEL, GRID, BLOCKDIM, LDS, STREAM, ...)                                                                  \
+    do {                                                                                                                       \
+        if (t_kernel_events) {                                                                                                 \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, LDS, STREAM, t_kernel_events[0], t_kernel_events[1], 0, __VA_ARGS__); \
+            t_kernel_events = nullptr;                                                                                         \
+        } else {                                                                                                               \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, LDS, STREAM, __VA_ARGS__);                                              \
+        }                                                                                                                      \
+    } while (0)
+
 static int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -1883,11 +1900,11 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
 #define CG_RB(NT, UNR)                                                                                                  \
     do {                                                                                                                \
         if (ilv) {                                                                                                      \
-            if (fuse) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -2>), g5, block, lds, st, a);  \
-            else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -2>), g5, block, lds, st, a);      \
+            if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -2>), g5, block, lds, st, a);        \
+            else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -2>), g5, block, lds, st, a);            \
         } else {                                                                                                        \
-            if (fuse) hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, true, UNR>), g5, block, lds, st, a);      \
-            else hipLaunchKernelGGL((spmv_rowblock_kernel<T, kBlock, NT, false, UNR>), g5, block, lds, st, a);          \
+            if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR>), g5, block, lds, st, a);            \
+            else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR>), g5, block, lds, st, a);                \
         }                                                                                                               \
     } while (0)
         // 8 gathers in flight per lane for 4/8-byte values; 4 for complex128 (8 would cost 3 waves/SIMD of occupancy)

@@ -89,16 +89,22 @@ static bool fused2_now(const cgamd_solver *s) { return s->fused2 && !s->rm && !s
 // k = iterations already enqueued since set_rhs (the iteration being enqueued is number k + 1)
 static int enqueue_spmv(cgamd_solver *s, int k, hipStream_t st) {
     const int dt = s->dtype, n = s->n, nr = s->nrhs;
-    if (s->ev_pair) CG_HIP(hipEventRecord(s->ev_pair[0], st));
+    // timed pass: the row-block kernel of a single right-hand side takes the event pair on its dispatch (kernel duration);
+    // every other SpMV form is bracketed by hipEventRecord (duration + launch gaps)
+    const bool fused2 = fused2_now(s);
+    const bool ext = s->ev_pair && !fused2 && !s->rm && nr == 1 && s->plan.kind == 5;
+    if (s->ev_pair && !ext) CG_HIP(hipEventRecord(s->ev_pair[0], st));
+    if (ext) set_kernel_event_pair(s->ev_pair);
     int rc;
-    if (fused2_now(s))
+    if (fused2)
         rc = launch_spmv_fused(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, dbuf(s, k), dbuf(s, k + 1), s->r, s->q, nr, s->part_dq,
                                s->part_rr, s->vgrid, s->sc, st);
     else if (s->rm) rc = launch_spmm_rm(dt, n, s->nnz, s->vals, s->ptr, s->cols, s->d, s->q, nr, s->part_dq, s->plan.max_quad, st);
     else if (s->flags & CGAMD_UNFUSED) rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, nullptr, nullptr, st);
     else rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st);
+    set_kernel_event_pair(nullptr);
     if (rc) return rc;
-    if (s->ev_pair) CG_HIP(hipEventRecord(s->ev_pair[1], st));
+    if (s->ev_pair && !ext) CG_HIP(hipEventRecord(s->ev_pair[1], st));
     return CGAMD_OK;
 }
 

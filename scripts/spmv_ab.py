@@ -62,7 +62,7 @@ def main():
     ys = torch.empty(n, dtype=tdt, device=dev)
     torch.cuda.synchronize()
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-    defaults = {"spmv_variant": 5, "spmv_nt": -1, "spmv_grid": 0, "vec_grid": 0, "spmv_cycle": 64, "spmv_ilv": -1, "defer_x": 1, "spmv_chunked": 1, "spmv_chunk_kb": 0, "spmv_slice_kb": 0, "fold_alpha": 1, "alpha_two_level": 1, "spmv_unroll": 0, "spmv_lds_pad": 0, "spmv_policy": -1, "vec_nt": -1, "vec_skew": 0}
+    defaults = {"spmv_variant": 5, "spmv_nt": -1, "spmv_grid": 0, "vec_grid": 0, "spmv_cycle": 64, "spmv_ilv": -1, "defer_x": 1, "spmv_chunked": 1, "spmv_chunk_kb": 0, "spmv_slice_kb": 0, "fold_alpha": 1, "alpha_two_level": 1, "spmv_unroll": 0, "vec_nt": -1, "vec_skew": 0}
     solvers = []
     for cfg in args.cfgs:
         kv = dict(defaults)
@@ -79,7 +79,7 @@ def main():
     for rnd in range(args.rounds):
         for cfg, kv, s in solvers:
             for k, v in kv.items():
-                lib.cgamd_tune(k.encode(), v)       # variant/nt are read at launch time
+                lib.cgamd_tune(k.encode(), v)       # (every solver runs with the snapshot taken when it was created)
             for _ in range(3):
                 s.spmv(xs, ys, fused_dot=True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
