@@ -30,9 +30,27 @@ from . import _lib
 from ._lib import check, ptr
 
 
-def row_ranges(n, world):
-    """[(begin, end)] of the contiguous row block of every rank."""
-    return [(n * g // world, n * (g + 1) // world) for g in range(world)]
+def row_ranges(n, world, indptr=None):
+    """[(begin, end)] of the contiguous row block of every rank.
+
+    Without `indptr`: equal row counts (what a stencil wants).  With the global row pointers (any array-like of n + 1
+    non-decreasing integers): contiguous blocks of (nearly) equal NON-ZERO counts -- rank g ends at the first row whose
+    pointer reaches g+1 shares of nnz -- for matrices whose rows differ in length (the SpMV streams non-zeros, so that is what
+    balances the ranks); every rank keeps at least one row while there are rows left."""
+    if indptr is None:
+        return [(n * g // world, n * (g + 1) // world) for g in range(world)]
+    ip = np.asarray(indptr.cpu() if hasattr(indptr, "cpu") else indptr, dtype=np.int64)
+    if ip.shape[0] != n + 1:
+        raise ValueError("indptr must have n + 1 entries")
+    nnz = int(ip[-1])
+    cuts = [0]
+    for g in range(1, world):
+        target = (nnz * g + world - 1) // world
+        r = int(np.searchsorted(ip, target, side="left"))
+        r = min(max(r, cuts[-1] + 1), n - (world - g))      # at least one row per rank on either side
+        cuts.append(max(r, cuts[-1]))
+    cuts.append(n)
+    return [(cuts[g], cuts[g + 1]) for g in range(world)]
 
 
 @dataclass

@@ -57,7 +57,7 @@ def _worker(rank, world, port, kind, iters, out_dir):
     try:
         ip, ix, da, b = _system(kind)
         n = len(ip) - 1
-        ranges = dmod.row_ranges(n, world)
+        ranges = dmod.row_ranges(n, world, indptr=ip if kind == "random" else None)
         rb, re = ranges[rank]
         lo, hi = ip[rb], ip[re]
         ip_loc = (ip[rb:re + 1] - lo).astype(np.int32)
@@ -105,7 +105,8 @@ def test_distributed_cg_matches_serial_oracle(tmp_path, world, kind):
     xo, ho = cg_oracle.cg(ip, ix, da, b.astype(da.dtype), n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
     parts = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
     x = np.concatenate([p["x"] for p in parts])
-    assert [int(p["rb"]) for p in parts] == [len(b) * g // world for g in range(world)]
+    if kind != "random":
+        assert [int(p["rb"]) for p in parts] == [len(b) * g // world for g in range(world)]
     # every rank holds the same global residual history
     for p in parts[1:]:
         assert np.allclose(p["hist"], parts[0]["hist"], rtol=1e-12)
@@ -115,6 +116,29 @@ def test_distributed_cg_matches_serial_oracle(tmp_path, world, kind):
     if kind == "lap3d":       # z-slab partition of a 7-point stencil: one plane per neighbour
         assert all(int(p["n_halo"]) in (30, 60) for p in parts)
         assert [list(p["peers"]) for p in parts] == ([[1], [0]] if world == 2 else [[1], [0, 2], [1]])
+
+
+def test_nnz_balanced_row_ranges(pkg):
+    """irregular matrices: contiguous row blocks with (nearly) equal non-zero counts"""
+    dmod = importlib.import_module(PKG_NAME + ".dist")
+    rng = np.random.default_rng(2)
+    counts = np.concatenate([rng.integers(1, 4, 700), rng.integers(40, 60, 300)])        # a dense tail
+    ip = np.concatenate([[0], np.cumsum(counts)])
+    n, nnz = len(counts), int(ip[-1])
+    for world in (2, 3, 8):
+        rr = dmod.row_ranges(n, world, indptr=ip)
+        assert rr[0][0] == 0 and rr[-1][1] == n and all(a[1] == b[0] for a, b in zip(rr, rr[1:]))
+        per = [int(ip[e] - ip[b]) for b, e in rr]
+        assert all(e > b for b, e in rr)
+        assert max(per) - min(per) <= 2 * counts.max(), (world, per)
+        assert max(per) < 1.1 * nnz / world + counts.max()
+        rows_equal = [int(ip[e] - ip[b]) for b, e in dmod.row_ranges(n, world)]
+        assert max(rows_equal) > 1.5 * max(per) or world == 2          # equal row counts would be badly unbalanced here
+    # degenerate shapes: more ranks than "shares", empty rows, all weight in one row
+    assert dmod.row_ranges(3, 3, indptr=[0, 0, 0, 9]) == [(0, 1), (1, 2), (2, 3)]
+    assert dmod.row_ranges(4, 2, indptr=[0, 100, 100, 100, 100]) == [(0, 1), (1, 4)]
+    with pytest.raises(ValueError):
+        dmod.row_ranges(4, 2, indptr=[0, 1, 2])
 
 
 def test_row_ranges_and_single_rank_plan(pkg):
