@@ -35,6 +35,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmv_nt") g_tune.spmv_nt = value;
     else if (k == "spmv_grid") g_tune.spmv_grid = value;
     else if (k == "vec_grid") g_tune.vec_grid = value;
+    else if (k == "vec_ppt") g_tune.vec_ppt = value;
     else if (k == "spmv_cycle") g_tune.spmv_cycle = value;
     else if (k == "spmv_ilv") g_tune.spmv_ilv = value;
     else if (k == "spmv_chunked") g_tune.spmv_chunked = value;

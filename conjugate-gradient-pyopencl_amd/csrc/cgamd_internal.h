@@ -87,6 +87,7 @@ struct Tuning {
     int spmv_cycle = 64;    // row-block schedule: block-cyclic over the XCDs, cycle length in row blocks (1 = contiguous eighths)
     int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)
     int vec_grid = 0;       // vector kernels: 0 = auto
+    int vec_ppt = 0;        // vector kernels: 16-byte packs per thread the grid is sized for (0 = by size: 1, 2 or 4)
 };
 // g_tune is the process-wide configuration cgamd_tune edits (under a mutex).  Nothing on a compute path reads it
 // directly: every solver / distributed handle copies it at creation (tune_snapshot()), and each C-ABI entry installs the
@@ -109,7 +110,7 @@ struct TuneScope {
     explicit TuneScope(const Tuning *t);
     ~TuneScope();
 };
-int vec_grid(long long n_elems_per_rhs, int dtype);
+int vec_grid(long long n_elems_per_rhs, int dtype, int nrhs = 1);
 
 // ---- kernel launchers (all asynchronous on `st`) ------------------------------
 // y = A x for nrhs vectors; x has leading dimension ldx (>= number of columns), y has ldy.

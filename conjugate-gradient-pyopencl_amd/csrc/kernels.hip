@@ -1829,8 +1829,13 @@ SpmvPlan make_spmv_plan(int n) {
     return p;
 }
 
-int vec_grid(long long n, int dtype) {
-    const long long per_block = (long long)kBlock * (16 / (long long)dtype_size(dtype)) * 4;  // 4 packs per thread
+int vec_grid(long long n, int dtype, int nrhs) {
+    // 16-byte packs per thread the grid is sized for: 4 for streaming sizes; small systems want every CU busy instead
+    // (profiles/r2_experiments/vec_ppt.log: 16k rows 10.4 -> 9.2 us per iteration with 1, 250k rows 16.2 -> 15.8 with 2,
+    // N = 1M 32.2 -> 34.0 with 1); "vec_ppt" overrides
+    const long long total = n * (long long)(nrhs > 0 ? nrhs : 1);
+    const int ppt = tune().vec_ppt > 0 ? tune().vec_ppt : (total <= 262144 ? 1 : total <= 524288 ? 2 : 4);
+    const long long per_block = (long long)kBlock * (16 / (long long)dtype_size(dtype)) * ppt;
     long long g = (n + per_block - 1) / per_block;
     const long long cap = tune().vec_grid > 0 ? tune().vec_grid : kMaxGrid;
     if (g > cap) g = cap;
@@ -2122,7 +2127,7 @@ int launch_reduce_to_value(int dtype, const void *partials, int grid, int nrhs, 
 template <typename T, int OP>
 static int ewise_impl(int n, const void *x, void *y, const void *b2, long long ld, const void *alpha, int nrhs, bool vec,
                       hipStream_t st) {
-    dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
+    dim3 g(vec_grid(n, VT<T>::dtype, nrhs), nrhs), blk(kBlock);
     if (vec) hipLaunchKernelGGL((ewise_kernel<T, kBlock, true, OP>), g, blk, 0, st, n, (const T *)x, (T *)y, (const T *)b2, ld, (const T *)alpha);
     else hipLaunchKernelGGL((ewise_kernel<T, kBlock, false, OP>), g, blk, 0, st, n, (const T *)x, (T *)y, (const T *)b2, ld, (const T *)alpha);
     return check_launch("ewise");
@@ -2203,7 +2208,7 @@ int launch_axpy_dot_alpha(int dtype, int n, const void *q, void *r, long long ld
 template <typename T>
 static int aypx_beta_x_impl(int n, const void *x, void *y, void *xs, long long ld, const void *partials, int P, int nrhs,
                             const CgScalars &sc, bool vec, int vnt, hipStream_t st) {
-    dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
+    dim3 g(vec_grid(n, VT<T>::dtype, nrhs), nrhs), blk(kBlock);
     auto *pp = static_cast<const typename VT<T>::acc *>(partials);
 #define CG_AX(V, N) hipLaunchKernelGGL((aypx_beta_x_kernel<T, kBlock, V, N>), g, blk, 0, st, n, (const T *)x, (T *)y, (T *)xs, ld, pp, P, nrhs, \
                                        (const T *)sc.alpha, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (const int *)sc.iter)
@@ -2314,7 +2319,7 @@ int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, h
 template <typename T>
 static int aypx_beta_impl(int n, const void *x, void *y, long long ld, const void *partials, int P, int nrhs,
                           const CgScalars &sc, bool vec, hipStream_t st) {
-    dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
+    dim3 g(vec_grid(n, VT<T>::dtype, nrhs), nrhs), blk(kBlock);
     auto *pp = static_cast<const typename VT<T>::acc *>(partials);
     if (vec) hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter);
     else hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter);
@@ -2400,7 +2405,7 @@ int launch_pcg_axpy2_dot2(int dtype, bool init, int n, const void *d, void *x, c
 template <typename T>
 static int pcg_aypx_impl(int n, const void *r, void *p, const void *m, long long ld, const void *part_rz, const void *part_rr,
                          int P, int nrhs, const CgScalars &sc, void *rho2, void *xs, bool vec, hipStream_t st) {
-    dim3 g(vec_grid(n, VT<T>::dtype), nrhs), blk(kBlock);
+    dim3 g(vec_grid(n, VT<T>::dtype, nrhs), nrhs), blk(kBlock);
     using A = typename VT<T>::acc;
     if (vec) hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
     else hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);

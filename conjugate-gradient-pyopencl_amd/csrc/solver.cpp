@@ -206,7 +206,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     TuneScope ts(&s->tune);
     s->ctx = ctx; s->dtype = dtype; s->n = size; s->nnz = nnz; s->nrhs = nRHS; s->flags = flags;
     s->plan = make_spmv_plan(size);
-    s->vgrid = vec_grid(size, dtype);
+    s->vgrid = vec_grid(size, dtype, nRHS);
     s->defer_x = tune().defer_x != 0;
     s->rm_ok = nRHS > 1 && tune().spmm_rowmajor != 0 && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS, size);
     if (s->rm_ok) s->rm_vgrid = rm_vec_grid((long long)size * nRHS, dtype);
