@@ -70,7 +70,8 @@ struct Tuning {
     int spmm_wgs = 0;       // row-major SpMM sweep: work-groups per XCD (0 = 64: 256 strips of 16 rows open per XCD)
     int spmm_tq = 0;        // fp64 row-major SpMM: 8 = always the generic 8-K-steps-per-quad instance (experiment)
     int spmm_nq = 0;        // fp64 row-major SpMM: 2 = 8-row strips where they fit (experiment; default 16-row strips)
-    int spmm_rowmajor = 1;  // solvers with 16/32/64 right-hand sides (f32, f64; complex64: 16/32) keep the block row-major
+    int spmm_rowmajor = 1;  // 1: solvers keep the block row-major where that loop is the faster one (f64 x 32); 2: for every supported type
+                            // (f32 16/32/64, f64 16/32, complex64 16/32); 0: never
                             // and multiply on the matrix cores (0 = RHS-major VALU kernel as for every other width)
     int vec_skew = 0;       // bytes added to the pitch between the solver's vectors (multiple of 16)
     int vec_nt = -1;        // -1 auto (by working-set size, finalize_spmv_plan); axpy2_dot: bit0 = x loaded/stored non-temporally (touched once per iteration), bit1 = q loaded

@@ -5,7 +5,7 @@
 // same layout); the reference's ABI layout (RHS-major, spmv.cl:25,48) is converted once per solve at the boundary
 // (set_rhs / get_x), not per iteration.
 //
-//   spmm_rm_mfma_kernel   Y = A X (+ per-RHS d.q partials), CSR A, f32 / f64 / complex64, R*(1|2) in {16, 32, 64} real columns
+//   spmm_rm_kernel        Y = A X (+ per-RHS d.q partials), CSR A, f32 / f64 / complex64, R*(1|2) in {16, 32, 64} real columns
 //   rm_dot / rm_axpy_dot / rm_aypx_x   the vector kernels of the fused loop with per-column scalars
 //
 // SpMM design (MI355X).  Measured problem of the round-1 kernels (profiles/r1/pmc_spmm_c4_summary.txt): X was fetched
@@ -37,8 +37,6 @@
 #include <algorithm>
 
 namespace cgamd {
-
-constexpr int kRmCap = 128;      // entries of a strip staged per round and wave (32 K-steps); longer strips take more rounds
 
 template <typename T, int NH> struct alignas(NH * sizeof(T)) RowVec { T v[NH]; };
 template <typename T, int NH> CG_DEV RowVec<T, NH> ld_rowvec(const T *p) { return *reinterpret_cast<const RowVec<T, NH> *>(p); }
@@ -77,272 +75,60 @@ template <typename T> struct SpmmRmArgs {
     double *partials;       // fused d.q: real [RC][nwg] doubles; complex [RC/2][nwg] (re, im) pairs
 };
 
-// T = float | double (real element type), NH = real columns / 16, CPLX: values and X/Y columns are (re, im) pairs
-template <typename T, int NH, bool CPLX, bool FUSE_DOT, bool YNT>
-__global__ __launch_bounds__(256, 2) void spmm_rm_mfma_kernel(SpmmRmArgs<T> a) {
-    constexpr bool F64 = sizeof(T) == 8;
-    static_assert(!(F64 && CPLX), "complex128 runs the RHS-major kernel");
-    constexpr int RC = 16 * NH, VW = CPLX ? 2 : 1;
-    constexpr int UBraw = 80 / (NH * (int)sizeof(T) / 4);
-    constexpr int UB = UBraw > 32 ? 32 : (UBraw < 4 ? 4 : UBraw);          // K-steps whose X rows are in flight together
-    using RV = RowVec<T, NH>;
-    __shared__ T sv[4][2][kRmCap * VW];
-    __shared__ int sc[4][2][kRmCap];
-    __shared__ double red[4][2 * RC];
-
-    // the wave index is the same in all 64 lanes: say so (readfirstlane), or every strip-level decision below is
-    // compiled as a divergent branch with exec masking
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 15, kq = lane >> 4;
-    const int xcd = blockIdx.x & 7, W = ((int)gridDim.x >> 3) * 4, wl = ((int)blockIdx.x >> 3) * 4 + wave;
-    const int sb = (int)((long long)xcd * a.strips / 8), se = (int)((long long)(xcd + 1) * a.strips / 8);
-
-    double dsum[NH], dcross[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) { dsum[h] = 0.; dcross[h] = 0.; }
-
-    auto load_ptr = [&](int s) -> int {
-        const int row = s * 16 + (lane < 16 ? lane : 16);
-        return a.ptr[row < a.n ? row : a.n];
-    };
-    // entries [tb + r0, min(tb + r0 + kRmCap, te)) of a strip: two per lane, coalesced, streamed past the caches
-    auto fetch = [&](int tb, int te, int r0, T (&ev)[2][VW], int (&ec)[2]) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const long long j = (long long)tb + r0 + e * 64 + lane;
-            if (j < te) {
-                ec[e] = __builtin_nontemporal_load(a.cols + j);
-#pragma unroll
-                for (int w = 0; w < VW; ++w) ev[e][w] = __builtin_nontemporal_load(a.vals + j * VW + w);
-            }
-        }
-    };
-    auto stage = [&](int buf, int cnt, const T (&ev)[2][VW], const int (&ec)[2]) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int jl = e * 64 + lane;
-            if (jl < cnt) {
-                sc[wave][buf][jl] = ec[e];
-#pragma unroll
-                for (int w = 0; w < VW; ++w) sv[wave][buf][jl * VW + w] = ev[e][w];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // LDS of one wave executes in order; compiler ordering only
-    };
-
-    int s = sb + wl;
-    if (s < se) {
-        int p_cur = load_ptr(s);
-        int s_n = s + W;
-        int p_nxt = s_n < se ? load_ptr(s_n) : 0;
-        int tb = __builtin_amdgcn_readlane(p_cur, 0), te = __builtin_amdgcn_readlane(p_cur, 16);
-        int buf = 0;
-        {
-            T ev[2][VW]; int ec[2];
-            fetch(tb, te, 0, ev, ec);
-            stage(0, min(kRmCap, te - tb), ev, ec);
-        }
-        while (true) {
-            const bool has_n = s_n < se;
-            int tbn = 0, ten = 0;
-            T evn[2][VW]; int ecn[2];
-            if (has_n) {                      // next strip's entries: on their way while this strip is multiplied
-                tbn = __builtin_amdgcn_readlane(p_nxt, 0);
-                ten = __builtin_amdgcn_readlane(p_nxt, 16);
-                fetch(tbn, ten, 0, evn, ecn);
-            }
-            const int s_nn = s_n + W;
-            const int p_nn = s_nn < se ? load_ptr(s_nn) : 0;
-
-            // ------------------------------------------------------------------ strip s
-            const int rowbase = s * 16, cnt_total = te - tb;
-            // local row of accumulator slot i: f64 (4x4x4): 4 i + (l >> 4); f32 (16x16x4): 4 (l >> 4) + i
-            auto lrow = [&](int i) -> int { return F64 ? 4 * i + kq : 4 * kq + i; };
-            RV xo[4];
-            if (FUSE_DOT) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = min(rowbase + lrow(i), a.n - 1);
-                    xo[i] = ld_rowvec<T, NH>(a.x + (long long)row * RC + NH * m);
-                }
-            }
-            // row bounds relative to tb.  f32: lane's A-row is m; f64: quad q's A-row is 4q + (l & 3)
-            int s_r[F64 ? 4 : 1], e_r[F64 ? 4 : 1], qs[4], qe[4];
-            if constexpr (F64) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    s_r[q] = __shfl(p_cur, 4 * q + (lane & 3), 64) - tb;
-                    e_r[q] = __shfl(p_cur, 4 * q + (lane & 3) + 1, 64) - tb;
-                    qs[q] = __builtin_amdgcn_readlane(p_cur, 4 * q) - tb;
-                    qe[q] = __builtin_amdgcn_readlane(p_cur, 4 * q + 4) - tb;
-                }
-            } else {
-                s_r[0] = __shfl(p_cur, m, 64) - tb;
-                e_r[0] = __shfl(p_cur, m + 1, 64) - tb;
-            }
-            f32x4 acc16[F64 ? 1 : NH];
-            double acc4[F64 ? 4 : 1][NH];
-            if constexpr (F64) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) acc4[q][h] = 0.;
-            } else {
-#pragma unroll
-                for (int h = 0; h < NH; ++h) acc16[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-
-            for (int r0 = 0; r0 < cnt_total; r0 += kRmCap) {          // rounds (one for <= 8 non-zeros per row)
-                if (r0 > 0) {
-                    T ev[2][VW]; int ec[2];
-                    fetch(tb, te, r0, ev, ec);
-                    stage(buf, min(kRmCap, cnt_total - r0), ev, ec);
-                }
-                const int cnt = min(kRmCap, cnt_total - r0);
-                const int steps = (cnt + 3) >> 2, nb = (steps + UB - 1) / UB, per = (steps + nb - 1) / nb;
-                for (int b = 0; b < nb; ++b) {
-                    const int k0 = b * per, nst = min(per, steps - k0);
-                    RV bv[UB];
-                    // all gathers of the batch are issued back to back, branch-free (slots past the batch re-read its
-                    // last entry: an L1 hit, never consumed)
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        const int jl = min(4 * (k0 + min(u, nst - 1)) + kq, cnt - 1);
-                        const int c = sc[wave][buf][jl];
-                        bv[u] = ld_rowvec<T, NH>(a.x + (long long)c * RC + NH * m);
-                    }
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        if (u < nst) {                                 // wave-uniform
-                            const int jl0 = 4 * (k0 + u), jl = jl0 + kq, jlc = min(jl, cnt - 1), jr = r0 + jl;
-                            const bool live = jl < cnt;
-                            if constexpr (F64) {
-                                const double v = sv[wave][buf][jlc];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    if (r0 + jl0 < qe[q] && r0 + jl0 + 4 > qs[q]) {      // K-step touches quad q (wave-uniform)
-                                        const double av = (live && jr >= s_r[q] && jr < e_r[q]) ? v : 0.;
-#pragma unroll
-                                        for (int h = 0; h < NH; ++h) acc4[q][h] = mfma_f64_4(av, bv[u].v[h], acc4[q][h]);
-                                    }
-                                }
-                            } else {
-                                const bool mine = live && jr >= s_r[0] && jr < e_r[0];
-                                if constexpr (CPLX) {
-                                    const float vr = sv[wave][buf][2 * jlc], vi = sv[wave][buf][2 * jlc + 1];
-                                    const float ar = mine ? vr : 0.f, ai = mine ? vi : 0.f;
-#pragma unroll
-                                    for (int h = 0; h < NH; ++h) {
-                                        acc16[h] = mfma_f32_16(ar, bv[u].v[h], acc16[h]);
-                                        // (ar + i ai)(xr + i xi): the re column gets -ai xi, the im column +ai xr (cmplx.h:20-25)
-                                        const float xs = (h & 1) ? bv[u].v[h - 1] : -bv[u].v[h + 1];
-                                        acc16[h] = mfma_f32_16(ai, xs, acc16[h]);
-                                    }
-                                } else {
-                                    const float av = mine ? sv[wave][buf][jlc] : 0.f;
-#pragma unroll
-                                    for (int h = 0; h < NH; ++h) acc16[h] = mfma_f32_16(av, bv[u].v[h], acc16[h]);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            // ---- store the strip: every store instruction of the wave covers 4 whole rows of Y
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = rowbase + lrow(i);
-                RV out;
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    if constexpr (F64) out.v[h] = acc4[i][h];
-                    else out.v[h] = acc16[h][i];
-                }
-                if (row < a.n) {
-                    st_rowvec<YNT, T, NH>(a.y + (long long)row * RC + NH * m, out);
-                    if (FUSE_DOT) {
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) {
-                            dsum[h] += (double)(xo[i].v[h] * out.v[h]);
-                            if constexpr (CPLX) dcross[h] += (double)(xo[i].v[h] * out.v[h ^ 1]);
-                        }
-                    }
-                }
-            }
-            // ------------------------------------------------------------------ install the next strip
-            if (!has_n) break;
-            stage(buf ^ 1, min(kRmCap, ten - tbn), evn, ecn);
-            buf ^= 1;
-            p_cur = p_nxt; p_nxt = p_nn;
-            tb = tbn; te = ten;
-            s = s_n; s_n = s_nn;
-        }
-    }
-    if (FUSE_DOT) {
-        // per-lane column sums -> per-wave (lanes with equal m) -> per work-group, fixed order
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            dsum[h] += __shfl_xor(dsum[h], 16, 64);
-            dsum[h] += __shfl_xor(dsum[h], 32, 64);
-            if constexpr (CPLX) {
-                dcross[h] += __shfl_xor(dcross[h], 16, 64);
-                dcross[h] += __shfl_xor(dcross[h], 32, 64);
-            }
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                red[wave][NH * m + h] = dsum[h];
-                red[wave][RC + NH * m + h] = dcross[h];
-            }
-        }
-        __syncthreads();
-        if constexpr (CPLX) {
-            if (t < RC / 2) {
-                auto tot = [&](int c) { return ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]; };
-                const double re = tot(2 * t) - tot(2 * t + 1);                     // unconjugated (complex/vdot.cl:15)
-                const double im = tot(RC + 2 * t) + tot(RC + 2 * t + 1);
-                double *p = a.partials + 2 * ((long long)t * a.nwg + blockIdx.x);
-                p[0] = re; p[1] = im;
-            }
-        } else {
-            if (t < RC) a.partials[(long long)t * a.nwg + blockIdx.x] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
-        }
-    }
-}
-
 // -------------------------------------------------------------------------------------------------
-// fp64 form: v_mfma_f64_4x4x4_4b, software-pipelined across strips.
+// The SpMM kernel: T = double (v_mfma_f64_4x4x4_4b) or float (v_mfma_f32_16x16x4; CPLX: values and the X / Y columns are
+// (re, im) pairs), NH = real columns / 16, software-pipelined across strips.
 // A strip's 16 rows are 4 QUADS of 4 rows.  A quad's non-zeros are staged QUAD-ALIGNED in the wave's LDS area: quad q owns
 // slots [q QS, (q+1) QS), QS = 4 TQ, so a K-step (4 consecutive slots) never straddles two quads and every LDS address of
-// the multiply phase is "static offset + lane part".  The A operand is staged already selected: sval[i][slot] holds the
-// value if the slot's non-zero lies in row i of its quad, else 0 (tail slots of a quad's last K-step: 0 in all four), so
-// a lane's operand for MFMA (q, t) is ONE ds_read_b64 of sval[l & 3][q QS + 4t + (l >> 4)] -- no compares, no selects.
-// (The first version tested row ranges per K-step and quad in the multiply loop: 80 guarded blocks per strip, ~2 us of
-// issue per strip and wave, 187 us per SpMM.)  TQ = K-steps per quad and round, a template parameter chosen from the
+// the multiply phase is "static offset + lane part".
+//   fp64: the A operand is staged already selected: sval[i][slot] holds the value if the slot's non-zero lies in row i of
+//         its quad, else 0 (tail slots: 0 in all four), so a lane's operand for MFMA (q, u) is ONE ds_read_b64 of
+//         sval[l & 3][q QS + 4u + (l >> 4)] -- no compares, no selects; every quad has its own 4x4x4 accumulators.
+//   fp32: the tile is the whole strip (16 rows); each slot is staged as (value[, imaginary part], row of the strip) and the
+//         lane keeps the value when that row is its A-row (one compare + select per K-step; tail slots carry row 255).
+// (The first version tested row RANGES per K-step and quad in the multiply loop: 80 guarded blocks per strip, ~2 us of
+// issue per strip and wave, 187 us per fp64 SpMM.)  TQ = K-steps per quad and round, a template parameter chosen from the
 // matrix (5: <= 20 non-zeros per 4 rows, the 5-point stencil; 8: anything, longer quads take more rounds).
 // Pipeline per wave, strip k current:   stage(k+1) -> fetch entries(k+2), pointers(k+3) -> gathers(k+1) -> multiply(k)
 // -> store(k): the gathers of two strips are in flight, and nothing a strip waits for is younger (vmcnt is in order) than
-// the loads it does not need yet.  (Tried and dropped: touching the next-but-one strip's new X rows with one dword load per
-// cache line a step early -- 122 -> 149 us and +33 % read traffic; profiles/r2_experiments/spmm_ab8.log.)  Strips past the wave's last alias it (redundant, discarded) so the loop is branch-free.
+// the loads it does not need yet.  Strips past the wave's last alias it (redundant, discarded) so the loop is branch-free.
+// (Tried and dropped: touching the next-but-one strip's new X rows with one dword load per cache line a step early --
+// 122 -> 149 us and +33 % read traffic; profiles/r2_experiments/spmm_ab8.log.)
 // -------------------------------------------------------------------------------------------------
-template <int NH, int TQ, int NQ, bool FUSE_DOT>
-__global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmRmArgs<double> a) {
-    // NQ quads = 4 NQ rows per strip (a.strips counts strips of that height).  Two strips' gathers in flight need
-    // 2 x NQ TQ x 2 NH registers; where that exceeds the budget the instance keeps one strip in flight (PIPE = false)
-    constexpr bool PIPE = NH * TQ * NQ <= 40;
-    constexpr int ROWS = 4 * NQ, RC = 16 * NH, QS = 4 * TQ, SLOTS = NQ * QS, EPL = (SLOTS + 63) / 64, VS = SLOTS + 4;   // VS: bank-conflict-free row stride
-    using RV = RowVec<double, NH>;
+template <typename T, int NH, int TQ, int NQ, bool CPLX>
+struct RmGeom {
+    static constexpr bool F64 = sizeof(T) == 8;
+    static constexpr int BV = NQ * TQ * NH * (int)sizeof(T) / 4;      // registers holding one strip's gathers
+    static constexpr bool PIPE = BV <= 80;                            // two strips in flight fit 256 VGPRs
+    static constexpr int WAVES = (PIPE ? 2 * BV : BV) <= 64 ? 4 : 2;  // waves per SIMD the instance is built for
+};
+
+template <typename T, int NH, int TQ, int NQ, bool CPLX, bool FUSE_DOT>
+__global__ __launch_bounds__(256, (RmGeom<T, NH, TQ, NQ, CPLX>::WAVES)) void spmm_rm_kernel(SpmmRmArgs<T> a) {
+    using G = RmGeom<T, NH, TQ, NQ, CPLX>;
+    constexpr bool F64 = G::F64, PIPE = G::PIPE;
+    static_assert(!(F64 && CPLX), "complex128 runs the RHS-major kernel");
+    static_assert(F64 || NQ == 4, "the fp32 tile is the 16-row strip");
+    static_assert(!CPLX || NH % 2 == 0, "a lane must hold whole (re, im) pairs");
+    constexpr int ROWS = 4 * NQ, RC = 16 * NH, QS = 4 * TQ, SLOTS = NQ * QS, EPL = (SLOTS + 63) / 64;
+    constexpr int VW = CPLX ? 2 : 1;                        // value words per entry
+    constexpr int VS = SLOTS + 4;                           // fp64: bank-conflict-free stride between the 4 operand copies
+    constexpr int SW = CPLX ? 4 : 2;                        // fp32: words per staged slot (value[, imag], row[, pad])
+    constexpr int LDSV = F64 ? 4 * VS * 2 : SLOTS * SW;     // 32-bit words of the value area per wave and buffer
+    using RV = RowVec<T, NH>;
     __shared__ int scol[4][2][SLOTS];
-    __shared__ double sval[4][2][4 * VS];
-    __shared__ double red[4][RC];
+    __shared__ __attribute__((aligned(16))) unsigned sraw[4][2][LDSV];
+    __shared__ double red[4][2 * RC];
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 15, kq = lane >> 4;
     const int xcd = blockIdx.x & 7, W = ((int)gridDim.x >> 3) * 4, wl = ((int)blockIdx.x >> 3) * 4 + wave;
     const int sb = (int)((long long)xcd * a.strips / 8), se = (int)((long long)(xcd + 1) * a.strips / 8);
 
-    double dsum[NH];
+    double dsum[NH], dcross[CPLX ? NH : 1];
 #pragma unroll
     for (int h = 0; h < NH; ++h) dsum[h] = 0.;
+#pragma unroll
+    for (int h = 0; h < (CPLX ? NH : 1); ++h) dcross[h] = 0.;
 
     auto load_ptr = [&](int s) -> int {
         const int row = s * ROWS + (lane < ROWS ? lane : ROWS);
@@ -365,7 +151,7 @@ __global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmR
         for (int k = 1; k < NQ; ++k) { Qq = q == k ? g.Q[k] : Qq; Qn = q == k ? g.Q[k + 1] : Qn; }
         return Qq + r + (idx - q * QS);
     };
-    auto fetch = [&](int p, int r, double (&ev)[EPL], int (&ec)[EPL]) {
+    auto fetch = [&](int p, int r, T (&ev)[EPL][VW], int (&ec)[EPL]) {
         const Quads g = quads(p);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -373,11 +159,16 @@ __global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmR
             const int idx = e * 64 + lane, j = slot_entry(g, idx, r, q, Qq, Qn);
             if (idx < SLOTS && j < Qn) {
                 ec[e] = __builtin_nontemporal_load(a.cols + (long long)g.tb + j);
-                ev[e] = __builtin_nontemporal_load(a.vals + (long long)g.tb + j);
+                if constexpr (CPLX) {
+                    const f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(a.vals) + (long long)g.tb + j);
+                    ev[e][0] = w.x; ev[e][1] = w.y;
+                } else {
+                    ev[e][0] = __builtin_nontemporal_load(a.vals + (long long)g.tb + j);
+                }
             }
         }
     };
-    auto stage = [&](int buf, int p, int r, int safe_col, const double (&ev)[EPL], const int (&ec)[EPL]) {
+    auto stage = [&](int buf, int p, int r, int safe_col, const T (&ev)[EPL][VW], const int (&ec)[EPL]) {
         const Quads g = quads(p);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -390,8 +181,16 @@ __global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmR
                 const bool live = j < Qn;
                 const int ri = live ? (j >= R1) + (j >= R2) + (j >= R3) : -1;
                 scol[wave][buf][idx] = live ? ec[e] : safe_col;
+                if constexpr (F64) {
+                    double *sv = reinterpret_cast<double *>(sraw[wave][buf]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sval[wave][buf][k * VS + idx] = (k == ri) ? ev[e] : 0.;
+                    for (int k = 0; k < 4; ++k) sv[k * VS + idx] = (k == ri) ? ev[e][0] : 0.;
+                } else {
+                    unsigned *sv = sraw[wave][buf] + idx * SW;
+#pragma unroll
+                    for (int w = 0; w < VW; ++w) sv[w] = live ? __float_as_uint(ev[e][w]) : 0u;
+                    sv[VW] = live ? (unsigned)(4 * q + ri) : 255u;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // one wave's LDS ops execute in order; compiler ordering only
@@ -399,40 +198,71 @@ __global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmR
     auto steps_of = [&](const Quads &g, int q, int r) -> int {      // K-steps of quad q in round r (uniform)
         return min(max((g.Q[q + 1] - g.Q[q] - r + 3) >> 2, 0), TQ);
     };
-    // the gathers of one round: NQ TQ loads of NH doubles per lane, each instruction = 4 whole X rows.  Branch-free, LDS
+    // the gathers of one round: NQ TQ loads of NH values per lane, each instruction = 4 whole X rows.  Branch-free, LDS
     // offsets are immediates (slots past a quad's last K-step hold `safe_col`: an L1 hit that the multiply never consumes),
     // addresses are uniform base + 32-bit byte offset (the launcher guarantees the block is < 4 GiB)
-    const char *xbase = reinterpret_cast<const char *>(a.x) + NH * m * sizeof(double);
+    const char *xbase = reinterpret_cast<const char *>(a.x) + NH * m * sizeof(T);
     auto issue = [&](int buf, RV (&bv)[NQ][TQ]) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
 #pragma unroll
             for (int u = 0; u < TQ; ++u) {
                 const unsigned c = (unsigned)scol[wave][buf][q * QS + 4 * u + kq];
-                bv[q][u] = *reinterpret_cast<const RV *>(xbase + (size_t)(c * (unsigned)(RC * sizeof(double))));
+                bv[q][u] = *reinterpret_cast<const RV *>(xbase + (size_t)(c * (unsigned)(RC * sizeof(T))));
             }
         }
     };
-    // K-step u of all quads before K-step u + 1: consecutive MFMAs go to NQ NH different accumulators, so none waits
+    // accumulators of one strip: fp64 one per quad and column group (4x4x4 blocks), fp32 one 16x16 tile per column group
+    struct Acc {
+        double d[F64 ? NQ : 1][NH];
+        f32x4 f[F64 ? 1 : NH];
+    };
+    // fp64: K-step u of all quads before K-step u + 1: consecutive MFMAs go to NQ NH different accumulators, so none waits
     // for its predecessor's result (with the quad loop outside, each accumulator chain stalled the next issue:
-    // SQ_WAIT_INST_ANY 38 % of the wave cycles)
-    auto multiply = [&](int buf, int p, int r, const RV (&bv)[NQ][TQ], double (&acc)[NQ][NH]) {
+    // SQ_WAIT_INST_ANY 38 % of the wave cycles).  fp32: consecutive MFMAs alternate between the NH tiles.
+    auto multiply = [&](int buf, int p, int r, const RV (&bv)[NQ][TQ], Acc &acc) {
         const Quads g = quads(p);
         int st[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) st[q] = steps_of(g, q, r);
 #pragma unroll
         for (int u = 0; u < TQ; ++u) {
-            double av[NQ];
+            if constexpr (F64) {
+                const double *sv = reinterpret_cast<const double *>(sraw[wave][buf]);
+                double av[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) av[q] = sval[wave][buf][(lane & 3) * VS + q * QS + 4 * u + kq];
+                for (int q = 0; q < NQ; ++q) av[q] = sv[(lane & 3) * VS + q * QS + 4 * u + kq];
 #pragma unroll
-            for (int h = 0; h < NH; ++h)
+                for (int h = 0; h < NH; ++h)
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    if (u < st[q]) acc[q][h] = mfma_f64_4(av[q], bv[q][u].v[h], acc[q][h]);     // wave-uniform guard
+                    for (int q = 0; q < NQ; ++q)
+                        if (u < st[q]) acc.d[q][h] = mfma_f64_4(av[q], bv[q][u].v[h], acc.d[q][h]);     // wave-uniform guard
+            } else {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (u < st[q]) {                                                                     // wave-uniform guard
+                        const unsigned *sv = sraw[wave][buf] + (q * QS + 4 * u + kq) * SW;
+                        const bool mine = (int)sv[VW] == m;
+                        const float ar = mine ? __uint_as_float(sv[0]) : 0.f;
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) acc.f[h] = mfma_f32_16(ar, bv[q][u].v[h], acc.f[h]);
+                        if constexpr (CPLX) {
+                            // (ar + i ai)(xr + i xi): the re column gets -ai xi, the im column +ai xr (cmplx.h:20-25)
+                            const float ai = mine ? __uint_as_float(sv[1]) : 0.f;
+#pragma unroll
+                            for (int h = 0; h < NH; ++h) {
+                                const float xs = (h & 1) ? bv[q][u].v[h - 1] : -bv[q][u].v[h + 1];
+                                acc.f[h] = mfma_f32_16(ai, xs, acc.f[h]);
+                            }
+                        }
+                    }
+                }
+            }
         }
     };
+    // local row of output slot i (i = 0..3) of this lane: fp64 D[b][i][j] @ 16 i + 4 b + j -> quad i, row l >> 4;
+    // fp32 16x16 tile: row 4 (l >> 4) + i
+    auto lrow = [&](int i) -> int { return F64 ? 4 * i + kq : 4 * kq + i; };
 
     const int s0 = sb + wl;
     if (s0 < se) {
@@ -440,10 +270,10 @@ __global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmR
         int s_cur = s0, s_nxt = s0 + W, s_nn = s0 + 2 * W;
         int p_cur = load_ptr(s_cur), p_nxt = load_ptr(clampS(s_nxt)), p_nn = load_ptr(clampS(s_nn));
         int buf = 0;
-        double evN[EPL]; int ecN[EPL];                           // entries of the next strip, fetched one step ahead
+        T evN[EPL][VW]; int ecN[EPL];                           // entries of the next strip, fetched one step ahead
         RV bvA[NQ][TQ], bvB[PIPE ? NQ : 1][PIPE ? TQ : 1];
         {
-            double ev[EPL]; int ec[EPL];
+            T ev[EPL][VW]; int ec[EPL];
             fetch(p_cur, 0, ev, ec);
             stage(0, p_cur, 0, min(s_cur * ROWS, a.n - 1), ev, ec);
         }
@@ -453,11 +283,11 @@ __global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmR
         // one pipeline step: strip s_cur is multiplied out of bvC while the next strip's gathers go into bvN
         auto step = [&](RV (&bvC)[NQ][TQ], auto &bvN) -> bool {
             const int rowbase = s_cur * ROWS;
-            RV xo[NQ];
+            RV xo[F64 ? NQ : 4];
             if (FUSE_DOT) {
 #pragma unroll
-                for (int i = 0; i < NQ; ++i)
-                    xo[i] = *reinterpret_cast<const RV *>(xbase + (size_t)((unsigned)min(rowbase + 4 * i + kq, a.n - 1) * (unsigned)(RC * sizeof(double))));
+                for (int i = 0; i < (F64 ? NQ : 4); ++i)
+                    xo[i] = *reinterpret_cast<const RV *>(xbase + (size_t)((unsigned)min(rowbase + lrow(i), a.n - 1) * (unsigned)(RC * sizeof(T))));
             }
             if constexpr (!PIPE) issue(buf, bvC);
             stage(buf ^ 1, p_nxt, 0, min(clampS(s_nxt) * ROWS, a.n - 1), evN, ecN);
@@ -465,11 +295,16 @@ __global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmR
             fetch(p_nn, 0, evN, ecN);
             if constexpr (PIPE) issue(buf ^ 1, bvN);
 
-            double acc[NQ][NH];
+            Acc acc;
+            if constexpr (F64) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int h = 0; h < NH; ++h) acc[q][h] = 0.;
+                    for (int h = 0; h < NH; ++h) acc.d[q][h] = 0.;
+            } else {
+#pragma unroll
+                for (int h = 0; h < NH; ++h) acc.f[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             multiply(buf, p_cur, 0, bvC, acc);
             {   // quads longer than one round (more than 4 TQ non-zeros in 4 rows): further rounds, not pipelined
                 const Quads g = quads(p_cur);
@@ -477,27 +312,33 @@ __global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmR
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) maxlen = max(maxlen, g.Q[q + 1] - g.Q[q]);
                 for (int r = QS; r < maxlen; r += QS) {
-                    double ev[EPL]; int ec[EPL];
+                    T ev[EPL][VW]; int ec[EPL];
                     fetch(p_cur, r, ev, ec);
                     stage(buf, p_cur, r, min(rowbase, a.n - 1), ev, ec);
                     issue(buf, bvC);
                     multiply(buf, p_cur, r, bvC, acc);
                 }
             }
-            // store: lane (i = l >> 4 in D) holds row 4q + (l >> 4), columns NH m .. NH m + NH - 1: 4 whole rows per instruction
+            // store: every store instruction of the wave covers 4 whole rows of Y
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int row = rowbase + 4 * q + kq;
+            for (int i = 0; i < (F64 ? NQ : 4); ++i) {
+                const int row = rowbase + lrow(i);
                 RV out;
 #pragma unroll
-                for (int h = 0; h < NH; ++h) out.v[h] = acc[q][h];
+                for (int h = 0; h < NH; ++h) {
+                    if constexpr (F64) out.v[h] = acc.d[i][h];
+                    else out.v[h] = acc.f[h][i];
+                }
                 if (row < a.n) {
-                    char *yp = reinterpret_cast<char *>(a.y) + NH * m * sizeof(double) + (size_t)((unsigned)row * (unsigned)(RC * sizeof(double)));
-                    if constexpr (NH == 2) st16_policy(yp, &out, a.ynt);     // wave-uniform policy
+                    char *yp = reinterpret_cast<char *>(a.y) + NH * m * sizeof(T) + (size_t)((unsigned)row * (unsigned)(RC * sizeof(T)));
+                    if constexpr (sizeof(RV) == 16) st16_policy(yp, &out, a.ynt);     // wave-uniform policy
                     else *reinterpret_cast<RV *>(yp) = out;
                     if (FUSE_DOT) {
 #pragma unroll
-                        for (int h = 0; h < NH; ++h) dsum[h] += xo[q].v[h] * out.v[h];
+                        for (int h = 0; h < NH; ++h) {
+                            dsum[h] += (double)(xo[i].v[h] * out.v[h]);
+                            if constexpr (CPLX) dcross[h] += (double)(xo[i].v[h] * out.v[h ^ 1]);
+                        }
                     }
                 }
             }
@@ -517,17 +358,35 @@ __global__ __launch_bounds__(256, NQ == 2 ? 4 : 2) void spmm_rm_f64_kernel(SpmmR
         }
     }
     if (FUSE_DOT) {
+        // per-lane column sums -> per-wave (lanes with equal m) -> per work-group, fixed order
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             dsum[h] += __shfl_xor(dsum[h], 16, 64);
             dsum[h] += __shfl_xor(dsum[h], 32, 64);
+            if constexpr (CPLX) {
+                dcross[h] += __shfl_xor(dcross[h], 16, 64);
+                dcross[h] += __shfl_xor(dcross[h], 32, 64);
+            }
         }
         if (lane < 16) {
 #pragma unroll
-            for (int h = 0; h < NH; ++h) red[wave][NH * m + h] = dsum[h];
+            for (int h = 0; h < NH; ++h) {
+                red[wave][NH * m + h] = dsum[h];
+                if constexpr (CPLX) red[wave][RC + NH * m + h] = dcross[h];
+            }
         }
         __syncthreads();
-        if (t < RC) a.partials[(long long)t * a.nwg + blockIdx.x] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+        auto tot = [&](int c) { return ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]; };
+        if constexpr (CPLX) {
+            if (t < RC / 2) {
+                const double re = tot(2 * t) - tot(2 * t + 1);                     // unconjugated (complex/vdot.cl:15)
+                const double im = tot(RC + 2 * t) + tot(RC + 2 * t + 1);
+                double *p = a.partials + 2 * ((long long)t * a.nwg + blockIdx.x);
+                p[0] = re; p[1] = im;
+            }
+        } else {
+            if (t < RC) a.partials[(long long)t * a.nwg + blockIdx.x] = tot(t);
+        }
     }
 }
 
@@ -583,7 +442,7 @@ __global__ __launch_bounds__(BLOCK) void rm_dot_kernel(long long total, int R, c
 }
 
 // r -= alpha[c] q ; partials of r.r per column      (reference axpy.cl with aSign = 0 + vdot.cl; clcg.c:345-374)
-template <typename T, int BLOCK>
+template <typename T, int BLOCK, bool NT>
 __global__ __launch_bounds__(BLOCK) void rm_axpy_dot_kernel(long long total, int R, const T *__restrict__ q, T *__restrict__ rv,
                                                              const T *__restrict__ alpha, typename VT<T>::acc *__restrict__ partials) {
     using A = typename VT<T>::acc;
@@ -596,7 +455,7 @@ __global__ __launch_bounds__(BLOCK) void rm_axpy_dot_kernel(long long total, int
     for (int k = 0; k < E; ++k) { al[k] = alpha[c0 + k]; acc[k] = vzero<A>(); }
     const long long npack = total / E, stride = (long long)gridDim.x * BLOCK;
     for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < npack; i += stride) {
-        const Pack<T> pq = ld_pack(q + i * E);
+        const Pack<T> pq = NT ? ld_pack_nt(q + i * E) : ld_pack(q + i * E);      // q: last use of the iteration
         Pack<T> pr = ld_pack(rv + i * E);
 #pragma unroll
         for (int k = 0; k < E; ++k) {
@@ -609,7 +468,7 @@ __global__ __launch_bounds__(BLOCK) void rm_axpy_dot_kernel(long long total, int
 }
 
 // x += alpha[c] d ; d = beta[c] d + r                (axpy.cl with aSign = 1, aypx.cl; clcg.c:338-342,415)
-template <typename T, int BLOCK>
+template <typename T, int BLOCK, bool NT>
 __global__ __launch_bounds__(BLOCK) void rm_aypx_x_kernel(long long total, int R, const T *__restrict__ rv, T *__restrict__ d,
                                                            T *__restrict__ xs, const T *__restrict__ alpha, const T *__restrict__ beta) {
     constexpr int E = Pack<T>::N;
@@ -620,13 +479,13 @@ __global__ __launch_bounds__(BLOCK) void rm_aypx_x_kernel(long long total, int R
     const long long npack = total / E, stride = (long long)gridDim.x * BLOCK;
     for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < npack; i += stride) {
         const Pack<T> pr = ld_pack(rv + i * E);
-        Pack<T> pd = ld_pack(d + i * E), px = ld_pack(xs + i * E);
+        Pack<T> pd = ld_pack(d + i * E), px = NT ? ld_pack_nt(xs + i * E) : ld_pack(xs + i * E);   // x: touched once per iteration
 #pragma unroll
         for (int k = 0; k < E; ++k) {
             px.v[k] = vadd(px.v[k], vmul(al[k], pd.v[k]));
-            pd.v[k] = vadd(vmul(bt[k], pd.v[k]), pr.v[k]);
+            pd.v[k] = vaypx(bt[k], pd.v[k], pr.v[k]);
         }
-        st_pack(xs + i * E, px);
+        if (NT) st_pack_nt(xs + i * E, px); else st_pack(xs + i * E, px);
         st_pack(d + i * E, pd);
     }
 }
@@ -652,28 +511,26 @@ bool spmm_rm_supported(int dtype, int nrhs, int n) {
     return rm_real_columns(dtype, nrhs) != 0 && (unsigned long long)n * nrhs * dtype_size(dtype) < (1ULL << 32);
 }
 
-// Work-groups of the sweep (a multiple of 8; 4 waves each).  The sweep only keeps its locality if every work-group of the
-// grid is resident from the start (a queued work-group would run its interleaved strips after the others have moved on),
-// so the grid is the instance's resident capacity (occupancy query x 32 CUs per XCD; `spmm_wgs` overrides), never more
-// waves than strips.
-struct RmConfig { int rows, tq, nq, wgs_per_cu; const void *fn; };
 template <typename K> static int rm_blocks_per_cu(K kernel) {
     int per = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 256, 0) != hipSuccess || per < 1) per = 1;
     return per > 8 ? 8 : per;
 }
-// which instance runs (dtype, nrhs, matrix) and how many rows a strip has
-template <int NH> static void rm_f64_instance(int max_quad, bool dot, int *rows, int *per_cu, int *tq, int *nq) {
-    // K-steps per quad and round: 5 when no 4 consecutive rows hold more than 20 non-zeros (5-point stencils), else 8.
-    // 8-row strips (NQ = 2: half the registers, four waves per SIMD) are an experiment knob: in-process A/B at N = 1M x 32
-    // (profiles/r2_experiments/spmm_ab9.log, spmm_ab10.log) 3 % faster than 16-row strips only with 96 of the 128
-    // resident work-groups per XCD, 13 % slower with all of them, and slower inside CG (the fused-dot instance spills)
+// which instance runs: K-steps per quad and round (5 when no 4 consecutive rows hold more than 20 non-zeros -- 5-point
+// stencils --, else 8) and strip height.  8-row strips (fp64 only, NQ = 2: half the registers, four waves per SIMD) are an
+// experiment knob: in-process A/B at N = 1M x 32 (profiles/r2_experiments/spmm_ab9.log, spmm_ab10.log) 3 % faster than
+// 16-row strips only with 96 of the 128 resident work-groups per XCD, 13 % slower with all of them, and slower inside CG.
+struct RmInstance { int tq, nq, rows, per_cu; };
+template <typename T, int NH, bool CPLX> static RmInstance rm_instance(int max_quad, bool dot) {
+    RmInstance r;
     const bool tq5 = max_quad > 0 && max_quad <= 20 && tune().spmm_tq != 8;
-    const bool nq2 = tq5 && tune().spmm_nq == 2;
-    *tq = tq5 ? 5 : 8; *nq = nq2 ? 2 : 4; *rows = 4 * *nq;
-    if (tq5 && nq2) *per_cu = dot ? rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 2, true>) : rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 2, false>);
-    else if (tq5) *per_cu = dot ? rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 4, true>) : rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 5, 4, false>);
-    else *per_cu = dot ? rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 8, 4, true>) : rm_blocks_per_cu(spmm_rm_f64_kernel<NH, 8, 4, false>);
+    const bool nq2 = sizeof(T) == 8 && tq5 && tune().spmm_nq == 2;
+    r.tq = tq5 ? 5 : 8; r.nq = nq2 ? 2 : 4; r.rows = 4 * r.nq;
+#define CG_OCC(TQ, NQ) (dot ? rm_blocks_per_cu(spmm_rm_kernel<T, NH, TQ, NQ, CPLX, true>) : rm_blocks_per_cu(spmm_rm_kernel<T, NH, TQ, NQ, CPLX, false>))
+    if constexpr (sizeof(T) == 8) r.per_cu = nq2 ? CG_OCC(5, 2) : tq5 ? CG_OCC(5, 4) : CG_OCC(8, 4);
+    else r.per_cu = tq5 ? CG_OCC(5, 4) : CG_OCC(8, 4);
+#undef CG_OCC
+    return r;
 }
 static int rm_grid_for(int n, int rows, int per_cu) {
     const int strips = (n + rows - 1) / rows;
@@ -683,13 +540,25 @@ static int rm_grid_for(int n, int rows, int per_cu) {
     if (per_xcd < 1) per_xcd = 1;
     return 8 * per_xcd;
 }
+// dispatch on (dtype, nrhs): F(T, NH, CPLX)
+#define CG_RM_TYPES(dtype, rc, F)                                                                        \
+    do {                                                                                                  \
+        if (dtype == CGAMD_F64) { if (rc == 16) F(double, 1, false); F(double, 2, false); }               \
+        if (dtype == CGAMD_F32) { if (rc == 16) F(float, 1, false); if (rc == 32) F(float, 2, false); F(float, 4, false); } \
+        if (rc == 32) F(float, 2, true);      /* complex64, 16 right-hand sides */                        \
+        F(float, 4, true);                                                                                \
+    } while (0)
+
+// Work-groups of the sweep (a multiple of 8; 4 waves each) = fused-dot partials per RHS.  The sweep only keeps its locality
+// if every work-group of the grid is resident from the start (a queued work-group would run its interleaved strips after
+// the others have moved on), so the grid is the instance's resident capacity (occupancy query x 32 CUs per XCD;
+// `spmm_wgs` overrides), never more waves than strips.
 int spmm_rm_grid(int dtype, int nrhs, int n, int max_quad, bool dot) {
-    int rows = 16, per_cu = 2, tq, nq;
-    if (dtype == CGAMD_F64) {
-        if (nrhs == 16) rm_f64_instance<1>(max_quad, dot, &rows, &per_cu, &tq, &nq);
-        else rm_f64_instance<2>(max_quad, dot, &rows, &per_cu, &tq, &nq);
-    }
-    return rm_grid_for(n, rows, per_cu);
+    const int rc = rm_real_columns(dtype, nrhs);
+    if (!rc) return 8;
+#define CG_GRID(T, NH, C) do { const RmInstance i = rm_instance<T, NH, C>(max_quad, dot); return rm_grid_for(n, i.rows, i.per_cu); } while (0)
+    CG_RM_TYPES(dtype, rc, CG_GRID);
+#undef CG_GRID
 }
 
 template <typename T, int NH, bool CPLX>
@@ -700,29 +569,22 @@ static int spmm_rm_launch(int n, long long nnz, const void *vals, const int *ptr
     a.ynt = tune().spmm_ynt >= 0 ? tune().spmm_ynt : 2;      // Y stores write-through (sc1): the lines do not displace X in L2
     a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
     a.x = static_cast<const T *>(x); a.y = static_cast<T *>(y); a.partials = static_cast<double *>(partials);
-    const dim3 b(256);
-    if constexpr (sizeof(T) == 8) {
-        int rows, per_cu, tq, nq;
-        rm_f64_instance<NH>(max_quad, partials != nullptr, &rows, &per_cu, &tq, &nq);
-        a.strips = (n + rows - 1) / rows;
-        a.nwg = rm_grid_for(n, rows, per_cu);
-        const dim3 g(a.nwg);
-#define CG_F64(TQ, NQ)                                                                                   \
-    do {                                                                                                  \
-        if (partials) hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, TQ, NQ, true>), g, b, 0, st, a);         \
-        else hipLaunchKernelGGL((spmm_rm_f64_kernel<NH, TQ, NQ, false>), g, b, 0, st, a);                 \
+    const RmInstance inst = rm_instance<T, NH, CPLX>(max_quad, partials != nullptr);
+    a.strips = (n + inst.rows - 1) / inst.rows;
+    a.nwg = rm_grid_for(n, inst.rows, inst.per_cu);
+    const dim3 g(a.nwg), b(256);
+#define CG_SPMM(TQ, NQ)                                                                                       \
+    do {                                                                                                       \
+        if (partials) hipLaunchKernelGGL((spmm_rm_kernel<T, NH, TQ, NQ, CPLX, true>), g, b, 0, st, a);         \
+        else hipLaunchKernelGGL((spmm_rm_kernel<T, NH, TQ, NQ, CPLX, false>), g, b, 0, st, a);                 \
     } while (0)
-        if (tq == 5 && nq == 2) CG_F64(5, 2); else if (tq == 5) CG_F64(5, 4); else CG_F64(8, 4);
-#undef CG_F64
-        return rm_check_launch("spmm_rm_f64");
+    if constexpr (sizeof(T) == 8) {
+        if (inst.tq == 5 && inst.nq == 2) CG_SPMM(5, 2); else if (inst.tq == 5) CG_SPMM(5, 4); else CG_SPMM(8, 4);
     } else {
-        a.strips = (n + 15) / 16;
-        a.nwg = rm_grid_for(n, 16, 2);
-        const dim3 g(a.nwg);
-        if (partials) hipLaunchKernelGGL((spmm_rm_mfma_kernel<T, NH, CPLX, true, false>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((spmm_rm_mfma_kernel<T, NH, CPLX, false, false>), g, b, 0, st, a);
-        return rm_check_launch("spmm_rm_mfma");
+        if (inst.tq == 5) CG_SPMM(5, 4); else CG_SPMM(8, 4);
     }
+#undef CG_SPMM
+    return rm_check_launch("spmm_rm");
 }
 
 int launch_spmm_rm(int dtype, int n, long long nnz, const void *vals, const int *ptr, const int *cols, const void *x, void *y,
@@ -732,18 +594,18 @@ int launch_spmm_rm(int dtype, int n, long long nnz, const void *vals, const int 
     if (rc && !spmm_rm_supported(dtype, nrhs, n)) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: the right-hand-side block must be smaller than 4 GiB");
     if (!rc) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: needs f64 with 16 or 32 right-hand sides, f32 with 16, 32 or 64, or complex64 with 16 or 32");
 #define CG_RM(T, NH, C) return spmm_rm_launch<T, NH, C>(n, nnz, vals, ptr, cols, x, y, partials, max_quad, st)
-    if (dtype == CGAMD_F64) { if (rc == 16) CG_RM(double, 1, false); CG_RM(double, 2, false); }
-    if (dtype == CGAMD_F32) { if (rc == 16) CG_RM(float, 1, false); if (rc == 32) CG_RM(float, 2, false); CG_RM(float, 4, false); }
-    if (rc == 32) CG_RM(float, 2, true);      // complex64, 16 right-hand sides
-    CG_RM(float, 4, true);
+    CG_RM_TYPES(dtype, rc, CG_RM);
 #undef CG_RM
 }
 
-// grid of the row-major vector kernels: <= 2048 work-groups, ~4 packs per thread
+// grid of the row-major vector kernels: ~4 packs per thread.  NOT capped at the resident 2048 work-groups like the
+// single-vector kernels: a block of 16-64 right-hand sides is 16-64 vectors long, and with 2048 work-groups every thread
+// walked 16+ packs one after the other (one iteration's loads in flight per thread) -- the RHS-major loop, which launches
+// nRHS x 2048 work-groups, ran its vector part 25 % faster.  One partial per work-group and column: cg_alpha/cg_beta sum them.
 int rm_vec_grid(long long total_elems, int dtype) {
     const long long per_block = (long long)kBlock * (16 / (long long)dtype_size(dtype)) * 4;
     long long g = (total_elems + per_block - 1) / per_block;
-    const long long cap = tune().vec_grid > 0 ? tune().vec_grid : kMaxGrid;
+    const long long cap = tune().vec_grid > 0 ? tune().vec_grid : 16 * kMaxGrid;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
@@ -775,8 +637,12 @@ int launch_rm_dot(int dtype, int n, int nrhs, const void *a, const void *b, void
     CG_RM_DISPATCH(dtype, rm_dot_impl, (long long)n * nrhs, nrhs, a, b, partials, grid, st);
 }
 template <typename T> static int rm_axpy_dot_impl(long long total, int R, const void *q, void *r, const void *alpha, void *partials, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((rm_axpy_dot_kernel<T, kBlock>), dim3(grid), dim3(kBlock), 0, st, total, R, (const T *)q, (T *)r, (const T *)alpha,
-                       (typename VT<T>::acc *)partials);
+    // streaming hints once the block is far beyond the 256 MB Infinity Cache (as the single-vector kernels do: Tuning::vec_nt)
+    const bool nt = tune().vec_nt >= 0 ? (tune().vec_nt & 2) != 0 : (size_t)total * sizeof(T) > ((size_t)96 << 20);
+    if (nt) hipLaunchKernelGGL((rm_axpy_dot_kernel<T, kBlock, true>), dim3(grid), dim3(kBlock), 0, st, total, R, (const T *)q, (T *)r, (const T *)alpha,
+                               (typename VT<T>::acc *)partials);
+    else hipLaunchKernelGGL((rm_axpy_dot_kernel<T, kBlock, false>), dim3(grid), dim3(kBlock), 0, st, total, R, (const T *)q, (T *)r, (const T *)alpha,
+                            (typename VT<T>::acc *)partials);
     return rm_check_launch("rm_axpy_dot");
 }
 int launch_rm_axpy_dot(int dtype, int n, int nrhs, const void *q, void *r, const void *alpha, void *partials, int grid, hipStream_t st) {
@@ -784,8 +650,11 @@ int launch_rm_axpy_dot(int dtype, int n, int nrhs, const void *q, void *r, const
     CG_RM_DISPATCH(dtype, rm_axpy_dot_impl, (long long)n * nrhs, nrhs, q, r, alpha, partials, grid, st);
 }
 template <typename T> static int rm_aypx_x_impl(long long total, int R, const void *r, void *d, void *x, const void *alpha, const void *beta, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((rm_aypx_x_kernel<T, kBlock>), dim3(grid), dim3(kBlock), 0, st, total, R, (const T *)r, (T *)d, (T *)x, (const T *)alpha,
-                       (const T *)beta);
+    const bool nt = tune().vec_nt >= 0 ? (tune().vec_nt & 1) != 0 : (size_t)total * sizeof(T) > ((size_t)96 << 20);
+    if (nt) hipLaunchKernelGGL((rm_aypx_x_kernel<T, kBlock, true>), dim3(grid), dim3(kBlock), 0, st, total, R, (const T *)r, (T *)d, (T *)x, (const T *)alpha,
+                               (const T *)beta);
+    else hipLaunchKernelGGL((rm_aypx_x_kernel<T, kBlock, false>), dim3(grid), dim3(kBlock), 0, st, total, R, (const T *)r, (T *)d, (T *)x, (const T *)alpha,
+                            (const T *)beta);
     return rm_check_launch("rm_aypx_x");
 }
 int launch_rm_aypx_x(int dtype, int n, int nrhs, const void *r, void *d, void *x, const void *alpha, const void *beta, int grid, hipStream_t st) {

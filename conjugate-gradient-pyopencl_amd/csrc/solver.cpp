@@ -208,7 +208,12 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     s->plan = make_spmv_plan(size);
     s->vgrid = vec_grid(size, dtype, nRHS);
     s->defer_x = tune().defer_x != 0;
-    s->rm_ok = nRHS > 1 && tune().spmm_rowmajor != 0 && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS, size);
+    // Row-major block + matrix-core SpMM inside the loop: by default only where the whole iteration is faster than the RHS-major
+    // one (measured in one process at N = 1M, profiles/r2_experiments/spmm_ab12.log: f64 x 32 +8 %; f64 x 16, f32 x 32 equal within
+    // 1 %, complex64 x 16 slower).  spmm_rowmajor = 2 takes it for every supported type, 0 never.
+    const int rm_knob = tune().spmm_rowmajor;
+    const bool rm_wins = dtype == CGAMD_F64 && nRHS == 32;
+    s->rm_ok = nRHS > 1 && (rm_knob >= 2 || (rm_knob == 1 && rm_wins)) && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS, size);
     if (s->rm_ok) s->rm_vgrid = rm_vec_grid((long long)size * nRHS, dtype);
     int rc = CGAMD_OK;
     if (flags & CGAMD_MATRIX_ON_DEVICE) {

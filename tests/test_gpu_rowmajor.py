@@ -81,9 +81,10 @@ def _systems(kind):
                                              (np.float32, "poisson", 32), (np.complex64, "helm", 16), (np.complex64, "helm", 32),
                                              (np.complex64, "poisson", 16)])
 def test_cg_rowmajor_block_matches_oracle_and_rhs_major_loop(pkg, gpu, dtype, kind, nrhs):
-    """the handle keeps 16/32/64 right-hand sides row-major (layout() == 1) and iterates with the matrix-core SpMM; x and
-    the per-RHS residual histories against the oracle (independent CG per RHS with its own alpha/beta, clcg.c:317-333)
-    and against the RHS-major loop of the same library (tuning knob spmm_rowmajor = 0)"""
+    """with the tuning knob spmm_rowmajor = 2 the handle keeps 16/32/64 right-hand sides row-major (layout() == 1) and iterates
+    with the matrix-core SpMM; x and the per-RHS residual histories against the oracle (independent CG per RHS with its own
+    alpha/beta, clcg.c:317-333) and against the RHS-major loop of the same library (spmm_rowmajor = 0).  The default (1)
+    takes the row-major loop only where it is the faster one: fp64 with 32 right-hand sides."""
     ctx, queue, kernels = gpu
     lib = pkg._lib.load()
     ip, ix, da, cplx = _systems(kind)
@@ -111,9 +112,12 @@ def test_cg_rowmajor_block_matches_oracle_and_rhs_major_loop(pkg, gpu, dtype, ki
         finally:
             pkg._lib.check(lib.cgamd_tune(b"spmm_rowmajor", 1))
 
-    x1, h1, lay1 = run(True)
-    x0_, h0, lay0 = run(False)
+    x1, h1, lay1 = run(2)
+    x0_, h0, lay0 = run(0)
     assert lay1 == 1 and lay0 == 0
+    xd, hd, layd = run(1)
+    assert layd == (1 if (np.dtype(dtype) == np.float64 and nrhs == 32) else 0)
+    assert np.array_equal(hd, h1 if layd else h0)
     tol_h, tol_x = (1e-10, 1e-9) if np.dtype(dtype) == np.float64 else (2e-4, 2e-4)
     live = np.abs(ho) > 1e-4 * np.abs(ho[0])          # never compare the converged tail
     assert h1.shape == ho.shape == h0.shape
@@ -135,7 +139,7 @@ def test_rowmajor_handle_falls_back_for_preconditioned_and_unfused_loops(pkg, gp
     ctx, queue, kernels = gpu
     lib = pkg._lib.load()
     ip, ix, da = cg_numpy.poisson2d(20)
-    n, nrhs = 400, 16
+    n, nrhs = 400, 32
     b = np.tile(np.linspace(1, 2, n), nrhs)
     s = pkg.Solver(ctx, n, len(ix), da, ip, ix, nrhs, flags=pkg._lib.UNFUSED)
     s.set_rhs(b, None)
@@ -186,7 +190,11 @@ def test_config4_full_size_spmm_and_cg_against_oracle(pkg, gpu, dtype):
     B = np.concatenate([np.full(n, (r + 1) * 5.0) for r in range(nrhs)]).astype(dtype)
     iters = 6
     xo, ho = cg_oracle.cg(ip, ix, da.astype(wide), B.astype(wide), nrhs=nrhs, n_iterations=iters, mode=cg_oracle.MODE_FAST)
-    s = pkg.Solver(ctx, n, len(ix), da.astype(dtype), ip, ix, nrhs)
+    pkg._lib.check(lib.cgamd_tune(b"spmm_rowmajor", 2))          # complex64 is not row-major by default
+    try:
+        s = pkg.Solver(ctx, n, len(ix), da.astype(dtype), ip, ix, nrhs)
+    finally:
+        pkg._lib.check(lib.cgamd_tune(b"spmm_rowmajor", 1))
     s.set_rhs(B, None)
     assert lib.cgamd_solver_layout(s.handle) == 1
     s.iterate(iters)
