@@ -88,6 +88,7 @@ def load():
         "cgamd_solver_spmv": (ci, [vp, vp, vp, ci]),
         "cgamd_solver_spmm_rowmajor": (ci, [vp, vp, vp, ci]),
         "cgamd_solver_layout": (ci, [vp]),
+        "cgamd_solver_loop_launches": (ci, [vp]),
         "cgamd_transpose": (ci, [vp, ci, ci, ci, vp, vp]),
         "cgamd_solver_spmv_bytes": (ll, [vp]),
         "cgamd_solver_iter_bytes": (ll, [vp, ci]),

@@ -80,6 +80,10 @@ struct Tuning {
     int defer_x = 1;        // fused loop: x += alpha d rides in the aypx launch (10 vector passes per iteration instead of 11)
     int fold_alpha = 1;     // small systems (<= 2048 d.q partials): alpha in the prologue of axpy2_dot, three launches per iteration
     int two_launch = 1;     // ... and beta / d = beta d + r inside the next SpMV launch: two launches per iteration
+    int resident = 1;       // systems of at most 65536 rows whose 1024-row matrix slices fit LDS: all iterations of an iterate() call in
+                            // ONE launch (resident.hip); 0 = never, 2 = always with write-through stores (the cross-XCD form)
+    int resident_min = 8;   // ... for iterate() calls of at least this many iterations
+    int resident_window = 1; // ... staging the column range of a member's rows in LDS once per iteration (0 = per-non-zero gathers)
     int spmm_wide_max = -1; // multi-RHS, RHS-major: largest row_blocks x nRHS for the one-work-group-per-RHS form (-1 = 4096, 0 = never)
     int spmv_slice_kb = 0;  // largest 256-row LDS slice the one-lane-per-row kernel accepts, in KB (0 = kMaxSliceBytes)
     int spmv_chunk_kb = 0;  // chunked row-block kernel: preferred LDS chunk in KB (0 = kChunkBytes); smaller -> more lanes per row
@@ -195,6 +199,26 @@ int launch_rm_dot(int dtype, int n, int nrhs, const void *a, const void *b, void
 int launch_rm_axpy_dot(int dtype, int n, int nrhs, const void *q, void *r, const void *alpha, void *partials, int grid, hipStream_t st);
 int launch_rm_aypx_x(int dtype, int n, int nrhs, const void *r, void *d, void *x, const void *alpha, const void *beta, int grid,
                      hipStream_t st);
+// ---- resident loop (resident.hip): every iteration of an iterate() call of a small system inside ONE launch ---------------
+struct ResidentPlan {
+    int G = 0;          // work-groups (of 1024 rows) per right-hand side
+    int cap = 0;        // LDS entries of the largest 1024-row matrix slice
+    int wcap = 0;       // LDS entries for the per-iteration window of beta d + r (0 = every non-zero gathers from L2)
+    int unroll = 8;     // gathers in flight per row walk round
+    int local = 1;      // a group lives on one XCD (plain stores, sc1 loads); 0: write-through stores (groups wider than an XCD)
+    int lg = 0;         // groups per ticket counter (per XCD when local)
+    int slots = 0;      // group slots the sync words cover
+    size_t lds_bytes = 0, sync_bytes = 0;
+};
+// false = the loop does not apply (size, alignment, LDS, partial-sum structure of the two-launch loop); ptr_host: n + 1 row pointers
+bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const int *ptr_host, ResidentPlan *out);
+// K iterations (number it0 + 1 ... it0 + K) of every right-hand side; state in and out is the two-launch loop's (x, r, d of
+// iteration k in (k & 1 ? d1 : d0), r.r partials, delta / beta / alpha / history / iter), bit for bit.  Synchronises `st`;
+// sync: rp.sync_bytes of device memory.
+int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
+                    void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
+                    int n_cus, hipStream_t st);
+
 // [rows][cols] -> [cols][rows]: RHS-major (the reference ABI) <-> row-major
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);
 

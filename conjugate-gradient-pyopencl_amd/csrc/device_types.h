@@ -99,9 +99,36 @@ CG_DEV double2 acc_div(double2 a, double2 b) {
 }
 
 // ---- cross-lane reductions (wave64) -----------------------------------------
+// wave_sum: the shuffle-down tree  v[l] += v[l + off], off = 32, 16, 8, 4, 2, 1  -- result valid in LANE 0 ONLY -- with the
+// cross-lane moves of gfx950 instead of six ds_bpermute round trips: v_permlane32_swap (lanes 0..31 <- 32..63),
+// v_permlane16_swap (row 0 <- row 1), then DPP row_shl 8 / 4 / 2 / 1 inside row 0.  The pairs added are the tree's, so the
+// sum has the tree's bits (scripts/microbench/wave_sum_probe.hip checks it against __shfl_down); a call must be reached by
+// the whole wave.
+template <int N> CG_DEV double dpp_row_shl(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)b, 0x100 + N, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(b >> 32), 0x100 + N, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+CG_DEV double lanes_plus32(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+CG_DEV double lanes_plus16(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
 CG_DEV double wave_sum(double v) {
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    v += lanes_plus32(v);
+    v += lanes_plus16(v);
+    v += dpp_row_shl<8>(v);
+    v += dpp_row_shl<4>(v);
+    v += dpp_row_shl<2>(v);
+    v += dpp_row_shl<1>(v);
     return v;
 }
 CG_DEV double2 wave_sum(double2 v) {

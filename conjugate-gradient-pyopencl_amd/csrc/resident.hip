@@ -1,0 +1,609 @@
+// Resident CG loop for small systems (gfx950): ALL iterations of an iterate() call inside ONE launch.
+//
+// The reference solves many small systems per time step (one sub-domain per right-hand side: 16k rows x 9 complex64 RHS x
+// 256 iterations, p_h-PY_C-CL.py:1925-1950 -> clcg.c:297-419); at that size an iteration is a handful of microseconds of
+// work behind two kernel launches.  Here a GROUP of G = ceil(n / 1024) work-groups (one per CU) owns one
+// right-hand side for the whole solve:
+//   * member m (512 threads, two rows each) keeps rows [1024 m, 1024 m + 1024) of the matrix in LDS for the whole launch
+//     and its 16-byte packs of x, r and d in registers;
+//   * the recurrence is the two-launch loop's (kernels.hip, spmv_fused_kernel / axpy2_dot_alpha_kernel): beta and
+//     d = beta d + r are recomputed for every gathered column, d ping-pongs between two buffers; only r and d are
+//     exchanged through memory (write + gather), q stays in LDS;
+//   * the two scalar reductions of an iteration are "granule" all-gathers: every partial sum is published as 8-byte
+//     words {tag, 32 payload bits}; a member polls the P words of its group and has barrier and data in one round trip.
+//     Tags count (claim, iteration, phase) within the launch; the words are zeroed before every launch.
+// Bit-identity: per-row accumulation order, the 256-row / 256-pack partial sums (wave tree, then 4 wave sums) and the order
+// the partials are added are those of the two-launch kernels, and the library is built with -ffp-contract=off, so x,
+// the residual history and the device scalars equal the other loops' bit for bit (tests/test_gpu_resident.py).
+//
+// Placement: groups are formed INSIDE the launch from the work-groups that are actually running -- a work-group takes a
+// ticket from the counter of its XCD (s_getreg XCC_ID); tickets [g G, g G + G) are group g of that XCD; the member that
+// draws the last ticket knows the group is complete and claims right-hand sides for it from a global counter until none is
+// left.  Nothing depends on the dispatch order or on a work-group -> XCD mapping.  With all members of a group on ONE XCD
+// (`LOCAL`) that XCD's L2 is the point of coherence: plain stores, L1-bypassing (sc1) loads.  Groups wider than an XCD
+// (`!LOCAL`, G > 32) use write-through (sc1) stores and sc1 loads, the cross-XCD form of MI355X_MICROARCH.md "Valid forms".
+// Every spin is bounded (wall clock); a time-out sets the error word, all work-groups drain and the host reports it.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+
+#include "cgamd_internal.h"
+#include "device_mem.h"
+
+namespace cgamd {
+namespace {
+
+typedef unsigned long long u64;
+constexpr int kResThreads = 512;                // threads per work-group
+constexpr int kResRows = 1024;                  // rows per member: every thread walks two (4 virtual blocks of 256 rows)
+constexpr long long kResSpinTicks = 200000000;  // 2 s of the 100 MHz wall clock
+
+// header words (unsigned), zeroed before every launch
+enum { kHdrTicket = 0 /* [16] */, kHdrNextRhs = 16, kHdrSolved = 17, kHdrError = 18, kHdrWords = 32 };
+// error codes
+enum { kErrClaim = 1, kErrSweep = 2 };
+
+template <typename T> struct ResArgs {
+    int n, nrhs, G, row_blocks, P_rr, npack;
+    int it0, K, history_cap, cap;   // cap: LDS entries reserved for the slice (multiple of 4)
+    int wcap;                       // LDS entries for the window of d / r a member stages per iteration (0 = gather from L2)
+    const T *vals;
+    const int *ptr, *cols;
+    T *x, *r, *d0, *d1;             // RHS-major [nrhs][n]; d of iteration k lives in (k & 1 ? d1 : d0)
+    typename VT<T>::acc *part_rr;   // [nrhs][P_rr]: read when it0 > 0, written by the last iteration
+    T *alpha, *beta, *delta, *history;
+    int *iter;
+    unsigned *hdr;                  // kHdrWords
+    u64 *slot_word;                 // [slots] {claim sequence, rhs}; slot = xcc * lg + group of that XCD
+    u64 *gran;                      // [slots][2][gran_stride] granule words
+    int gran_stride, lg;            // lg: groups per ticket counter (per XCD when LOCAL)
+    long long *prof;                // diagnostics (CGAMD_RESIDENT_PROF=1): phase times of one work-group, s_memtime ticks
+};
+#define RES_STAMP(i)                                                                   \
+    if (a.prof && t == 0 && m == 0 && rhs == 0) {                                        \
+        const long long now__ = clock64();                                               \
+        a.prof[i] += now__ - stamp;                                                      \
+        stamp = now__;                                                                   \
+    }
+
+CG_DEV unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 15u;
+}
+
+// ---- coherent accesses -----------------------------------------------------------------------------------------------
+CG_DEV u64 ld_word(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // sc1: served by L2, never L1
+CG_DEV unsigned ld_word(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool LOCAL> CG_DEV void st_word(u64 *p, u64 v) {
+    // LOCAL: a plain store -- the line stays in this XCD's L2, where every reader of the group looks (asm: the compiler may
+    // neither sink it below the spin that follows nor widen its scope, as it does for a volatile store)
+    if (LOCAL) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+CG_DEV float ld_coh(const float *p) { return __uint_as_float(ld_word(reinterpret_cast<const unsigned *>(p))); }
+CG_DEV double ld_coh(const double *p) { return __longlong_as_double((long long)ld_word(reinterpret_cast<const u64 *>(p))); }
+CG_DEV float2 ld_coh(const float2 *p) {
+    const u64 w = ld_word(reinterpret_cast<const u64 *>(p));
+    return make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+}
+CG_DEV double2 ld_coh(const double2 *p) {
+    return make_double2(ld_coh(reinterpret_cast<const double *>(p)), ld_coh(reinterpret_cast<const double *>(p) + 1));
+}
+template <bool LOCAL, typename T> CG_DEV void st_pack_coh(T *p, const Pack<T> &v) {
+    union { u32x4 raw; Pack<T> v; } u;
+    u.v = v;
+    if (LOCAL) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(u.raw) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(u.raw) : "memory");
+}
+template <typename T> CG_DEV T ld_coh_at(const T *base, unsigned byte_off) {
+    return ld_coh(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off));
+}
+template <typename T> CG_DEV T *at_off(T *base, unsigned byte_off) { return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off); }
+template <typename T> CG_DEV const T *at_off(const T *base, unsigned byte_off) { return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off); }
+template <typename T> CG_DEV Pack<T> ld_pack_coh(const T *p) {      // 16 bytes past L1, as two 8-byte loads
+    union { u64 w[2]; Pack<T> v; } u;
+    u.w[0] = ld_word(reinterpret_cast<const u64 *>(p));
+    u.w[1] = ld_word(reinterpret_cast<const u64 *>(p) + 1);
+    return u.v;
+}
+CG_DEV void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---- granules: a partial sum as 32-bit pieces, each in an 8-byte word under the tag of its phase -----------------------
+template <bool LOCAL> CG_DEV void put_granule(u64 *g, unsigned tag, double v) {
+    const u64 b = (u64)__double_as_longlong(v), t = (u64)tag << 32;
+    st_word<LOCAL>(g, t | (b & 0xffffffffull));
+    st_word<LOCAL>(g + 1, t | (b >> 32));
+}
+template <bool LOCAL> CG_DEV void put_granule(u64 *g, unsigned tag, double2 v) {
+    put_granule<LOCAL>(g, tag, v.x);
+    put_granule<LOCAL>(g + 2, tag, v.y);
+}
+CG_DEV bool get_granule(const u64 *g, unsigned tag, double &v) {
+    const u64 lo = ld_word(g), hi = ld_word(g + 1);
+    v = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
+    return (unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag;
+}
+CG_DEV bool get_granule(const u64 *g, unsigned tag, double2 &v) {
+    const u64 w0 = ld_word(g), w1 = ld_word(g + 1), w2 = ld_word(g + 2), w3 = ld_word(g + 3);      // one round trip
+    v.x = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+    v.y = __longlong_as_double((long long)((w2 & 0xffffffffull) | (w3 << 32)));
+    return (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag && (unsigned)(w2 >> 32) == tag && (unsigned)(w3 >> 32) == tag;
+}
+
+struct ResShared {
+    double2 ws[2 * kResThreads / kWave];   // wave sums of the virtual blocks (real types use .x): [value 0 | value 1][wave]
+    double2 gs[4];                     // wave sums of a group_sum
+    double2 bc;                        // broadcast of a reduced value
+    int ctl[4];
+    int fail;
+    int cmin, cmax;                    // column range of this member's rows
+};
+template <typename A> CG_DEV A &as_acc(double2 &v);
+template <> CG_DEV double &as_acc<double>(double2 &v) { return v.x; }
+template <> CG_DEV double2 &as_acc<double2>(double2 &v) { return v; }
+
+// Sum of P (<= 256) partials in the order of the two-launch kernels' prologues: thread t < 256 holds 0 + p[t], wave tree,
+// then ((w0 + w1) + w2) + w3 (every thread adds the four wave sums itself: one barrier).  `fetch(i, v)` returns false while
+// partial i is not there yet (granules) -- the poll is the barrier between the members; two polls are kept in flight, so a
+// word is seen one L2 trip after it lands, not one and a half.  Called by the whole work-group; false = timed out (error
+// word set).  sh.gs / sh.fail are rewritten only after the next work-group barrier (there is one between any two calls).
+template <typename A, typename F> CG_DEV bool group_sum(int P, ResShared &sh, unsigned *hdr, A &out, F fetch) {
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    if (t < 256) {      // waves 0..3; a wave polls only if it owns partials
+        A v = vzero<A>();
+        if ((t & ~(kWave - 1)) < P) {
+            const bool mine = t < P;
+            const int i = mine ? t : 0;
+            const long long t0 = wall_clock64();
+            A g0 = vzero<A>(), g1 = vzero<A>();
+            bool ok0 = fetch(i, g0), ok1;
+            for (unsigned spins = 0;; ++spins) {
+                ok1 = fetch(i, g1);
+                if (__all(ok0 || !mine)) { v = g0; break; }
+                ok0 = fetch(i, g0);
+                if (__all(ok1 || !mine)) { v = g1; break; }
+                if ((spins & 63) == 63 && (wall_clock64() - t0 > kResSpinTicks || ld_word(hdr + kHdrError) != 0)) {
+                    if (lane == 0) { atomicCAS(hdr + kHdrError, 0u, (unsigned)kErrSweep); sh.fail = 1; }
+                    break;
+                }
+            }
+            v = mine ? vadd(vzero<A>(), v) : vzero<A>();
+        }
+        v = wave_sum(v);
+        if (lane == 0) as_acc<A>(sh.gs[wave]) = v;
+    }
+    __syncthreads();
+    A s = as_acc<A>(sh.gs[0]);
+    s = vadd(s, as_acc<A>(sh.gs[1]));
+    s = vadd(s, as_acc<A>(sh.gs[2]));
+    s = vadd(s, as_acc<A>(sh.gs[3]));
+    out = s;
+    return sh.fail == 0;
+}
+
+// the 256-thread block sums of the two-launch kernels for the virtual blocks of this work-group: thread t holds values of
+// virtual blocks (t >> 8) [v0] and 2 + (t >> 8) [v1]; results valid in the first thread of every 256-thread half
+// (block_sum<256>: own wave sum, then + the 3 following waves' in order).  Every wave waits for its own outstanding stores
+// before the barrier (their acknowledgement overlaps the wave sums): whatever a leader signals afterwards, the
+// work-group's d / r stores have reached L2 (memory, in the write-through form).
+template <typename A> CG_DEV void vblock_sum2(A &v0, A &v1, ResShared &sh) {
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    v0 = wave_sum(v0);
+    v1 = wave_sum(v1);
+    if (lane == 0) { as_acc<A>(sh.ws[wave]) = v0; as_acc<A>(sh.ws[8 + wave]) = v1; }
+    drain_stores();
+    __syncthreads();
+    if ((t & 255) == 0) {
+#pragma unroll
+        for (int i = 1; i < 4; ++i) { v0 = vadd(v0, as_acc<A>(sh.ws[wave + i])); v1 = vadd(v1, as_acc<A>(sh.ws[8 + wave + i])); }
+    }
+}
+
+template <typename T, bool LOCAL, int UNROLL>
+__global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) {
+    using A = typename VT<T>::acc;
+    constexpr int E = Pack<T>::N;                    // 2 or 4 (16-byte value types are not handled here)
+    constexpr int W = sizeof(A) / 4;                 // granule words per partial
+    constexpr int VT_ = kResRows / E;                // threads with a pack (<= kResThreads)
+    static_assert(E >= 2 && VT_ <= kResThreads, "one pack per thread");
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    T *sv = reinterpret_cast<T *>(dyn_smem);
+    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));
+    T *qs = reinterpret_cast<T *>(dyn_smem + (size_t)a.cap * (sizeof(T) + sizeof(int)));
+    T *win = qs + kResRows;
+    __shared__ ResShared sh;
+    const int t = threadIdx.x;
+
+    // ---- group formation
+    if (t == 0) {
+        const unsigned xcc = LOCAL ? xcc_id() : 0u;
+        sh.ctl[0] = (int)xcc;
+        sh.ctl[1] = (int)atomicAdd(a.hdr + kHdrTicket + xcc, 1u);
+        sh.fail = 0;
+        sh.cmin = 0x7fffffff;
+        sh.cmax = 0;
+    }
+    __syncthreads();
+    const int xcc = __builtin_amdgcn_readfirstlane(sh.ctl[0]), ticket = __builtin_amdgcn_readfirstlane(sh.ctl[1]);
+    const int lg = ticket / a.G, m = ticket - lg * a.G;
+    if (lg >= a.lg) return;                          // beyond the groups this launch has words for (several work-groups per CU)
+    const int slot = xcc * a.lg + lg;
+    const bool leader = m == a.G - 1;                // drew the group's last ticket: every member is running
+
+    // ---- my 1024 rows of the matrix -> LDS, once; thread t walks rows t and t + 512 of them
+    const int R0 = m * kResRows;
+    const int p0 = a.ptr[R0], p1 = a.ptr[min(R0 + kResRows, a.n)];
+    const int cfirst = p0 & ~3;
+    int cmin = 0x7fffffff, cmax = 0;
+    for (int i = cfirst + t; i < p1; i += kResThreads) {
+        const int c = a.cols[i];
+        sv[i - cfirst] = a.vals[i];
+        sc[i - cfirst] = c;
+        if (i >= p0) { cmin = min(cmin, c); cmax = max(cmax, c); }
+    }
+    atomicMin(&sh.cmin, cmin);
+    atomicMax(&sh.cmax, cmax);
+    __syncthreads();
+    // Window: the columns my rows reference (and my own rows) lie in [w0, w0 + wlen).  If that range fits the LDS left over,
+    // each iteration stages beta d + r of the WHOLE range once (coalesced loads, one value per entry) and the row walk reads
+    // LDS; otherwise every non-zero gathers d and r from L2 (each entry ~ row-length times per work-group).
+    const int w0 = min(sh.cmin, R0) & ~(E - 1);
+    const int wlen = max(sh.cmax, min(R0 + kResRows, a.n) - 1) - w0 + 1;
+    const bool windowed = wlen <= a.wcap;                      // uniform
+    const int wpacks = (wlen + E - 1) / E;
+    __syncthreads();
+    for (int i = cfirst + t; i < p1; i += kResThreads)         // byte offsets: into the window, or into the global vectors (n <= 65536)
+        sc[i - cfirst] = (windowed ? sc[i - cfirst] - w0 : sc[i - cfirst]) * (int)sizeof(T);
+    int rs[2], re[2];
+    unsigned own_off[2];
+    bool live[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = R0 + t + h * kResThreads, rc = min(row, a.n - 1);
+        live[h] = row < a.n;
+        rs[h] = a.ptr[rc] - cfirst;
+        re[h] = live[h] ? a.ptr[rc + 1] - cfirst : rs[h];
+        own_off[h] = (unsigned)(windowed ? rc - w0 : rc) * (unsigned)sizeof(T);
+    }
+    const int pack = m * VT_ + t;                    // my 16-byte pack of every vector (t < VT_)
+    const bool packer = t < VT_ && pack < a.npack;
+    const unsigned pack_off = (unsigned)pack * 16u;
+    u64 *g_dq = a.gran + (size_t)(slot * 2) * a.gran_stride, *g_rr = g_dq + a.gran_stride;
+    __syncthreads();
+
+    for (unsigned seq = 1;; ++seq) {
+        // ---- which right-hand side: the leader claims, the others wait for its word (or for the end of all solves)
+        if (t == 0) {
+            int rhs = -1;
+            if (leader) {
+                rhs = (int)atomicAdd(a.hdr + kHdrNextRhs, 1u);
+                __hip_atomic_store(a.slot_word + slot, ((u64)seq << 32) | (unsigned)rhs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const long long t0 = wall_clock64();
+                for (unsigned spins = 0;; ++spins) {
+                    const u64 w = ld_word(a.slot_word + slot);
+                    if ((unsigned)(w >> 32) == seq) { rhs = (int)(unsigned)w; break; }
+                    if (ld_word(a.hdr + kHdrSolved) >= (unsigned)a.nrhs) break;           // every solve is done: nothing left for anyone
+                    if ((spins & 63) == 63 && (wall_clock64() - t0 > kResSpinTicks || ld_word(a.hdr + kHdrError) != 0)) {
+                        atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrClaim);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            sh.ctl[2] = rhs;
+        }
+        __syncthreads();
+        const int rhs = __builtin_amdgcn_readfirstlane(sh.ctl[2]);
+        __syncthreads();
+        if (rhs < 0 || rhs >= a.nrhs) return;
+
+        const long long off = (long long)rhs * a.n;
+        T *xr = a.x + off, *rr = a.r + off, *d0r = a.d0 + off, *d1r = a.d1 + off;
+        Pack<T> px, pr, pd;
+        if (packer) {
+            px = ld_pack(at_off(xr, pack_off));
+            pr = ld_pack(at_off(rr, pack_off));
+            pd = ld_pack(at_off((a.it0 & 1) ? d1r : d0r, pack_off));
+        }
+        T dlt = a.delta[rhs];                        // delta of the iteration being run (it0 == 0: delta_0 of set_rhs)
+        const unsigned tag0 = seq << 20;
+
+        long long stamp = clock64();
+        for (int k = 0; k < a.K; ++k) {
+            const int it = a.it0 + k;
+            RES_STAMP(0)
+            // ---- beta from the previous iteration's r.r partials (spmv_fused_kernel's prologue); the poll is barrier 2
+            T bt = vzero<T>();
+            if (it > 0) {
+                A tot;
+                bool ok;
+                if (k == 0) {
+                    const A *p = a.part_rr + (long long)rhs * a.P_rr;
+                    ok = group_sum<A>(a.P_rr, sh, a.hdr, tot, [&](int i, A &v) { v = p[i]; return true; });
+                } else {
+                    ok = group_sum<A>(a.P_rr, sh, a.hdr, tot, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * k, v); });
+                }
+                if (!ok) return;
+                const T dnT = from_acc<T>(tot);
+                const T dold = k == 0 ? a.history[(long long)(it - 1) * a.nrhs + rhs] : dlt;
+                bt = from_acc<T>(acc_div(to_acc(dnT), to_acc(dold)));
+                dlt = dnT;
+                if (leader && t == 0) {
+                    a.beta[rhs] = bt;
+                    a.delta[rhs] = dnT;
+                    if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = dnT;
+                }
+            }
+            RES_STAMP(1)
+            const T *dold_p = (it & 1) ? d1r : d0r;
+            T *dnew_p = (it & 1) ? d0r : d1r;
+            // ---- my pack of d_new = beta d + r, published for the NEXT iteration's gathers
+            if (packer) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) pd.v[j] = vaypx(bt, pd.v[j], pr.v[j]);
+                st_pack_coh<LOCAL>(at_off(dnew_p, pack_off), pd);
+            }
+            // ---- q[row] = sum a_ij (beta d_old[j] + r[j]) for my two rows, matrix from LDS
+            T dn_own[2], sum[2];
+            sum[0] = sum[1] = vzero<T>();
+            const int rounds = max(re[0] - rs[0], re[1] - rs[1]);
+            if (windowed) {
+                for (int p = t; p < wpacks; p += kResThreads) {
+                    const Pack<T> wd = ld_pack_coh(dold_p + w0 + p * E), wr = ld_pack_coh(rr + w0 + p * E);
+#pragma unroll
+                    for (int j = 0; j < E; ++j) win[p * E + j] = vaypx(bt, wd.v[j], wr.v[j]);
+                }
+                __syncthreads();
+                const char *wb = reinterpret_cast<const char *>(win);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) dn_own[h] = *reinterpret_cast<const T *>(wb + own_off[h]);
+                for (int kk = 0; kk < rounds; kk += UNROLL) {
+                    T dn[2][UNROLL], av[2][UNROLL];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < UNROLL; ++j) {
+                            const int idx = max(min(rs[h] + kk + j, re[h] - 1), 0);
+                            dn[h][j] = *reinterpret_cast<const T *>(wb + sc[idx]);
+                            av[h][j] = sv[idx];
+                        }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < UNROLL; ++j) {
+                            const T nxt = vfma(av[h][j], dn[h][j], sum[h]);
+                            sum[h] = vsel(rs[h] + kk + j < re[h], nxt, sum[h]);
+                        }
+                }
+            } else {
+                T d_own[2], r_own[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    d_own[h] = ld_coh_at(dold_p, own_off[h]);
+                    r_own[h] = ld_coh_at(rr, own_off[h]);
+                }
+                for (int kk = 0; kk < rounds; kk += UNROLL) {
+                    T dv[2][UNROLL], rv[2][UNROLL], av[2][UNROLL];
+                    unsigned go[2][UNROLL];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < UNROLL; ++j) go[h][j] = (unsigned)sc[max(min(rs[h] + kk + j, re[h] - 1), 0)];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < UNROLL; ++j) {      // uniform base + 32-bit byte offset: one address register per gather
+                            dv[h][j] = ld_coh_at(dold_p, go[h][j]);
+                            rv[h][j] = ld_coh_at(rr, go[h][j]);
+                        }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < UNROLL; ++j) av[h][j] = sv[max(min(rs[h] + kk + j, re[h] - 1), 0)];     // LDS reads behind the gathers
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < UNROLL; ++j) {
+                            const T nxt = vfma(av[h][j], vaypx(bt, dv[h][j], rv[h][j]), sum[h]);
+                            sum[h] = vsel(rs[h] + kk + j < re[h], nxt, sum[h]);
+                        }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) dn_own[h] = vaypx(bt, d_own[h], r_own[h]);
+            }
+            A dot0 = vzero<A>(), dot1 = vzero<A>();
+            if (live[0]) dot0 = to_acc(vmul(dn_own[0], sum[0]));
+            if (live[1]) dot1 = to_acc(vmul(dn_own[1], sum[1]));
+            RES_STAMP(2)
+            qs[t] = sum[0];
+            qs[t + kResThreads] = sum[1];
+            vblock_sum2(dot0, dot1, sh);              // drains this wave's d_new stores; its barrier also orders qs
+            if ((t & 255) == 0) {
+                const int rb = m * 4 + (t >> 8);
+                if (rb < a.row_blocks) put_granule<LOCAL>(g_dq + (size_t)rb * W, tag0 + 2 * k + 1, dot0);
+                if (rb + 2 < a.row_blocks) put_granule<LOCAL>(g_dq + (size_t)(rb + 2) * W, tag0 + 2 * k + 1, dot1);
+            }
+            RES_STAMP(3)
+            // ---- alpha = delta / d.q (axpy2_dot_alpha_kernel's prologue); the poll is barrier 1
+            A dq;
+            if (!group_sum<A>(a.row_blocks, sh, a.hdr, dq, [&](int i, A &v) { return get_granule(g_dq + (size_t)i * W, tag0 + 2 * k + 1, v); })) return;
+            RES_STAMP(4)
+            const T dqT = from_acc<T>(dq);
+            const T al = from_acc<T>(acc_div(to_acc(dlt), to_acc(dqT)));
+            if (leader && t == 0) a.alpha[rhs] = al;
+            // ---- x += alpha d ; r -= alpha q ; r.r partial of my 256-pack block (axpy2_dot_body)
+            A acc = vzero<A>(), unused = vzero<A>();
+            if (packer) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const T qv = qs[t * E + j];
+                    px.v[j] = vadd(px.v[j], vmul(al, pd.v[j]));
+                    pr.v[j] = vsub(pr.v[j], vmul(al, qv));
+                    acc = vadd(acc, to_acc(vmul(pr.v[j], pr.v[j])));
+                }
+                st_pack_coh<LOCAL>(at_off(rr, pack_off), pr);
+            }
+            RES_STAMP(5)
+            vblock_sum2(acc, unused, sh);             // drains the r stores
+            RES_STAMP(6)
+            if ((t & 255) == 0 && t < VT_) {
+                const int v = m * (4 / E) + (t >> 8);
+                if (v < a.P_rr) {
+                    put_granule<LOCAL>(g_rr + (size_t)v * W, tag0 + 2 * k + 2, acc);
+                    if (k == a.K - 1) a.part_rr[(long long)rhs * a.P_rr + v] = acc;
+                }
+            }
+            // no barrier here: qs and sh.ws are rewritten only behind the barrier of the next prologue's group_sum
+        }
+        if (packer) st_pack(at_off(xr, pack_off), px);
+        // ---- delta / beta / history of the last iteration (cg_tail_kernel), by the leader's work-group
+        if (leader) {
+            A tot;
+            if (!group_sum<A>(a.P_rr, sh, a.hdr, tot, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * a.K, v); })) return;
+            if (t == 0) {
+                const int it = a.it0 + a.K;
+                const T dnT = from_acc<T>(tot);
+                a.beta[rhs] = from_acc<T>(acc_div(to_acc(dnT), to_acc(dlt)));
+                a.delta[rhs] = dnT;
+                if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = dnT;
+                if (rhs == 0) *a.iter = it;
+                atomicAdd(a.hdr + kHdrSolved, 1u);
+            }
+        }
+    }
+}
+
+std::mutex g_resident_mutex;   // one resident launch at a time per process: two of them could hold each other's CUs while groups form
+
+}  // namespace
+
+// largest 4-aligned span of a 1024-row slice and the longest row (host copy of the row pointers)
+static int resident_max_span(int n, const int *ptr_host, int *max_row_len) {
+    int best = 0, longest = 0;
+    for (int r0 = 0; r0 < n; r0 += kResRows) {
+        const int p0 = ptr_host[r0] & ~3, p1 = ptr_host[std::min(r0 + kResRows, n)];
+        best = std::max(best, p1 - p0);
+    }
+    for (int i = 0; i < n; ++i) longest = std::max(longest, ptr_host[i + 1] - ptr_host[i]);
+    *max_row_len = longest;
+    return best;
+}
+
+// Does the resident loop apply?  The two-launch loop's partial sums must be the ones it reproduces: 256-row d.q partials
+// (row_blocks) and one 16-byte pack per thread in the vector launch (vgrid covers the packs once).
+bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const int *ptr_host, ResidentPlan *out) {
+    const int mode = tune().resident;
+    if (mode == 0 || !ptr_host || dtype == 3) return false;      // 16-byte values: the two-launch loop
+    const int E = (int)(16 / dtype_size(dtype));
+    if (n < 1 || n > 65536 || n % E || n_cus < 8) return false;
+    const int npack = n / E;
+    if (vgrid != (npack + kBlock - 1) / kBlock || row_blocks != (n + kBlock - 1) / kBlock) return false;
+    int max_len = 0;
+    const int span = resident_max_span(n, ptr_host, &max_len);
+    ResidentPlan rp;
+    rp.cap = (span + 3) & ~3;
+    rp.lds_bytes = (size_t)rp.cap * (dtype_size(dtype) + 4) + (size_t)kResRows * dtype_size(dtype);
+    if (rp.lds_bytes > 150 * 1024) return false;
+    // what is left of 150 KB holds the per-iteration window of beta d + r (at most the whole vector)
+    rp.wcap = (int)std::min<size_t>((150 * 1024 - rp.lds_bytes) / dtype_size(dtype), (size_t)n) & ~3;
+    if (rp.wcap < 64 || tune().resident_window == 0) rp.wcap = 0;
+    rp.lds_bytes += (size_t)rp.wcap * dtype_size(dtype);
+    rp.G = (n + kResRows - 1) / kResRows;
+    rp.unroll = (max_len > 10 && max_len <= 12 && dtype == 0) ? 12 : (max_len > 8 && max_len <= 10) ? 10 : 8;
+    const int per_xcd = n_cus / 8;
+    rp.local = mode == 2 ? 0 : (rp.G <= per_xcd ? 1 : 0);
+    rp.lg = rp.local ? per_xcd / rp.G : n_cus / rp.G;
+    if (rp.lg < 1) return false;
+    rp.slots = (rp.local ? 16 : 1) * rp.lg;
+    const size_t W = acc_size(dtype) / 4;
+    rp.sync_bytes = (size_t)kHdrWords * 4 + (size_t)rp.slots * 8 + (size_t)rp.slots * 2 * ((size_t)row_blocks * W) * 8;
+    rp.sync_bytes = (rp.sync_bytes + 15) & ~(size_t)15;
+    *out = rp;
+    return true;
+}
+
+static long long *g_prof_dev = nullptr;     // diagnostics only
+static void resident_print_prof(int K, hipStream_t st) {
+    long long h[8] = {0};
+    if (!g_prof_dev || hipMemcpyAsync(h, g_prof_dev, 64, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
+    fprintf(stderr, "resident prof (s_memtime ticks per iteration, %d iterations): loop-top %.0f  beta-poll %.0f  gather+fma %.0f  reduce+put %.0f  "
+                    "alpha-poll %.0f  update %.0f  reduce+put %.0f\n", K, (double)h[0] / K, (double)h[1] / K, (double)h[2] / K, (double)h[3] / K,
+            (double)h[4] / K, (double)h[5] / K, (double)h[6] / K);
+}
+
+template <typename T, bool LOCAL, int UNROLL>
+static int resident_launch_inst(const ResArgs<T> &a, size_t lds, int grid, hipStream_t st) {
+    auto kern = cg_resident_kernel<T, LOCAL, UNROLL>;
+    static thread_local size_t lds_set = 0;
+    if (lds > 64 * 1024 && lds > lds_set) {
+        const size_t want = std::min<size_t>((lds + 8191) & ~(size_t)8191, 152 * 1024);      // + the static words: below the 160 KB of a CU
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("resident loop: hipFuncSetAttribute: ") + hipGetErrorString(e));
+        lds_set = want;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kResThreads), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("resident loop launch: ") + hipGetErrorString(e));
+    return CGAMD_OK;
+}
+
+template <typename T>
+static int resident_impl(const ResidentPlan &rp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
+                         void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
+                         int grid, hipStream_t st) {
+    using A = typename VT<T>::acc;
+    constexpr int W = sizeof(A) / 4;
+    ResArgs<T> a;
+    a.n = n; a.nrhs = nrhs; a.G = rp.G; a.row_blocks = row_blocks; a.P_rr = P_rr; a.npack = n / Pack<T>::N;
+    a.it0 = it0; a.K = K; a.history_cap = sc.history_cap; a.cap = rp.cap; a.wcap = rp.wcap;
+    a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
+    a.x = static_cast<T *>(x); a.r = static_cast<T *>(r); a.d0 = static_cast<T *>(d0); a.d1 = static_cast<T *>(d1);
+    a.part_rr = static_cast<A *>(part_rr);
+    a.alpha = (T *)sc.alpha; a.beta = (T *)sc.beta; a.delta = (T *)sc.delta; a.history = (T *)sc.history; a.iter = sc.iter;
+    a.hdr = static_cast<unsigned *>(sync);
+    a.slot_word = reinterpret_cast<u64 *>(static_cast<char *>(sync) + kHdrWords * 4);
+    a.gran = a.slot_word + rp.slots;
+    a.gran_stride = row_blocks * W;
+    a.lg = rp.lg;
+    if (getenv("CGAMD_RESIDENT_PROF") && !g_prof_dev) CG_HIP(hipMalloc(&g_prof_dev, 64));
+    a.prof = g_prof_dev;
+    if (g_prof_dev) CG_HIP(hipMemsetAsync(g_prof_dev, 0, 64, st));
+    // every polled word is zero at the start of every launch (tags count within the launch)
+    CG_HIP(hipMemsetAsync(sync, 0, rp.sync_bytes, st));
+    if constexpr (sizeof(T) == 4)
+        if (rp.unroll == 12) return rp.local ? resident_launch_inst<T, true, 12>(a, rp.lds_bytes, grid, st) : resident_launch_inst<T, false, 12>(a, rp.lds_bytes, grid, st);
+    if (rp.unroll == 10) return rp.local ? resident_launch_inst<T, true, 10>(a, rp.lds_bytes, grid, st) : resident_launch_inst<T, false, 10>(a, rp.lds_bytes, grid, st);
+    return rp.local ? resident_launch_inst<T, true, 8>(a, rp.lds_bytes, grid, st) : resident_launch_inst<T, false, 8>(a, rp.lds_bytes, grid, st);
+}
+
+// K iterations of every right-hand side in one launch; synchronises `st` and reports a time-out inside the launch
+int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
+                    void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
+                    int n_cus, hipStream_t st) {
+    if (K < 1 || K >= (1 << 18)) return fail(CGAMD_ERR_INVALID, "resident loop: iteration count per launch out of range");
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    const int grid = n_cus;            // one work-group per CU; groups form from whatever is running (see the header comment)
+    int rc;
+    switch (dtype) {
+    case 0: rc = resident_impl<float>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st); break;
+    case 1: rc = resident_impl<double>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st); break;
+    case 2: rc = resident_impl<float2>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st); break;
+    default: return fail(CGAMD_ERR_INVALID, "resident loop: bad dtype");
+    }
+    if (rc) return rc;
+    unsigned hdr[kHdrWords];
+    CG_HIP(hipMemcpyAsync(hdr, sync, sizeof(hdr), hipMemcpyDeviceToHost, st));
+    CG_HIP(hipStreamSynchronize(st));
+    if (getenv("CGAMD_RESIDENT_PROF")) resident_print_prof(K, st);
+    if (hdr[kHdrError] != 0 || hdr[kHdrSolved] != (unsigned)nrhs)
+        return fail(CGAMD_ERR_HIP, "resident loop: " + std::string(hdr[kHdrError] == kErrSweep ? "a partial sum" : hdr[kHdrError] == kErrClaim ? "a group's claim" : "completion") +
+                                       " timed out (solved " + std::to_string(hdr[kHdrSolved]) + " of " + std::to_string(nrhs) +
+                                       " right-hand sides); cgamd_tune(\"resident\", 0) selects the two-launch loop");
+    return CGAMD_OK;
+}
+
+}  // namespace cgamd

@@ -52,6 +52,11 @@ struct cgamd_solver {
     // two-launch loop (small systems): d of iteration k lives in dbuf[k & 1] (dbuf[0] = d, the initial r); decided at creation
     bool fused2 = false;
     void *d2 = nullptr;
+    // resident loop (resident.hip): iterate() calls of a small system in ONE launch; decided with fused2
+    bool res_ok = false;
+    ResidentPlan res;
+    void *res_sync = nullptr;
+    int n_cus = 0;
 };
 
 static void destroy_graphs(cgamd_solver *s) {
@@ -152,6 +157,30 @@ static int enqueue_iteration(cgamd_solver *s, int k, hipStream_t st) {
     if ((rc = launch_dot_partials(dt, n, s->r, s->r, n, nr, s->part_rr, s->vgrid, st))) return rc;
     if ((rc = launch_cg_beta(dt, s->part_rr, s->vgrid, nr, s->sc, st))) return rc;
     return launch_aypx(dt, n, s->r, s->d, n, s->sc.beta, nr, st);
+}
+
+// the resident loop applies where the two-launch loop does and the matrix slices fit LDS (needs the row pointers on the host)
+static int setup_resident(cgamd_solver *s) {
+    s->res_ok = false;
+    if (!s->fused2 || tune().resident == 0 || s->n > 65536) return CGAMD_OK;
+    std::vector<int> tmp;
+    const int *ph = s->ptr_host.size() == (size_t)s->n + 1 ? s->ptr_host.data() : nullptr;
+    if (!ph) {          // borrowed device matrix
+        tmp.resize((size_t)s->n + 1);
+        CG_HIP(hipMemcpyAsync(tmp.data(), s->ptr, tmp.size() * 4, hipMemcpyDeviceToHost, s->ctx->stream));
+        CG_HIP(hipStreamSynchronize(s->ctx->stream));
+        ph = tmp.data();
+    }
+    if (!s->n_cus) CG_HIP(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device));
+    ResidentPlan rp;
+    if (!aligned16(s->x) || !aligned16(s->r) || !aligned16(s->d) || !aligned16(s->d2)) return CGAMD_OK;
+    if (!resident_plan(s->dtype, s->n, s->vgrid, s->plan.n_partials, s->n_cus, ph, &rp)) return CGAMD_OK;
+    if (s->res_sync && rp.sync_bytes > s->res.sync_bytes) { (void)hipFree(s->res_sync); s->res_sync = nullptr; }
+    if (!s->res_sync)
+        if (int rc = dmalloc(&s->res_sync, rp.sync_bytes, "resident sync words")) return rc;
+    s->res = rp;
+    s->res_ok = true;
+    return CGAMD_OK;
 }
 
 static int capture(cgamd_solver *s, int k0, int iters, hipGraph_t *g, hipGraphExec_t *ge) {
@@ -268,6 +297,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, size, nnz, s->vals, s->cols);
     if (!rc && s->rm_ok) s->rm_nwg = spmm_rm_grid(dtype, nRHS, size, s->plan.max_quad, true);
     if (!rc) s->fused2 = fused2_ok(s->plan, dtype, nRHS, s->vals, s->cols);
+    if (!rc) rc = setup_resident(s);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(ctx->stream);  // host matrix arrays may go away after return
         if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("solver_create sync: ") + hipGetErrorString(e));
@@ -309,6 +339,7 @@ int cgamd_solver_reload_matrix(cgamd_solver *s, const void *aValues, const int *
         if ((size_t)std::max(s->plan.grid, s->plan.row_blocks) > s->part_dq_cap) return fail(CGAMD_ERR_STATE, "reload_matrix: partial buffer too small");
         if (s->rm_ok) s->rm_nwg = spmm_rm_grid(s->dtype, s->nrhs, s->n, s->plan.max_quad, true);
         s->fused2 = fused2_ok(s->plan, s->dtype, s->nrhs, s->vals, s->cols);
+        if (int rc = setup_resident(s)) return rc;
     }
     CG_HIP(hipStreamSynchronize(st));   // the host arrays may go away after return
     return CGAMD_OK;
@@ -326,7 +357,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
         if (s->cols) (void)hipFree(s->cols);
     }
     void *bufs[] = {s->slab, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
-                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket};
+                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;
@@ -423,6 +454,18 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
     int left = nIterations, k = s->iters;
     const bool use_graph = !(s->flags & CGAMD_NO_GRAPH) && !s->graph_failed;
     const bool two = fused2_now(s);
+    if (two && s->res_ok && !(s->flags & CGAMD_NO_GRAPH) && nIterations >= std::max(1, tune().resident_min)) {
+        // small system: the whole call in one launch per 2^17 iterations (resident.hip); same state, same bits as the loop below
+        for (int left = nIterations; left > 0;) {
+            const int K = std::min(left, 1 << 17);
+            if (int rc = run_cg_resident(s->dtype, s->res, s->n, s->nrhs, s->vals, s->ptr, s->cols, s->x, s->r, s->d, s->d2, s->part_rr,
+                                         s->vgrid, s->plan.n_partials, s->sc, s->iters, K, s->res_sync, s->n_cus, st))
+                return rc;
+            s->iters += K;
+            left -= K;
+        }
+        return CGAMD_OK;
+    }
     // graphs start at a fixed parity of the iteration count (d ping-pongs in the two-launch loop; U is even)
     while (use_graph && !s->graph_failed && left > 0) {
         const int par = two ? (k & 1) : 0;
@@ -555,6 +598,15 @@ int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS
 }
 
 int cgamd_solver_layout(cgamd_solver *s) { return s ? (s->rm ? 1 : 0) : -CGAMD_ERR_INVALID; }
+int cgamd_solver_loop_launches(cgamd_solver *s) {
+    if (!s) return -CGAMD_ERR_INVALID;
+    TuneScope ts(&s->tune);
+    if (s->flags & CGAMD_UNFUSED) return 8;
+    if (s->rm) return 5;
+    if (s->mdiag) return 4;
+    if (fused2_now(s)) return (s->res_ok && !(s->flags & CGAMD_NO_GRAPH)) ? 0 : 2;
+    return fold_alpha_ok(s->plan.n_partials) ? 3 : 4;
+}
 
 long long cgamd_solver_spmv_bytes(cgamd_solver *s) {
     if (!s) return 0;

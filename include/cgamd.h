@@ -148,6 +148,10 @@ int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS
 /* 0: the handle's vectors (cgamd_solver_vector) are RHS-major [nRHS][size]; 1: row-major [size][nRHS] (decided by the
  * last cgamd_solver_set_rhs) */
 int cgamd_solver_layout(cgamd_solver *s);
+/* launches per iteration of the loop cgamd_solver_iterate runs for this handle: 0 = the resident loop (small systems: every
+ * iteration of a call of at least `resident_min` iterations inside ONE launch, csrc/resident.hip), 2 / 3 / 4 / 5 = the
+ * loops of DESIGN.md section 4, 8 = the reference's op structure (CGAMD_UNFUSED); negative: error */
+int cgamd_solver_loop_launches(cgamd_solver *s);
 int cgamd_transpose(cgamd_ctx *ctx, int dtype, int rows, int cols, const void *in, void *out);
 /* algorithmic HBM bytes of one SpMV / one CG iteration of this solver (SURVEY §8d formulae: 14 vector passes for the
  * reference's op structure, 11 for its "fused minimum"; the default loop here moves 10) */

@@ -1,0 +1,142 @@
+"""Resident CG loop (csrc/resident.hip): every iteration of an iterate() call of a small system inside ONE launch.  The loop
+reproduces the partial-sum structure of the two-launch loop, and the library is built with -ffp-contract=off, so x, the
+residual history and the device scalars must equal the two-launch loop's BIT FOR BIT (tuning knob resident = 0), and both
+are held to the oracle as everywhere else.  Reference loop: clcg.c:297-419; its workload of this size: the sub-domain
+solves of p_h-PY_C-CL.py:1925-1950 (16k rows x 9 complex64 right-hand sides x 256 iterations)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import cg_numpy
+import cg_oracle
+from conftest import rand_vec
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(kind):
+    if kind == "poisson40":
+        ip, ix, da = cg_numpy.poisson2d(40)                     # 1600 rows: 2 members, the second one partial
+        return ip, ix, da.astype(np.float64)
+    if kind == "poisson128":
+        ip, ix, da = cg_numpy.poisson2d(128)                    # 16384 rows: 16 members = half an XCD
+        return ip, ix, da.astype(np.float64)
+    if kind == "poisson200":
+        ip, ix, da = cg_numpy.poisson2d(200)                    # 40000 rows: 40 members > one XCD -> write-through form
+        return ip, ix, da.astype(np.float64)
+    if kind == "helm128":                                       # the reference's sub-domain matrix shape (as_prec)
+        N = 128
+        return cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    if kind == "helm24":
+        N = 24
+        return cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    raise ValueError(kind)
+
+
+def _run(pkg, ctx, ip, ix, da, B, X0, nrhs, calls, knobs):
+    lib = pkg._lib.load()
+    for k, v in knobs.items():
+        pkg._lib.check(lib.cgamd_tune(k.encode(), int(v)))
+    try:
+        s = pkg.Solver(ctx, len(ip) - 1, len(ix), da, ip, ix, nrhs)
+        s.set_rhs(B, X0)
+        kind = lib.cgamd_solver_loop_launches(s.handle)
+        for c in calls:
+            s.iterate(c)
+        out = dict(x=s.x(), h=s.history(), kind=kind)
+        for name in ("r", "d"):
+            buf = np.empty((len(ip) - 1) * nrhs, dtype=da.dtype)
+            pkg._lib.check(lib.cgamd_memcpy_d2h(ctx.handle, pkg._lib.ptr(buf), ctypes.c_void_p(s.vector(name)), buf.nbytes))
+            out[name] = buf
+        s.close()
+        return out
+    finally:
+        for k in knobs:
+            pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_min": 8}.get(k, 0)))
+
+
+CASES = [
+    (np.float64, "poisson40", 1, [25, 9]),
+    (np.float32, "poisson40", 3, [30]),
+    (np.float64, "poisson128", 1, [40, 24]),
+    (np.float64, "poisson128", 5, [32]),
+    (np.float32, "poisson128", 2, [32]),
+    (np.complex64, "helm24", 4, [20, 20]),
+    (np.complex64, "helm128", 9, [64]),             # the as_prec shape
+    (np.complex64, "helm128", 20, [24]),            # more right-hand sides than groups: groups claim several in turn (vec_ppt = 1)
+    (np.float64, "poisson200", 2, [24]),            # groups wider than an XCD
+]
+
+
+@pytest.mark.parametrize("dtype,kind,nrhs,calls", CASES)
+def test_resident_loop_is_bit_identical_to_two_launch_loop(pkg, gpu, dtype, kind, nrhs, calls):
+    ctx, queue, kernels = gpu
+    ip, ix, da = _system(kind)
+    if np.dtype(dtype).kind != "c" and np.iscomplexobj(da):
+        pytest.skip("complex matrix")
+    n = len(ip) - 1
+    rng = np.random.default_rng(n + nrhs)
+    wide = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    B = np.concatenate([(r + 1) * 0.5 + rand_vec(rng, n, wide) for r in range(nrhs)])
+    X0 = 0.1 * rand_vec(rng, n * nrhs, wide)
+    A = da.astype(dtype)
+    # the loop needs the vector launch's "one 16-byte pack per thread" partial structure: the default up to 262144 values
+    base = {"vec_ppt": 1} if n * nrhs > 262144 else {}
+    res = _run(pkg, ctx, ip, ix, A, B.astype(dtype), X0.astype(dtype), nrhs, calls, dict(base))
+    two = _run(pkg, ctx, ip, ix, A, B.astype(dtype), X0.astype(dtype), nrhs, calls, dict(base, resident=0))
+    assert res["kind"] == 0 and two["kind"] == 2
+    for key in ("h", "x", "r", "d"):
+        assert np.array_equal(res[key], two[key]), key
+    # ... and the write-through (cross-XCD) form of the same kernel
+    wt = _run(pkg, ctx, ip, ix, A, B.astype(dtype), X0.astype(dtype), nrhs, calls, dict(base, resident=2))
+    assert wt["kind"] == 0
+    for key in ("h", "x", "r", "d"):
+        assert np.array_equal(wt[key], two[key]), key
+    # against the oracle (fp64: the north star's 1e-10 on delta_k; lower precisions as in test_gpu_cg.py)
+    iters = sum(calls)
+    xo, ho = cg_oracle.cg(ip, ix, da.astype(wide), B, x0=X0, nrhs=nrhs, n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
+    tol = 1e-10 if np.dtype(dtype) == np.float64 else 5e-3
+    live = np.abs(ho) > 1e-4 * np.abs(ho[0])
+    assert res["h"].shape == ho.shape
+    # fp32 / complex64 against the fp64 oracle: the recurrence amplifies rounding (the Helmholtz history is non-monotone), so
+    # only the first 12 iterations are held to the tolerance; the whole run is bit-equal to the two-launch loop (above), which
+    # tests/test_gpu_two_launch.py and tests/test_gpu_refprec.py hold to the oracle at full length
+    upto = ho.shape[0] if np.dtype(dtype) == np.float64 else 13
+    assert np.max((np.abs(res["h"] - ho) / np.abs(ho))[:upto][live[:upto]]) < tol
+
+
+def test_resident_and_two_launch_calls_mix(pkg, gpu):
+    """calls shorter than resident_min run the two-launch loop on the same state; any interleaving gives the same bits"""
+    ctx, queue, kernels = gpu
+    ip, ix, da = _system("poisson128")
+    n, nrhs = len(ip) - 1, 2
+    rng = np.random.default_rng(3)
+    B = rand_vec(rng, n * nrhs, np.float64)
+    mixed = _run(pkg, ctx, ip, ix, da, B, None, nrhs, [3, 20, 1, 2, 17, 5], {})
+    plain = _run(pkg, ctx, ip, ix, da, B, None, nrhs, [48], {"resident": 0})
+    one = _run(pkg, ctx, ip, ix, da, B, None, nrhs, [48], {})
+    for key in ("h", "x", "r", "d"):
+        assert np.array_equal(mixed[key], plain[key]), key
+        assert np.array_equal(one[key], plain[key]), key
+
+
+def test_resident_loop_does_not_apply(pkg, gpu):
+    """sizes / types / flags outside the loop's reach keep the launched loops"""
+    ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
+    ip, ix, da = cg_numpy.poisson2d(300)                    # 90000 rows > 65536
+    s = pkg.Solver(ctx, 90000, len(ix), da, ip, ix, 1)
+    assert lib.cgamd_solver_loop_launches(s.handle) == 2
+    s.close()
+    ip, ix, da = cg_numpy.poisson2d(37)                     # 1369 rows: odd, no 16-byte packs per right-hand side
+    s = pkg.Solver(ctx, 1369, len(ix), da, ip, ix, 2)
+    assert lib.cgamd_solver_loop_launches(s.handle) != 0
+    s.close()
+    ip, ix, da = cg_numpy.poisson2d(40)
+    s = pkg.Solver(ctx, 1600, len(ix), da.astype(np.complex128), ip, ix, 1)
+    assert lib.cgamd_solver_loop_launches(s.handle) == 2
+    s.close()
+    s = pkg.Solver(ctx, 1600, len(ix), da, ip, ix, 1, flags=pkg._lib.UNFUSED)
+    assert lib.cgamd_solver_loop_launches(s.handle) == 8
+    s.close()
