@@ -211,7 +211,9 @@ struct ResidentPlan {
     size_t lds_bytes = 0, sync_bytes = 0;
 };
 // false = the loop does not apply (size, alignment, LDS, partial-sum structure of the two-launch loop); ptr_host: n + 1 row pointers
-bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const int *ptr_host, ResidentPlan *out);
+// max_window: resident_max_window()'s answer (0 = unknown: no LDS window)
+bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const int *ptr_host, int max_window, ResidentPlan *out);
+int resident_max_window(int dtype, int n, const int *ptr_dev, const int *cols_dev, int *scratch_dev, hipStream_t st, int *out);
 // K iterations (number it0 + 1 ... it0 + K) of every right-hand side; state in and out is the two-launch loop's (x, r, d of
 // iteration k in (k & 1 ? d1 : d0), r.r partials, delta / beta / alpha / history / iter), bit for bit.  Synchronises `st`;
 // sync: rp.sync_bytes of device memory.

@@ -136,51 +136,61 @@ CG_DEV bool get_granule(const u64 *g, unsigned tag, double2 &v) {
 struct ResShared {
     double2 ws[2 * kResThreads / kWave];   // wave sums of the virtual blocks (real types use .x): [value 0 | value 1][wave]
     double2 gs[4];                     // wave sums of a group_sum
-    double2 bc;                        // broadcast of a reduced value
+    double2 bcT[2];                    // broadcast of the scalars a group_scalars call produces
     int ctl[4];
     int fail;
     int cmin, cmax;                    // column range of this member's rows
 };
+CG_DEV double lane0(double v) { return __shfl(v, 0, kWave); }
+CG_DEV double2 lane0(double2 v) { return make_double2(__shfl(v.x, 0, kWave), __shfl(v.y, 0, kWave)); }
 template <typename A> CG_DEV A &as_acc(double2 &v);
 template <> CG_DEV double &as_acc<double>(double2 &v) { return v.x; }
 template <> CG_DEV double2 &as_acc<double2>(double2 &v) { return v; }
 
-// Sum of P (<= 256) partials in the order of the two-launch kernels' prologues: thread t < 256 holds 0 + p[t], wave tree,
-// then ((w0 + w1) + w2) + w3 (every thread adds the four wave sums itself: one barrier).  `fetch(i, v)` returns false while
-// partial i is not there yet (granules) -- the poll is the barrier between the members; two polls are kept in flight, so a
-// word is seen one L2 trip after it lands, not one and a half.  Called by the whole work-group; false = timed out (error
-// word set).  sh.gs / sh.fail are rewritten only after the next work-group barrier (there is one between any two calls).
-template <typename A, typename F> CG_DEV bool group_sum(int P, ResShared &sh, unsigned *hdr, A &out, F fetch) {
+// A scalar of the recurrence from P (<= 256) partial sums.  The sum is formed in the order of the two-launch kernels'
+// prologues -- thread t < 256 holds 0 + p[t], wave tree, then ((w0 + w1) + w2) + w3 -- and `finish(sum, o0, o1)` (the
+// divisions: double precision, ~80 instructions) runs in wave 0 only; the results reach the other waves through LDS.
+// `fetch(i, v)` returns false while partial i is not there yet (granules): the poll is the barrier between the members; two
+// polls are kept in flight, so a word is seen one L2 trip after it lands, not one and a half.  Called by the whole
+// work-group; false = timed out (error word set).  The shared words are rewritten only after the next work-group barrier
+// (there is one between any two calls).
+struct NoMid { CG_DEV void operator()() const {} };
+template <typename A, typename T, typename F, typename G, typename M = NoMid>
+CG_DEV bool group_scalars(int P, ResShared &sh, unsigned *hdr, T &o0, T &o1, F fetch, G finish, bool HAS_MID = false, M mid = M()) {
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
-    if (t < 256) {      // waves 0..3; a wave polls only if it owns partials
-        A v = vzero<A>();
-        if ((t & ~(kWave - 1)) < P) {
-            const bool mine = t < P;
-            const int i = mine ? t : 0;
-            const long long t0 = wall_clock64();
-            A g0 = vzero<A>(), g1 = vzero<A>();
-            bool ok0 = fetch(i, g0), ok1;
-            for (unsigned spins = 0;; ++spins) {
-                ok1 = fetch(i, g1);
-                if (__all(ok0 || !mine)) { v = g0; break; }
-                ok0 = fetch(i, g0);
-                if (__all(ok1 || !mine)) { v = g1; break; }
-                if ((spins & 63) == 63 && (wall_clock64() - t0 > kResSpinTicks || ld_word(hdr + kHdrError) != 0)) {
-                    if (lane == 0) { atomicCAS(hdr + kHdrError, 0u, (unsigned)kErrSweep); sh.fail = 1; }
-                    break;
-                }
+    A v = vzero<A>();
+    if (t < 256 && (t & ~(kWave - 1)) < P) {      // waves 0..3 that own partials poll
+        const bool mine = t < P;
+        const int i = mine ? t : 0;
+        const long long t0 = wall_clock64();
+        A g0 = vzero<A>(), g1 = vzero<A>();
+        bool ok0 = fetch(i, g0), ok1;
+        for (unsigned spins = 0;; ++spins) {
+            ok1 = fetch(i, g1);
+            if (__all(ok0 || !mine)) { v = g0; break; }
+            ok0 = fetch(i, g0);
+            if (__all(ok1 || !mine)) { v = g1; break; }
+            if ((spins & 63) == 63 && (wall_clock64() - t0 > kResSpinTicks || ld_word(hdr + kHdrError) != 0)) {
+                if (lane == 0) { atomicCAS(hdr + kHdrError, 0u, (unsigned)kErrSweep); sh.fail = 1; }
+                break;
             }
-            v = mine ? vadd(vzero<A>(), v) : vzero<A>();
         }
-        v = wave_sum(v);
-        if (lane == 0) as_acc<A>(sh.gs[wave]) = v;
+        v = wave_sum(mine ? vadd(vzero<A>(), v) : vzero<A>());
+        if (lane == 0 && wave > 0) as_acc<A>(sh.gs[wave]) = v;
+    }
+    if (HAS_MID || P > kWave) __syncthreads();    // uniform: the members' words are in (and the other polling waves' sums)
+    if (HAS_MID) mid();                           // loads that need the barrier but not the scalars: in flight behind the divisions
+    if (wave == 0) {
+        A s = lane0(v);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) s = vadd(s, w * kWave < P ? as_acc<A>(sh.gs[w]) : vzero<A>());
+        T r0, r1;
+        finish(s, r0, r1);
+        if (lane == 0) { *reinterpret_cast<T *>(&sh.bcT[0]) = r0; *reinterpret_cast<T *>(&sh.bcT[1]) = r1; }
     }
     __syncthreads();
-    A s = as_acc<A>(sh.gs[0]);
-    s = vadd(s, as_acc<A>(sh.gs[1]));
-    s = vadd(s, as_acc<A>(sh.gs[2]));
-    s = vadd(s, as_acc<A>(sh.gs[3]));
-    out = s;
+    o0 = *reinterpret_cast<const T *>(&sh.bcT[0]);
+    o1 = *reinterpret_cast<const T *>(&sh.bcT[1]);
     return sh.fail == 0;
 }
 
@@ -202,7 +212,44 @@ template <typename A> CG_DEV void vblock_sum2(A &v0, A &v1, ResShared &sh) {
     }
 }
 
-template <typename T, bool LOCAL, int UNROLL>
+template <typename A> CG_DEV void vblock_sum1(A &v0, ResShared &sh) {
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    v0 = wave_sum(v0);
+    if (lane == 0) as_acc<A>(sh.ws[wave]) = v0;
+    drain_stores();
+    __syncthreads();
+    if ((t & 255) == 0) {
+#pragma unroll
+        for (int i = 1; i < 4; ++i) v0 = vadd(v0, as_acc<A>(sh.ws[wave + i]));
+    }
+}
+
+// column range [w0, w0 + wlen) a member stages per iteration: the columns of its rows and the rows themselves, w0 a multiple of E
+CG_DEV void window_of(int cmin, int cmax, int R0, int n, int E, int &w0, int &wlen) {
+    w0 = min(cmin, R0) & ~(E - 1);
+    wlen = max(cmax, min(R0 + kResRows, n) - 1) - w0 + 1;
+}
+
+// largest window over the members (host: does it fit the LDS left over?): out[0] = max wlen
+__global__ __launch_bounds__(kResThreads) void resident_window_kernel(int n, int E, const int *__restrict__ ptr, const int *__restrict__ cols, int *out) {
+    __shared__ int smin, smax;
+    const int t = threadIdx.x, R0 = blockIdx.x * kResRows;
+    if (t == 0) { smin = 0x7fffffff; smax = 0; }
+    __syncthreads();
+    const int p0 = ptr[R0], p1 = ptr[min(R0 + kResRows, n)];
+    int cmin = 0x7fffffff, cmax = 0;
+    for (int i = p0 + t; i < p1; i += kResThreads) { cmin = min(cmin, cols[i]); cmax = max(cmax, cols[i]); }
+    atomicMin(&smin, cmin);
+    atomicMax(&smax, cmax);
+    __syncthreads();
+    if (t == 0) {
+        int w0, wlen;
+        window_of(smin, smax, R0, n, E, w0, wlen);
+        atomicMax(out, wlen);
+    }
+}
+
+template <typename T, bool LOCAL, int UNROLL, bool WINDOW>
 __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) {
     using A = typename VT<T>::acc;
     constexpr int E = Pack<T>::N;                    // 2 or 4 (16-byte value types are not handled here)
@@ -247,13 +294,17 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
     atomicMin(&sh.cmin, cmin);
     atomicMax(&sh.cmax, cmax);
     __syncthreads();
-    // Window: the columns my rows reference (and my own rows) lie in [w0, w0 + wlen).  If that range fits the LDS left over,
-    // each iteration stages beta d + r of the WHOLE range once (coalesced loads, one value per entry) and the row walk reads
-    // LDS; otherwise every non-zero gathers d and r from L2 (each entry ~ row-length times per work-group).
-    const int w0 = min(sh.cmin, R0) & ~(E - 1);
-    const int wlen = max(sh.cmax, min(R0 + kResRows, a.n) - 1) - w0 + 1;
-    const bool windowed = wlen <= a.wcap;                      // uniform
+    // WINDOW (the host checked that every member's range fits the LDS left over): the columns my rows reference, and the
+    // rows themselves, lie in [w0, w0 + wlen); each iteration has beta d + r of that range in LDS -- my own rows straight from
+    // the registers that hold them, the halo by coalesced loads, one per entry -- and the row walk reads LDS.  !WINDOW:
+    // every non-zero gathers d and r from L2 (each entry ~ row-length times per work-group: 1 us more at 9 per row).
+    int w0, wlen;
+    window_of(sh.cmin, sh.cmax, R0, a.n, E, w0, wlen);
+    constexpr bool windowed = WINDOW;
     const int wpacks = (wlen + E - 1) / E;
+    const int nlow = (R0 - w0) / E;                                             // halo packs below my rows
+    const int hi0 = (min(R0 + kResRows, a.n) - w0) / E;                         // first pack above them
+    const int nhalo = nlow + (wpacks - hi0);
     __syncthreads();
     for (int i = cfirst + t; i < p1; i += kResThreads)         // byte offsets: into the window, or into the global vectors (n <= 65536)
         sc[i - cfirst] = (windowed ? sc[i - cfirst] - w0 : sc[i - cfirst]) * (int)sizeof(T);
@@ -273,6 +324,21 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
     const unsigned pack_off = (unsigned)pack * 16u;
     u64 *g_dq = a.gran + (size_t)(slot * 2) * a.gran_stride, *g_rr = g_dq + a.gran_stride;
     __syncthreads();
+    // WINDOW: the first UNROLL entries of my two rows stay in registers for the whole launch (longer rows: the rest from LDS)
+    T mv[2][WINDOW ? UNROLL : 1];
+    int mo[2][WINDOW ? UNROLL : 1];
+    if constexpr (WINDOW) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const int idx = max(min(rs[h] + j, re[h] - 1), 0);
+                const bool real = rs[h] + j < re[h];
+                mv[h][j] = vsel(real, sv[idx], vzero<T>());                         // beyond the row's end: 0 times the window's zero cell
+                mo[h][j] = real ? sc[idx] : (a.wcap - 1) * (int)sizeof(T);
+            }
+        if (t == 0) win[a.wcap - 1] = vzero<T>();                                   // never touched by the staging (pack of slack)
+    }
 
     for (unsigned seq = 1;; ++seq) {
         // ---- which right-hand side: the leader claims, the others wait for its word (or for the end of all solves)
@@ -318,19 +384,44 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
             RES_STAMP(0)
             // ---- beta from the previous iteration's r.r partials (spmv_fused_kernel's prologue); the poll is barrier 2
             T bt = vzero<T>();
+            const T *dold_p = (it & 1) ? d1r : d0r;
+            T *dnew_p = (it & 1) ? d0r : d1r;
+            // WINDOW: the first round of halo loads (d_old and r of my neighbours) needs barrier 2 but not beta: issued between the
+            // poll and wave 0's divisions (4.57 -> 4.33 us per iteration at 16k rows x 9 complex64, scripts/resident_ab.py)
+            Pack<T> h_da, h_ra, h_db, h_rb;
+            int h_pa = 0, h_pb = 0;
+            bool h_two = false;
+            bool halo_prefetch_late = false;
+            const int ht = kResThreads - 1 - t;       // the LAST waves load the halo: wave 0 is busy with the divisions meanwhile
+            auto halo_prefetch = [&]() {
+                if constexpr (WINDOW) {
+                    if (ht < nhalo) {
+                        const int hq = ht + kResThreads;
+                        h_two = hq < nhalo;
+                        h_pa = ht < nlow ? ht : hi0 + (ht - nlow);
+                        h_pb = h_two ? (hq < nlow ? hq : hi0 + (hq - nlow)) : h_pa;
+                        h_da = ld_pack_coh(dold_p + w0 + h_pa * E); h_ra = ld_pack_coh(rr + w0 + h_pa * E);
+                        h_db = ld_pack_coh(dold_p + w0 + h_pb * E); h_rb = ld_pack_coh(rr + w0 + h_pb * E);
+                    }
+                }
+            };
+            if (it == 0) halo_prefetch_late = true;      // no prologue in the very first iteration
             if (it > 0) {
-                A tot;
+                const T dold = k == 0 ? a.history[(long long)(it - 1) * a.nrhs + rhs] : dlt;
+                auto fin = [&](A tot, T &b, T &dn) {
+                    dn = from_acc<T>(tot);
+                    b = from_acc<T>(acc_div(to_acc(dn), to_acc(dold)));
+                };
+                T dnT;
                 bool ok;
                 if (k == 0) {
                     const A *p = a.part_rr + (long long)rhs * a.P_rr;
-                    ok = group_sum<A>(a.P_rr, sh, a.hdr, tot, [&](int i, A &v) { v = p[i]; return true; });
+                    ok = group_scalars<A, T>(a.P_rr, sh, a.hdr, bt, dnT, [&](int i, A &v) { v = p[i]; return true; }, fin, WINDOW, halo_prefetch);
                 } else {
-                    ok = group_sum<A>(a.P_rr, sh, a.hdr, tot, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * k, v); });
+                    ok = group_scalars<A, T>(a.P_rr, sh, a.hdr, bt, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * k, v); }, fin,
+                                             WINDOW, halo_prefetch);
                 }
                 if (!ok) return;
-                const T dnT = from_acc<T>(tot);
-                const T dold = k == 0 ? a.history[(long long)(it - 1) * a.nrhs + rhs] : dlt;
-                bt = from_acc<T>(acc_div(to_acc(dnT), to_acc(dold)));
                 dlt = dnT;
                 if (leader && t == 0) {
                     a.beta[rhs] = bt;
@@ -338,9 +429,8 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
                     if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = dnT;
                 }
             }
+            if (halo_prefetch_late) halo_prefetch();
             RES_STAMP(1)
-            const T *dold_p = (it & 1) ? d1r : d0r;
-            T *dnew_p = (it & 1) ? d0r : d1r;
             // ---- my pack of d_new = beta d + r, published for the NEXT iteration's gathers
             if (packer) {
 #pragma unroll
@@ -351,17 +441,43 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
             T dn_own[2], sum[2];
             sum[0] = sum[1] = vzero<T>();
             const int rounds = max(re[0] - rs[0], re[1] - rs[1]);
-            if (windowed) {
-                for (int p = t; p < wpacks; p += kResThreads) {
-                    const Pack<T> wd = ld_pack_coh(dold_p + w0 + p * E), wr = ld_pack_coh(rr + w0 + p * E);
+            if constexpr (WINDOW) {
+                char *wb = reinterpret_cast<char *>(win);
+                if (packer) *reinterpret_cast<Pack<T> *>(wb + (size_t)(R0 - w0) * sizeof(T) + (size_t)t * 16) = pd;      // my rows: already beta d + r
+                if (ht < nhalo) {                                           // the prefetched first round of the halo
+                    Pack<T> oa, ob;
 #pragma unroll
-                    for (int j = 0; j < E; ++j) win[p * E + j] = vaypx(bt, wd.v[j], wr.v[j]);
+                    for (int j = 0; j < E; ++j) { oa.v[j] = vaypx(bt, h_da.v[j], h_ra.v[j]); ob.v[j] = vaypx(bt, h_db.v[j], h_rb.v[j]); }
+                    *reinterpret_cast<Pack<T> *>(wb + (size_t)h_pa * 16) = oa;
+                    if (h_two) *reinterpret_cast<Pack<T> *>(wb + (size_t)h_pb * 16) = ob;
+                }
+                for (int hp = ht + 2 * kResThreads; hp < nhalo; hp += 2 * kResThreads) {     // wider halos: two packs of d and of r in flight per thread
+                    const int hq = hp + kResThreads;
+                    const bool two = hq < nhalo;
+                    const int pa = hp < nlow ? hp : hi0 + (hp - nlow), pb = two ? (hq < nlow ? hq : hi0 + (hq - nlow)) : pa;
+                    const Pack<T> da_ = ld_pack_coh(dold_p + w0 + pa * E), ra_ = ld_pack_coh(rr + w0 + pa * E);
+                    const Pack<T> db_ = ld_pack_coh(dold_p + w0 + pb * E), rb_ = ld_pack_coh(rr + w0 + pb * E);
+                    Pack<T> oa, ob;
+#pragma unroll
+                    for (int j = 0; j < E; ++j) { oa.v[j] = vaypx(bt, da_.v[j], ra_.v[j]); ob.v[j] = vaypx(bt, db_.v[j], rb_.v[j]); }
+                    *reinterpret_cast<Pack<T> *>(wb + (size_t)pa * 16) = oa;
+                    if (two) *reinterpret_cast<Pack<T> *>(wb + (size_t)pb * 16) = ob;
                 }
                 __syncthreads();
-                const char *wb = reinterpret_cast<const char *>(win);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) dn_own[h] = *reinterpret_cast<const T *>(wb + own_off[h]);
-                for (int kk = 0; kk < rounds; kk += UNROLL) {
+                {
+                    T dn[2][UNROLL];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < UNROLL; ++j) dn[h][j] = *reinterpret_cast<const T *>(wb + mo[h][j]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < UNROLL; ++j) sum[h] = vfma(mv[h][j], dn[h][j], sum[h]);     // padding adds 0 * 0 (sum is never -0)
+                }
+                for (int kk = UNROLL; kk < rounds; kk += UNROLL) {          // rows longer than UNROLL
                     T dn[2][UNROLL], av[2][UNROLL];
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
@@ -429,14 +545,18 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
             }
             RES_STAMP(3)
             // ---- alpha = delta / d.q (axpy2_dot_alpha_kernel's prologue); the poll is barrier 1
-            A dq;
-            if (!group_sum<A>(a.row_blocks, sh, a.hdr, dq, [&](int i, A &v) { return get_granule(g_dq + (size_t)i * W, tag0 + 2 * k + 1, v); })) return;
+            T al, al_unused;
+            if (!group_scalars<A, T>(a.row_blocks, sh, a.hdr, al, al_unused,
+                                     [&](int i, A &v) { return get_granule(g_dq + (size_t)i * W, tag0 + 2 * k + 1, v); },
+                                     [&](A dq, T &o, T &u) {
+                                         const T dqT = from_acc<T>(dq);      // the reference rounds d.q to the value type before dividing (clcg.c:318-327)
+                                         o = from_acc<T>(acc_div(to_acc(dlt), to_acc(dqT)));
+                                         u = o;
+                                     })) return;
             RES_STAMP(4)
-            const T dqT = from_acc<T>(dq);
-            const T al = from_acc<T>(acc_div(to_acc(dlt), to_acc(dqT)));
             if (leader && t == 0) a.alpha[rhs] = al;
             // ---- x += alpha d ; r -= alpha q ; r.r partial of my 256-pack block (axpy2_dot_body)
-            A acc = vzero<A>(), unused = vzero<A>();
+            A acc = vzero<A>();
             if (packer) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
@@ -448,7 +568,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
                 st_pack_coh<LOCAL>(at_off(rr, pack_off), pr);
             }
             RES_STAMP(5)
-            vblock_sum2(acc, unused, sh);             // drains the r stores
+            vblock_sum1(acc, sh);                     // drains the r stores
             RES_STAMP(6)
             if ((t & 255) == 0 && t < VT_) {
                 const int v = m * (4 / E) + (t >> 8);
@@ -462,12 +582,15 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
         if (packer) st_pack(at_off(xr, pack_off), px);
         // ---- delta / beta / history of the last iteration (cg_tail_kernel), by the leader's work-group
         if (leader) {
-            A tot;
-            if (!group_sum<A>(a.P_rr, sh, a.hdr, tot, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * a.K, v); })) return;
+            T bfin, dnT;
+            if (!group_scalars<A, T>(a.P_rr, sh, a.hdr, bfin, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * a.K, v); },
+                                     [&](A tot, T &b, T &dn) {
+                                         dn = from_acc<T>(tot);
+                                         b = from_acc<T>(acc_div(to_acc(dn), to_acc(dlt)));
+                                     })) return;
             if (t == 0) {
                 const int it = a.it0 + a.K;
-                const T dnT = from_acc<T>(tot);
-                a.beta[rhs] = from_acc<T>(acc_div(to_acc(dnT), to_acc(dlt)));
+                a.beta[rhs] = bfin;
                 a.delta[rhs] = dnT;
                 if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = dnT;
                 if (rhs == 0) *a.iter = it;
@@ -495,7 +618,7 @@ static int resident_max_span(int n, const int *ptr_host, int *max_row_len) {
 
 // Does the resident loop apply?  The two-launch loop's partial sums must be the ones it reproduces: 256-row d.q partials
 // (row_blocks) and one 16-byte pack per thread in the vector launch (vgrid covers the packs once).
-bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const int *ptr_host, ResidentPlan *out) {
+bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const int *ptr_host, int max_window, ResidentPlan *out) {
     const int mode = tune().resident;
     if (mode == 0 || !ptr_host || dtype == 3) return false;      // 16-byte values: the two-launch loop
     const int E = (int)(16 / dtype_size(dtype));
@@ -509,8 +632,9 @@ bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const
     rp.lds_bytes = (size_t)rp.cap * (dtype_size(dtype) + 4) + (size_t)kResRows * dtype_size(dtype);
     if (rp.lds_bytes > 150 * 1024) return false;
     // what is left of 150 KB holds the per-iteration window of beta d + r (at most the whole vector)
-    rp.wcap = (int)std::min<size_t>((150 * 1024 - rp.lds_bytes) / dtype_size(dtype), (size_t)n) & ~3;
-    if (rp.wcap < 64 || tune().resident_window == 0) rp.wcap = 0;
+    const size_t left = (150 * 1024 - rp.lds_bytes) / dtype_size(dtype);
+    rp.wcap = 0;
+    if (max_window > 0 && tune().resident_window != 0 && (size_t)max_window + 4 <= left) rp.wcap = (max_window + 3 + 4) & ~3;      // + a pack of slack
     rp.lds_bytes += (size_t)rp.wcap * dtype_size(dtype);
     rp.G = (n + kResRows - 1) / kResRows;
     rp.unroll = (max_len > 10 && max_len <= 12 && dtype == 0) ? 12 : (max_len > 8 && max_len <= 10) ? 10 : 8;
@@ -535,9 +659,9 @@ static void resident_print_prof(int K, hipStream_t st) {
             (double)h[4] / K, (double)h[5] / K, (double)h[6] / K);
 }
 
-template <typename T, bool LOCAL, int UNROLL>
+template <typename T, bool LOCAL, int UNROLL, bool WINDOW>
 static int resident_launch_inst(const ResArgs<T> &a, size_t lds, int grid, hipStream_t st) {
-    auto kern = cg_resident_kernel<T, LOCAL, UNROLL>;
+    auto kern = cg_resident_kernel<T, LOCAL, UNROLL, WINDOW>;
     static thread_local size_t lds_set = 0;
     if (lds > 64 * 1024 && lds > lds_set) {
         const size_t want = std::min<size_t>((lds + 8191) & ~(size_t)8191, 152 * 1024);      // + the static words: below the 160 KB of a CU
@@ -549,6 +673,11 @@ static int resident_launch_inst(const ResArgs<T> &a, size_t lds, int grid, hipSt
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("resident loop launch: ") + hipGetErrorString(e));
     return CGAMD_OK;
+}
+template <typename T, int UNROLL>
+static int resident_launch_u(const ResidentPlan &rp, const ResArgs<T> &a, int grid, hipStream_t st) {
+    if (rp.wcap > 0) return rp.local ? resident_launch_inst<T, true, UNROLL, true>(a, rp.lds_bytes, grid, st) : resident_launch_inst<T, false, UNROLL, true>(a, rp.lds_bytes, grid, st);
+    return rp.local ? resident_launch_inst<T, true, UNROLL, false>(a, rp.lds_bytes, grid, st) : resident_launch_inst<T, false, UNROLL, false>(a, rp.lds_bytes, grid, st);
 }
 
 template <typename T>
@@ -575,9 +704,19 @@ static int resident_impl(const ResidentPlan &rp, int n, int nrhs, const void *va
     // every polled word is zero at the start of every launch (tags count within the launch)
     CG_HIP(hipMemsetAsync(sync, 0, rp.sync_bytes, st));
     if constexpr (sizeof(T) == 4)
-        if (rp.unroll == 12) return rp.local ? resident_launch_inst<T, true, 12>(a, rp.lds_bytes, grid, st) : resident_launch_inst<T, false, 12>(a, rp.lds_bytes, grid, st);
-    if (rp.unroll == 10) return rp.local ? resident_launch_inst<T, true, 10>(a, rp.lds_bytes, grid, st) : resident_launch_inst<T, false, 10>(a, rp.lds_bytes, grid, st);
-    return rp.local ? resident_launch_inst<T, true, 8>(a, rp.lds_bytes, grid, st) : resident_launch_inst<T, false, 8>(a, rp.lds_bytes, grid, st);
+        if (rp.unroll == 12) return resident_launch_u<T, 12>(rp, a, grid, st);
+    if (rp.unroll == 10) return resident_launch_u<T, 10>(rp, a, grid, st);
+    return resident_launch_u<T, 8>(rp, a, grid, st);
+}
+
+// the widest column range a member's rows touch (device pass over the column indices; synchronises `st`)
+int resident_max_window(int dtype, int n, const int *ptr, const int *cols, int *scratch_dev, hipStream_t st, int *out) {
+    const int E = (int)(16 / dtype_size(dtype));
+    CG_HIP(hipMemsetAsync(scratch_dev, 0, 4, st));
+    hipLaunchKernelGGL(resident_window_kernel, dim3((n + kResRows - 1) / kResRows), dim3(kResThreads), 0, st, n, E, ptr, cols, scratch_dev);
+    CG_HIP(hipMemcpyAsync(out, scratch_dev, 4, hipMemcpyDeviceToHost, st));
+    CG_HIP(hipStreamSynchronize(st));
+    return CGAMD_OK;
 }
 
 // K iterations of every right-hand side in one launch; synchronises `st` and reports a time-out inside the launch

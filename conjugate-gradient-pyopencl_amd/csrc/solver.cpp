@@ -174,7 +174,10 @@ static int setup_resident(cgamd_solver *s) {
     if (!s->n_cus) CG_HIP(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device));
     ResidentPlan rp;
     if (!aligned16(s->x) || !aligned16(s->r) || !aligned16(s->d) || !aligned16(s->d2)) return CGAMD_OK;
-    if (!resident_plan(s->dtype, s->n, s->vgrid, s->plan.n_partials, s->n_cus, ph, &rp)) return CGAMD_OK;
+    int max_window = 0;
+    if (s->dtype != 3 && s->n % (int)(16 / dtype_size(s->dtype)) == 0)
+        if (int rc = resident_max_window(s->dtype, s->n, s->ptr, s->cols, s->sc.iter, s->ctx->stream, &max_window)) return rc;
+    if (!resident_plan(s->dtype, s->n, s->vgrid, s->plan.n_partials, s->n_cus, ph, max_window, &rp)) return CGAMD_OK;
     if (s->res_sync && rp.sync_bytes > s->res.sync_bytes) { (void)hipFree(s->res_sync); s->res_sync = nullptr; }
     if (!s->res_sync)
         if (int rc = dmalloc(&s->res_sync, rp.sync_bytes, "resident sync words")) return rc;
@@ -339,8 +342,8 @@ int cgamd_solver_reload_matrix(cgamd_solver *s, const void *aValues, const int *
         if ((size_t)std::max(s->plan.grid, s->plan.row_blocks) > s->part_dq_cap) return fail(CGAMD_ERR_STATE, "reload_matrix: partial buffer too small");
         if (s->rm_ok) s->rm_nwg = spmm_rm_grid(s->dtype, s->nrhs, s->n, s->plan.max_quad, true);
         s->fused2 = fused2_ok(s->plan, s->dtype, s->nrhs, s->vals, s->cols);
-        if (int rc = setup_resident(s)) return rc;
     }
+    if (int rc = setup_resident(s)) return rc;      // also with unchanged row pointers: the column range of a row slice may have moved
     CG_HIP(hipStreamSynchronize(st));   // the host arrays may go away after return
     return CGAMD_OK;
 }

@@ -53,7 +53,7 @@ def _run(pkg, ctx, ip, ix, da, B, X0, nrhs, calls, knobs):
         return out
     finally:
         for k in knobs:
-            pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_min": 8}.get(k, 0)))
+            pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_min": 8, "resident_window": 1}.get(k, 0)))
 
 
 CASES = [
@@ -93,6 +93,11 @@ def test_resident_loop_is_bit_identical_to_two_launch_loop(pkg, gpu, dtype, kind
     assert wt["kind"] == 0
     for key in ("h", "x", "r", "d"):
         assert np.array_equal(wt[key], two[key]), key
+    # ... and the form without the LDS window (every non-zero gathers d and r from L2: what irregular patterns get)
+    nw = _run(pkg, ctx, ip, ix, A, B.astype(dtype), X0.astype(dtype), nrhs, calls, dict(base, resident_window=0))
+    assert nw["kind"] == 0
+    for key in ("h", "x", "r", "d"):
+        assert np.array_equal(nw[key], two[key]), key
     # against the oracle (fp64: the north star's 1e-10 on delta_k; lower precisions as in test_gpu_cg.py)
     iters = sum(calls)
     xo, ho = cg_oracle.cg(ip, ix, da.astype(wide), B, x0=X0, nrhs=nrhs, n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
