@@ -80,8 +80,9 @@ struct Tuning {
     int defer_x = 1;        // fused loop: x += alpha d rides in the aypx launch (10 vector passes per iteration instead of 11)
     int fold_alpha = 1;     // small systems (<= 2048 d.q partials): alpha in the prologue of axpy2_dot, three launches per iteration
     int two_launch = 1;     // ... and beta / d = beta d + r inside the next SpMV launch: two launches per iteration
-    int resident = 1;       // systems of at most 65536 rows whose 1024-row matrix slices fit LDS: all iterations of an iterate() call in
-                            // ONE launch (resident.hip); 0 = never, 2 = always with write-through stores (the cross-XCD form)
+    int resident = 1;       // systems of at most 32768 rows (a group of 1024-row work-groups inside one XCD) whose matrix slices fit LDS:
+                            // all iterations of an iterate() call in ONE launch (resident.hip); 0 = never, 2 = always in the cross-XCD
+                            // form (write-through stores; up to 65536 rows; slower than launches, kept for the any-placement tests)
     int resident_min = 8;   // ... for iterate() calls of at least this many iterations
     int resident_window = 1; // ... staging the column range of a member's rows in LDS once per iteration (0 = per-non-zero gathers)
     int spmm_wide_max = -1; // multi-RHS, RHS-major: largest row_blocks x nRHS for the one-work-group-per-RHS form (-1 = 4096, 0 = never)

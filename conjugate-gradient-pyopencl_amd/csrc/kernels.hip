@@ -1834,7 +1834,8 @@ int vec_grid(long long n, int dtype, int nrhs) {
     // (profiles/r2_experiments/vec_ppt.log: 16k rows 10.4 -> 9.2 us per iteration with 1, 250k rows 16.2 -> 15.8 with 2,
     // N = 1M 32.2 -> 34.0 with 1); "vec_ppt" overrides
     const long long total = n * (long long)(nrhs > 0 ? nrhs : 1);
-    const int ppt = tune().vec_ppt > 0 ? tune().vec_ppt : (total <= 262144 ? 1 : total <= 524288 ? 2 : 4);
+    // (up to 65536 rows always 1, whatever the number of right-hand sides: the partial-sum structure the resident loop reproduces)
+    const int ppt = tune().vec_ppt > 0 ? tune().vec_ppt : ((total <= 262144 || n <= 65536) ? 1 : total <= 524288 ? 2 : 4);
     const long long per_block = (long long)kBlock * (16 / (long long)dtype_size(dtype)) * ppt;
     long long g = (n + per_block - 1) / per_block;
     const long long cap = tune().vec_grid > 0 ? tune().vec_grid : kMaxGrid;

@@ -37,6 +37,7 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr int kResThreads = 512;                // threads per work-group
+constexpr int kResMaxRows = 65536;              // 256 d.q partials: one per polling thread
 constexpr int kResRows = 1024;                  // rows per member: every thread walks two (4 virtual blocks of 256 rows)
 constexpr long long kResSpinTicks = 200000000;  // 2 s of the 100 MHz wall clock
 
@@ -622,7 +623,7 @@ bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const
     const int mode = tune().resident;
     if (mode == 0 || !ptr_host || dtype == 3) return false;      // 16-byte values: the two-launch loop
     const int E = (int)(16 / dtype_size(dtype));
-    if (n < 1 || n > 65536 || n % E || n_cus < 8) return false;
+    if (n < 1 || n > kResMaxRows || n % E || n_cus < 8) return false;
     const int npack = n / E;
     if (vgrid != (npack + kBlock - 1) / kBlock || row_blocks != (n + kBlock - 1) / kBlock) return false;
     int max_len = 0;
@@ -640,6 +641,10 @@ bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const
     rp.unroll = (max_len > 10 && max_len <= 12 && dtype == 0) ? 12 : (max_len > 8 && max_len <= 10) ? 10 : 8;
     const int per_xcd = n_cus / 8;
     rp.local = mode == 2 ? 0 : (rp.G <= per_xcd ? 1 : 0);
+    // groups wider than an XCD exchange through memory (write-through stores): measured SLOWER than two launches per iteration
+    // (65536 rows complex64 11.4 vs 9.4 us; with four partials per polling thread 250k rows 17.8 vs 15.2,
+    // profiles/r2_experiments/resident_ab.log) -- only on request
+    if (!rp.local && mode != 2) return false;
     rp.lg = rp.local ? per_xcd / rp.G : n_cus / rp.G;
     if (rp.lg < 1) return false;
     rp.slots = (rp.local ? 16 : 1) * rp.lg;

@@ -28,6 +28,9 @@ def _system(kind):
     if kind == "helm128":                                       # the reference's sub-domain matrix shape (as_prec)
         N = 128
         return cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    if kind == "helm256":
+        N = 256
+        return cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
     if kind == "helm24":
         N = 24
         return cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
@@ -64,8 +67,9 @@ CASES = [
     (np.float32, "poisson128", 2, [32]),
     (np.complex64, "helm24", 4, [20, 20]),
     (np.complex64, "helm128", 9, [64]),             # the as_prec shape
-    (np.complex64, "helm128", 20, [24]),            # more right-hand sides than groups: groups claim several in turn (vec_ppt = 1)
+    (np.complex64, "helm128", 20, [24]),            # more right-hand sides than groups: groups claim several in turn
     (np.float64, "poisson200", 2, [24]),            # groups wider than an XCD
+    (np.complex64, "helm256", 1, [24]),             # 65536 rows: the largest group (64 work-groups, 256 d.q partials)
 ]
 
 
@@ -81,8 +85,10 @@ def test_resident_loop_is_bit_identical_to_two_launch_loop(pkg, gpu, dtype, kind
     B = np.concatenate([(r + 1) * 0.5 + rand_vec(rng, n, wide) for r in range(nrhs)])
     X0 = 0.1 * rand_vec(rng, n * nrhs, wide)
     A = da.astype(dtype)
-    # the loop needs the vector launch's "one 16-byte pack per thread" partial structure: the default up to 262144 values
-    base = {"vec_ppt": 1} if n * nrhs > 262144 else {}
+    # the loop needs the vector launch's "one 16-byte pack per thread" partial structure: the default up to 65536 rows
+    base = {"vec_ppt": 1} if n * nrhs > 262144 and n > 65536 else {}
+    if n > 32768:
+        base["resident"] = 2                 # groups wider than an XCD: the write-through form, not taken by default (slower than launches)
     res = _run(pkg, ctx, ip, ix, A, B.astype(dtype), X0.astype(dtype), nrhs, calls, dict(base))
     two = _run(pkg, ctx, ip, ix, A, B.astype(dtype), X0.astype(dtype), nrhs, calls, dict(base, resident=0))
     assert res["kind"] == 0 and two["kind"] == 2
@@ -130,8 +136,8 @@ def test_resident_loop_does_not_apply(pkg, gpu):
     """sizes / types / flags outside the loop's reach keep the launched loops"""
     ctx, queue, kernels = gpu
     lib = pkg._lib.load()
-    ip, ix, da = cg_numpy.poisson2d(300)                    # 90000 rows > 65536
-    s = pkg.Solver(ctx, 90000, len(ix), da, ip, ix, 1)
+    ip, ix, da = cg_numpy.poisson2d(200)                    # 40000 rows: a group would span two XCDs
+    s = pkg.Solver(ctx, 40000, len(ix), da, ip, ix, 1)
     assert lib.cgamd_solver_loop_launches(s.handle) == 2
     s.close()
     ip, ix, da = cg_numpy.poisson2d(37)                     # 1369 rows: odd, no 16-byte packs per right-hand side
