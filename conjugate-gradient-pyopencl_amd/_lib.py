@@ -98,6 +98,9 @@ def load():
         "cgamd_solver_reload_matrix": (ci, [vp, vp, vp, vp]),
         "cgamd_gen_laplace3d": (ci, [vp, ci, ci, ci, ci, ll, ll, vp, vp, vp, ctypes.POINTER(ll)]),
         "cgamd_gen_poisson2d": (ci, [vp, ci, ci, vp, vp, vp, ctypes.POINTER(ll)]),
+        "cgamd_gen_helm_fe_var": (ci, [vp, ci, ci, ctypes.c_double, vp, ctypes.c_double, ci, ci, vp, vp, vp, ctypes.POINTER(ll)]),
+        "cgamd_gen_local_rect": (ci, [vp, ci, ci, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ci, ci, vp, vp, vp,
+                                 ctypes.POINTER(ll)]),
         "cgamd_mm_read": (ci, [ctypes.c_char_p, ctypes.POINTER(ci), ctypes.POINTER(ll), ctypes.POINTER(ci),
                                ctypes.POINTER(ctypes.POINTER(ctypes.c_double)),
                                ctypes.POINTER(ctypes.POINTER(ci)), ctypes.POINTER(ctypes.POINTER(ci))]),

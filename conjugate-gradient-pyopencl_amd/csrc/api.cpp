@@ -6,6 +6,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/clcg.h"
 #include "cgamd_internal.h"
@@ -265,6 +266,45 @@ int cgamd_gen_poisson2d(cgamd_ctx *c, int dtype, int N, void *aValues, int *aPoi
     if (int rc = check_op(c, dtype, 0, 1, "gen_poisson2d")) return rc;
     if (!aValues || !aCols) return fail(CGAMD_ERR_INVALID, "gen_poisson2d: null pointer");
     return launch_gen_poisson2d(dtype, N, aValues, aPointers, aCols, c->stream);
+}
+
+static int gen_fe_common(cgamd_ctx *c, int dtype, int variable, int N, double p0, double p1, double p2, double L, const double *C_host, int Nh,
+                         int Nv, void *aValues, int *aPointers, int *aCols, long long *nnz_out, const char *what) {
+    if (N < 2 || Nh < 2 || Nv < 2 || (long long)Nh * Nv > 200000000LL) return fail(CGAMD_ERR_INVALID, std::string(what) + ": bad N / Nhoriz / Nvert");
+    const long long nnz = helm_fe_nnz(Nh, Nv);
+    if (nnz_out) *nnz_out = nnz;
+    if (!aPointers) return CGAMD_OK;
+    if (int rc = check_op(c, dtype, 0, 1, what)) return rc;
+    if (!aValues || !aCols) return fail(CGAMD_ERR_INVALID, std::string(what) + ": null pointer");
+    if (dtype != CGAMD_C64 && dtype != CGAMD_C128) return fail(CGAMD_ERR_INVALID, std::string(what) + ": the matrix is complex (dtype complex64 or complex128)");
+    double *C_dev = nullptr;
+    if (variable) {     // wave speed per square on the device (all ones when the caller passes none)
+        const size_t count = (size_t)(Nh - 1) * (Nv - 1);
+        std::vector<double> ones;
+        if (!C_host) { ones.assign(count, 1.0); C_host = ones.data(); }
+        for (size_t i = 0; i < count; ++i)
+            if (!(C_host[i] != 0.0)) return fail(CGAMD_ERR_INVALID, std::string(what) + ": wave speed C must be non-zero");
+        CG_HIP(hipMalloc(&C_dev, count * sizeof(double)));
+        hipError_t e = hipMemcpyAsync(C_dev, C_host, count * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);     // `ones` / the caller's array may go away
+        if (e != hipSuccess) { (void)hipFree(C_dev); return fail(CGAMD_ERR_HIP, std::string(what) + ": upload of C: " + hipGetErrorString(e)); }
+    }
+    int rc = launch_gen_helm_fe(dtype, variable, N, p0, p1, p2, L, C_dev, Nh, Nv, aValues, aPointers, aCols, c->stream);
+    if (C_dev) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(C_dev);
+    }
+    return rc;
+}
+
+int cgamd_gen_helm_fe_var(cgamd_ctx *c, int dtype, int N, double omega, const double *C, double rho, int Nhoriz, int Nvert, void *aValues,
+                          int *aPointers, int *aCols, long long *nnz_out) {
+    return gen_fe_common(c, dtype, 1, N, omega, rho, 0.0, 1.0, C, Nhoriz, Nvert, aValues, aPointers, aCols, nnz_out, "gen_helm_fe_var");
+}
+
+int cgamd_gen_local_rect(cgamd_ctx *c, int dtype, int N, double k, double eps, double eta, double L, int Nhoriz, int Nvert, void *aValues,
+                         int *aPointers, int *aCols, long long *nnz_out) {
+    return gen_fe_common(c, dtype, 0, N, k, eps, eta, L, nullptr, Nhoriz, Nvert, aValues, aPointers, aCols, nnz_out, "gen_local_rect");
 }
 
 // ---- one-call typed solve on host arrays ----------------------------------------------------------

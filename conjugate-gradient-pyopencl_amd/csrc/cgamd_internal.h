@@ -266,6 +266,10 @@ int launch_gen_laplace3d(int dtype, int nx, int ny, int nz, long long row_begin,
                          int *ptr, int *cols, hipStream_t st);
 long long laplace3d_ptr(long long i, int nx, int ny, int nz);
 int launch_gen_poisson2d(int dtype, int N, void *vals, int *ptr, int *cols, hipStream_t st);
+// generators.hip: variable = 1 helmFE_var (p0 = omega, p1 = rho; C_dev = wave speed per square or nullptr... never nullptr), 0 local_rect (p0 = k, p1 = eps, p2 = eta)
+long long helm_fe_nnz(int Nh, int Nv);
+int launch_gen_helm_fe(int dtype, int variable, int N, double p0, double p1, double p2, double L, const double *C_dev, int Nh, int Nv, void *vals,
+                       int *ptr, int *cols, hipStream_t st);
 long long poisson2d_ptr(long long i, int N);
 
 }  // namespace cgamd

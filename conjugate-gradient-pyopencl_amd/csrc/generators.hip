@@ -1,0 +1,162 @@
+// P1 finite-element Helmholtz matrices on a structured triangulation of a rectangle, generated straight into device CSR:
+//   * helmFE_var(N, omega, C, rho, Nhoriz, Nvert)   -- reference helmFE_var.py:9-331 (BASELINE config 3: N = 500, omega = 12, C = 1,
+//     rho = 0.15): variable wave speed, k = omega / C on every mesh square, absorption cr = 1 + i rho, impedance term i k;
+//   * local_rect(N, k, eps, eta, L, Nhoriz, Nvert)  -- reference p_h-PY_C-CL.py:1439-1639 (the sub-domain matrices as_prec solves
+//     with CG): constant k, shift k^2 + i eps, impedance parameter eta.
+// Both have the same pattern: node (j, m) = column j, row m, index m Nhoriz + j couples to +-1, +-Nhoriz and +-(Nhoriz + 1)
+// (7 entries inside, 5 on an edge, 4 / 3 in the corners: nnz = 2 (5 Nhoriz - 3) + (Nvert - 2)(7 Nhoriz - 4)), so row
+// pointers are closed-form and one thread writes one row, columns ascending = scipy's canonical CSR of the reference's
+// coordinate lists.  Every value is evaluated in the reference's own operation order in complex double (the library is built
+// with -ffp-contract=off), then rounded to the requested type: tests/test_gpu_generators.py holds the result to the golden
+// matrices produced by the unmodified reference (pattern exact, values to 1e-15) and to the CPU restatement at N = 500.
+#include <hip/hip_runtime.h>
+
+#include "cgamd_internal.h"
+#include "device_types.h"
+
+namespace cgamd {
+namespace {
+
+struct Cx {
+    double re, im;
+};
+CG_DEV Cx cx(double re, double im) { return Cx{re, im}; }
+CG_DEV Cx operator-(Cx a, Cx b) { return Cx{a.re - b.re, a.im - b.im}; }
+CG_DEV Cx operator*(Cx a, double s) { return Cx{a.re * s, a.im * s}; }      // complex x (s + 0i): the cross terms are exact zeros
+CG_DEV Cx operator/(Cx a, double s) { return Cx{a.re / s, a.im / s}; }      // Smith's division by (s + 0i): ratio 0, denominator s
+CG_DEV Cx neg(Cx a) { return Cx{-a.re, -a.im}; }
+CG_DEV Cx real_minus(double r, Cx a) { return Cx{r - a.re, 0.0 - a.im}; }
+
+struct FeArgs {
+    int Nh, Nv, variable;
+    double h, h2;
+    double omega, rho;            // helmFE_var
+    double k2, eps, eta;          // local_rect
+    const double *C;              // [Nv - 1][Nh - 1] wave speed per square (helmFE_var)
+};
+
+// the zeroth-order coefficient on a square and the impedance coefficient on its boundary edge
+struct Sq {
+    double k;                     // helmFE_var: omega / C; local_rect: unused
+};
+CG_DEV double sq_k(const FeArgs &a, int m, int j) {
+    m = min(max(m, 0), a.Nv - 2);
+    j = min(max(j, 0), a.Nh - 2);
+    return a.variable ? a.omega / a.C[(long long)m * (a.Nh - 1) + j] : 0.0;
+}
+// cr * s (helmFE_var: s a real combination of k^2) / (k2 + i eps) * w (local_rect: w the combination's weight)
+CG_DEV Cx zterm(const FeArgs &a, double s_var, double w_const) {
+    if (a.variable) return cx(s_var, a.rho * s_var);                        // (1 + i rho) * (s + 0i)
+    return cx(a.k2 * w_const, a.eps * w_const);
+}
+
+CG_DEV long long fe_row_start(int m, int j, int Nh, int Nv) {
+    const long long edge_row = 5LL * Nh - 3, mid_row = 7LL * Nh - 4;
+    long long p = m == 0 ? 0 : edge_row + (long long)(m - 1) * mid_row;
+    if (j > 0) {
+        if (m == 0) p += 4 + 5LL * (j - 1);
+        else if (m == Nv - 1) p += 3 + 5LL * (j - 1);
+        else p += 5 + 7LL * (j - 1);
+    }
+    return p;
+}
+
+template <typename T> CG_DEV T to_val(Cx v);
+template <> CG_DEV float2 to_val<float2>(Cx v) { return make_float2((float)v.re, (float)v.im); }
+template <> CG_DEV double2 to_val<double2>(Cx v) { return make_double2(v.re, v.im); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void gen_helm_fe_kernel(FeArgs a, T *__restrict__ vals, int *__restrict__ ptr, int *__restrict__ cols) {
+    const long long nn = (long long)a.Nh * a.Nv;
+    const double h = a.h, h2 = a.h2;
+    for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row <= nn; row += (long long)gridDim.x * blockDim.x) {
+        if (row == nn) { ptr[nn] = (int)(2 * (5LL * a.Nh - 3) + (long long)(a.Nv - 2) * (7LL * a.Nh - 4)); break; }
+        const int m = (int)(row / a.Nh), j = (int)(row % a.Nh);
+        long long p = fe_row_start(m, j, a.Nh, a.Nv);
+        ptr[row] = (int)p;
+        const bool bot = m == 0, top = m == a.Nv - 1, left = j == 0, right = j == a.Nh - 1;
+        const double knw = sq_k(a, m, j - 1), ksw = sq_k(a, m - 1, j - 1), kne = sq_k(a, m, j), kse = sq_k(a, m - 1, j);
+        // helmFE_var: k of the square(s) an entry belongs to; local_rect: the same formulas with k2 + i eps and eta
+        auto edge = [&](double k) {          // -0.5 - z h2 / 24 - i kappa h / 6      (helmFE_var.py:147-293, p_h:1534-1600)
+            const Cx z = zterm(a, k * k, 1.0);
+            const double kap = a.variable ? k : a.eta;
+            return cx(-0.5, 0.0) - z * h2 / 24. - cx(0.0, kap * h / 6.);
+        };
+        auto diagnb = [&](double k) {        // -z h2 / 12
+            return neg(zterm(a, k * k, 1.0)) * h2 / 12.;
+        };
+        auto cross = [&](double ka, double kb) {   // -1 - cr (ka^2 + kb^2) h2 / 24   |   -1 - (k2 + i eps) h2 / 12
+            if (a.variable) return cx(-1.0, 0.0) - zterm(a, ka * ka + kb * kb, 0.0) * h2 / 24.;
+            return cx(-1.0, 0.0) - zterm(a, 0.0, 1.0) * h2 / 12.;
+        };
+        Cx dg;
+        if (a.variable) {
+            if (bot && left) dg = real_minus(1., zterm(a, kne * kne, 0.) * h2 / 6.) - cx(0.0, kne * 2 * h / 3.);
+            else if (bot && right) dg = real_minus(1., zterm(a, knw * knw, 0.) * h2 / 12.) - cx(0.0, knw * 2. * h / 3.);
+            else if (top && left) dg = real_minus(1., zterm(a, kse * kse, 0.) * h2 / 12.) - cx(0.0, kse * 2. * h / 3.);
+            else if (top && right) dg = real_minus(1., zterm(a, ksw * ksw, 0.) * (h2 / 6.)) - cx(0.0, ksw * 2. * h / 3.);
+            else if (bot) dg = real_minus(2., zterm(a, knw * knw + 2. * (kne * kne), 0.) * h2 / 12.) - cx(0.0, (knw + kne) * h / 3.);
+            else if (top) dg = real_minus(2., zterm(a, 2. * (ksw * ksw) + kse * kse, 0.) * h2 / 12.) - cx(0.0, (ksw + kse) * h / 3.);
+            else if (left) dg = real_minus(2., zterm(a, 2. * (kne * kne) + kse * kse, 0.) * h2 / 12.) - cx(0.0, (kne + kse) * h / 3.);
+            else if (right) dg = real_minus(2., zterm(a, knw * knw + 2. * (ksw * ksw), 0.) * h2 / 12.) - cx(0.0, (knw + ksw) * h / 3.);
+            else dg = real_minus(4., zterm(a, knw * knw + 2. * (ksw * ksw) + 2. * (kne * kne) + kse * kse, 0.) * h2 / 12.);
+        } else {
+            const Cx z = zterm(a, 0.0, 1.0);
+            if ((bot && left) || (top && right)) dg = real_minus(1., z * h2 / 6.) - cx(0.0, a.eta * 2 * h / 3.);
+            else if ((bot && right) || (top && left)) dg = real_minus(1., z * h2 / 12.) - cx(0.0, a.eta * 2 * h / 3.);
+            else if (bot || top || left || right) dg = real_minus(2., z * h2 / 4.) - cx(0.0, 2. * a.eta * h / 3.);
+            else dg = real_minus(4., z * h2 / 2.);
+        }
+        auto put = [&](long long col, Cx v) { cols[p] = (int)col; vals[p] = to_val<T>(v); ++p; };
+        const int Nh = a.Nh;
+        // columns ascending: row - Nh - 1, row - Nh, row - 1, row, row + 1, row + Nh, row + Nh + 1
+        if (!bot && !left) put(row - Nh - 1, diagnb(ksw));                                     // all rows with a south-west square
+        if (!bot) {
+            if (left) put(row - Nh, edge(kse));
+            else if (right) put(row - Nh, edge(ksw));
+            else put(row - Nh, top ? cross(ksw, kse) : cross(ksw, kse));
+        }
+        if (!left) {
+            if (bot) put(row - 1, edge(knw));
+            else if (top) put(row - 1, edge(ksw));
+            else put(row - 1, right ? cross(ksw, knw) : cross(knw, ksw));
+        }
+        put(row, dg);
+        if (!right) {
+            if (bot) put(row + 1, edge(kne));
+            else if (top) put(row + 1, edge(kse));
+            else put(row + 1, left ? cross(kse, kne) : cross(kne, kse));
+        }
+        if (!top) {
+            if (left) put(row + Nh, edge(kne));
+            else if (right) put(row + Nh, edge(knw));
+            else put(row + Nh, cross(knw, kne));
+        }
+        if (!top && !right) put(row + Nh + 1, diagnb(kne));
+    }
+}
+
+}  // namespace
+
+long long helm_fe_nnz(int Nh, int Nv) { return 2 * (5LL * Nh - 3) + (long long)(Nv - 2) * (7LL * Nh - 4); }
+
+int launch_gen_helm_fe(int dtype, int variable, int N, double p0, double p1, double p2, double L, const double *C_dev, int Nh, int Nv, void *vals,
+                       int *ptr, int *cols, hipStream_t st) {
+    FeArgs a;
+    a.Nh = Nh; a.Nv = Nv; a.variable = variable;
+    a.h = (variable ? 1.0 : L * 1.0) / (N - 1.0);        // helmFE_var.py:47 / p_h-PY_C-CL.py:1474
+    a.h2 = a.h * a.h;
+    a.omega = p0; a.rho = p1;
+    a.k2 = p0 * p0; a.eps = p1; a.eta = p2;
+    a.C = C_dev;
+    const long long nn = (long long)Nh * Nv;
+    const int grid = (int)std::min<long long>((nn + 256) / 256, 65536);
+    if (dtype == 2) hipLaunchKernelGGL((gen_helm_fe_kernel<float2>), dim3(grid), dim3(256), 0, st, a, static_cast<float2 *>(vals), ptr, cols);
+    else if (dtype == 3) hipLaunchKernelGGL((gen_helm_fe_kernel<double2>), dim3(grid), dim3(256), 0, st, a, static_cast<double2 *>(vals), ptr, cols);
+    else return fail(CGAMD_ERR_INVALID, "gen_helm_fe: the matrix is complex (dtype complex64 or complex128)");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("gen_helm_fe launch: ") + hipGetErrorString(e));
+    return CGAMD_OK;
+}
+
+}  // namespace cgamd

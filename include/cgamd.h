@@ -181,6 +181,18 @@ int cgamd_gen_laplace3d(cgamd_ctx *ctx, int dtype, int nx, int ny, int nz, long 
 int cgamd_gen_poisson2d(cgamd_ctx *ctx, int dtype, int N, void *aValues, int *aPointers, int *aCols,
                         long long *nnz_out);
 
+/* P1 finite-element Helmholtz matrices of the reference's drivers, Nhoriz x Nvert nodes, complex symmetric, 7 entries per interior
+ * row (canonical CSR; dtype complex64 or complex128; values evaluated in complex double in the reference's operation order):
+ *   cgamd_gen_helm_fe_var: helmFE_var(N, omega, C, rho, Nhoriz, Nvert) of helmFE_var.py:9-331 -- BASELINE config 3 is N = Nhoriz =
+ *     Nvert = 500, omega = 12, C = 1, rho = 0.15.  C: (Nvert - 1) x (Nhoriz - 1) wave speeds, row-major, HOST doubles (NULL = all 1);
+ *   cgamd_gen_local_rect:  local_rect(N, k, eps, eta, L, Nhoriz, Nvert) of p_h-PY_C-CL.py:1439-1639 -- the sub-domain matrices
+ *     as_prec hands to cg().
+ * Pass aPointers == NULL to query the number of non-zeros via *nnz_out. */
+int cgamd_gen_helm_fe_var(cgamd_ctx *ctx, int dtype, int N, double omega, const double *C, double rho, int Nhoriz, int Nvert,
+                          void *aValues, int *aPointers, int *aCols, long long *nnz_out);
+int cgamd_gen_local_rect(cgamd_ctx *ctx, int dtype, int N, double k, double eps, double eta, double L, int Nhoriz, int Nvert,
+                         void *aValues, int *aPointers, int *aCols, long long *nnz_out);
+
 /* ---- Matrix-Market ingest (reference main.c:20-33 via BeBOP) ---------------
  * Reads a coordinate file (real/complex/integer/pattern x general/symmetric/hermitian/skew-symmetric),
  * expands symmetric storage, sums duplicates, converts 1-based -> 0-based CSR with sorted columns.
