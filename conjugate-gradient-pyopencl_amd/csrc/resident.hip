@@ -39,7 +39,8 @@ typedef unsigned long long u64;
 constexpr int kResThreads = 512;                // threads per work-group
 constexpr int kResMaxRows = 65536;              // 256 d.q partials: one per polling thread
 constexpr int kResRows = 1024;                  // rows per member: every thread walks two (4 virtual blocks of 256 rows)
-constexpr long long kResSpinTicks = 200000000;  // 2 s of the 100 MHz wall clock
+constexpr long long kResSpinTicks = 400000000;  // a partial sum that does not arrive: 4 s of the 100 MHz wall clock
+constexpr long long kResClaimTicks = 1500000000; // a group that does not fill (its work-groups queue behind other kernels): 15 s
 
 // header words (unsigned), zeroed before every launch
 enum { kHdrTicket = 0 /* [16] */, kHdrNextRhs = 16, kHdrSolved = 17, kHdrError = 18, kHdrWords = 32 };
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
                     const u64 w = ld_word(a.slot_word + slot);
                     if ((unsigned)(w >> 32) == seq) { rhs = (int)(unsigned)w; break; }
                     if (ld_word(a.hdr + kHdrSolved) >= (unsigned)a.nrhs) break;           // every solve is done: nothing left for anyone
-                    if ((spins & 63) == 63 && (wall_clock64() - t0 > kResSpinTicks || ld_word(a.hdr + kHdrError) != 0)) {
+                    if ((spins & 63) == 63 && (wall_clock64() - t0 > kResClaimTicks || ld_word(a.hdr + kHdrError) != 0)) {
                         atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrClaim);
                         break;
                     }

@@ -34,7 +34,47 @@ def _system(kind):
     if kind == "helm24":
         N = 24
         return cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    if kind == "band5":                                         # rows of 1 .. 11 entries
+        return _banded_spd(6144, 5, 0.8, 5)
+    if kind == "band12":                                        # rows of 1 .. 25 entries: longer than any unroll
+        return _banded_spd(4096, 12, 0.4, 12)
+    if kind == "scattered":
+        return _scattered_spd(20480, 3, 3)
     raise ValueError(kind)
+
+
+def _banded_spd(n, half_band, keep, seed):
+    """symmetric, diagonally dominant, unsorted columns, rows of very different lengths (up to 2 half_band + 1 entries,
+    some rows with the diagonal only): exercises the 10 / 12-entry instances and the beyond-the-unroll row walk"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    A = sp.lil_matrix((n, n))
+    for d in range(1, half_band + 1):
+        v = rng.uniform(-1.0, -0.1, n - d) * (rng.random(n - d) < keep)
+        A.setdiag(v, d)
+    A = sp.csr_matrix(A)
+    A = A + A.T
+    A = sp.csr_matrix(A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0))
+    ip, ix, da = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    for r in range(n):                       # unsorted columns inside the rows
+        s, e = ip[r], ip[r + 1]
+        perm = rng.permutation(e - s)
+        ix[s:e], da[s:e] = ix[s:e][perm], da[s:e][perm]
+    return ip, ix, da
+
+
+def _scattered_spd(n, per_row, seed):
+    """symmetric, diagonally dominant, columns anywhere in [0, n): the column range of a row slice is the whole vector --
+    too wide for the LDS window, the loop gathers d and r per non-zero"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n), per_row)
+    cols = rng.integers(0, n, rows.size)
+    A = sp.csr_matrix((rng.uniform(-1.0, -0.1, rows.size), (rows, cols)), shape=(n, n))
+    A.sum_duplicates()
+    A = A + A.T
+    A = sp.csr_matrix(A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0))
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
 
 
 def _run(pkg, ctx, ip, ix, da, B, X0, nrhs, calls, knobs):
@@ -69,6 +109,12 @@ CASES = [
     (np.complex64, "helm128", 9, [64]),             # the as_prec shape
     (np.complex64, "helm128", 20, [24]),            # more right-hand sides than groups: groups claim several in turn
     (np.float64, "poisson200", 2, [24]),            # groups wider than an XCD
+    (np.float32, "band5", 2, [20]),                 # 12-entry instance (fp32 only)
+    (np.float64, "band5", 2, [20]),                 # 8-entry instance + rest of the row from LDS
+    (np.complex64, "band5", 1, [20]),
+    (np.float64, "band12", 3, [12, 9]),
+    (np.complex64, "band12", 1, [16]),
+    (np.float64, "scattered", 2, [16]),             # no LDS window: per-non-zero gathers by default
     (np.complex64, "helm256", 1, [24]),             # 65536 rows: the largest group (64 work-groups, 256 d.q partials)
 ]
 
