@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--dist-skip", type=str, default="", help="N>1: comma list of loop candidates to skip (p2p+graph,p2p,rccl+graph,rccl)")
     ap.add_argument("--dtype", type=str, default="f64", choices=["f32", "f64", "c64", "c128"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-small-system", action="store_true", help="skip the small-system extra (reference call shape, resident loop)")
     ap.add_argument("--unfused", action="store_true", help="reference op structure (6 kernels/iteration)")
     ap.add_argument("--no-graph", action="store_true", help="plain stream launches instead of hipGraph replay (A/B)")
     ap.add_argument("--spmv-reps", type=int, default=20)
@@ -186,6 +187,11 @@ def main():
             result["rehearsal"] = f"{world} ranks share {max(ndev, 1)} GPU(s): bootstrap over gloo, peer-to-peer loops only, not a scaling number"
 
     if rank == 0:
+        if world == 1 and not args.no_small_system:
+            try:
+                result["small_system"] = small_system_extra(pkg, ctx, torch, dev)
+            except Exception as e:   # a reported extra, never the measured path
+                result["small_system"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(nx, ny, nz, dtype)
@@ -196,6 +202,31 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def small_system_extra(pkg, ctx, torch, dev):
+    """Reported beside the headline, never part of `value`: the reference's own call shape (as_prec, p_h-PY_C-CL.py:1925-1950:
+    one sub-domain matrix, 9 complex64 right-hand sides, fixed iterations) on the helmFE_var(128) matrix (16 384 rows), generated
+    on the device; all iterations of a call run in one launch (csrc/resident.hip)."""
+    import time
+    N, nrhs, iters = 128, 9, 2560
+    ip, ix, da = pkg.generators.helm_fe_var(ctx, N, 12.0, None, 0.15, dtype=np.complex64)
+    s = pkg.Solver(ctx, N * N, int(ix.numel()), da, ip, ix, nrhs, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=np.complex64)
+    b = torch.full((N * N * nrhs,), 5.0, dtype=torch.complex64, device=dev)
+    torch.cuda.synchronize()
+    s.set_rhs(b, None, on_device=True)
+    s.iterate(64)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    s.iterate(iters)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    launches = pkg._lib.load().cgamd_solver_loop_launches(s.handle)
+    h = s.history()
+    s.close()
+    return {"workload": "helmFE_var(128) complex64, 16384 rows x 9 right-hand sides (the reference's as_prec call shape)",
+            "us_per_iteration": dt / iters * 1e6, "cg_it_per_s": iters / dt, "launches_per_iteration": launches,
+            "finite_history": bool(np.all(np.isfinite(h[: iters + 65])))}
 
 
 def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):

@@ -458,9 +458,10 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
     const bool use_graph = !(s->flags & CGAMD_NO_GRAPH) && !s->graph_failed;
     const bool two = fused2_now(s);
     if (two && s->res_ok && !(s->flags & CGAMD_NO_GRAPH) && nIterations >= std::max(1, tune().resident_min)) {
-        // small system: the whole call in one launch per 2^17 iterations (resident.hip); same state, same bits as the loop below
+        // small system: the whole call in one launch per 2^15 iterations (resident.hip; a launch stays well below the bound of its
+        // waits); same state, same bits as the loop below
         for (int left = nIterations; left > 0;) {
-            const int K = std::min(left, 1 << 17);
+            const int K = std::min(left, 1 << 15);
             if (int rc = run_cg_resident(s->dtype, s->res, s->n, s->nrhs, s->vals, s->ptr, s->cols, s->x, s->r, s->d, s->d2, s->part_rr,
                                          s->vgrid, s->plan.n_partials, s->sc, s->iters, K, s->res_sync, s->n_cus, st))
                 return rc;
