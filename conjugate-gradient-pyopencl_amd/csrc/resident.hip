@@ -25,9 +25,14 @@
 // Every spin is bounded (wall clock); a time-out sets the error word, all work-groups drain and the host reports it.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 
 #include "cgamd_internal.h"
 #include "device_mem.h"
@@ -604,6 +609,26 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
 
 std::mutex g_resident_mutex;   // one resident launch at a time per process: two of them could hold each other's CUs while groups form
 
+// ... and per GPU across the processes of this host (MPI ranks of the reference's driver sharing one GPU each call cg()): an
+// advisory lock on a file named after the device's PCI bus id, held from launch to completion.  Best effort: without a
+// writable temp directory the launch proceeds unlocked (a group that cannot fill is then reported after its bounded wait).
+struct DeviceFileLock {
+    int fd = -1;
+    explicit DeviceFileLock(int device) {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, device) != hipSuccess) return;
+        for (char *c = bus; *c; ++c)
+            if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+        const char *dir = getenv("TMPDIR");
+        const std::string path = std::string(dir && *dir ? dir : "/tmp") + "/cgamd-resident-" + std::to_string((long long)getuid()) + "-" + bus + ".lock";
+        fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        if (fd >= 0 && flock(fd, LOCK_EX) != 0) { close(fd); fd = -1; }
+    }
+    ~DeviceFileLock() {
+        if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); }
+    }
+};
+
 }  // namespace
 
 // largest 4-aligned span of a 1024-row slice and the longest row (host copy of the row pointers)
@@ -731,6 +756,9 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
                     int n_cus, hipStream_t st) {
     if (K < 1 || K >= (1 << 18)) return fail(CGAMD_ERR_INVALID, "resident loop: iteration count per launch out of range");
     std::lock_guard<std::mutex> lock(g_resident_mutex);
+    int device = 0;
+    CG_HIP(hipGetDevice(&device));
+    DeviceFileLock device_lock(device);
     const int grid = n_cus;            // one work-group per CU; groups form from whatever is running (see the header comment)
     int rc;
     switch (dtype) {
