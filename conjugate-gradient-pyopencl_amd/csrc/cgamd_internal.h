@@ -84,6 +84,8 @@ struct Tuning {
                             // all iterations of an iterate() call in ONE launch (resident.hip); 0 = never, 2 = always in the cross-XCD
                             // form (write-through stores; up to 65536 rows; slower than launches, kept for the any-placement tests)
     int resident_min = 8;   // ... for iterate() calls of at least this many iterations
+    int resident_wide = 0;  // single right-hand side, larger systems (rows of <= 8 entries, <= 256 work-groups of 2048 / 4096 rows): one
+                            // chip-wide resident group, matrix in registers; 1 = on
     int resident_window = 1; // ... staging the column range of a member's rows in LDS once per iteration (0 = per-non-zero gathers)
     int spmm_wide_max = -1; // multi-RHS, RHS-major: largest row_blocks x nRHS for the one-work-group-per-RHS form (-1 = 4096, 0 = never)
     int spmv_slice_kb = 0;  // largest 256-row LDS slice the one-lane-per-row kernel accepts, in KB (0 = kMaxSliceBytes)
@@ -221,6 +223,20 @@ int resident_max_window(int dtype, int n, const int *ptr_dev, const int *cols_de
 int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
                     void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
                     int n_cus, hipStream_t st);
+
+// wide resident loop (resident.hip): one chip-wide group for ONE right-hand side, matrix rows in registers
+struct ResidentWidePlan {
+    bool ok = false;
+    int rpt = 0, unroll = 0, G = 0, wcap = 0;
+    size_t lds_bytes = 0, sync_bytes = 0;
+};
+int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev, const int *cols_dev, int *scratch_dev, hipStream_t st,
+                       ResidentWidePlan *out);
+// state in and out: x, r, d of iteration k in (k & 1 ? d1 : d0), delta / beta / alpha / history / iter; d_ready: on entry d is
+// already beta d + r (three / four-launch loops); on exit d is always the direction of the last iteration (two-launch
+// convention) and the launched loops' r.r partials are NOT maintained -- the caller converts / rebuilds
+int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, const void *vals, const int *ptr, const int *cols, void *x, void *r,
+                         void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st);
 
 // [rows][cols] -> [cols][rows]: RHS-major (the reference ABI) <-> row-major
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);

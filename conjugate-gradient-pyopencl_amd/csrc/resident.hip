@@ -607,6 +607,306 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
     }
 }
 
+// =================================================================================================
+// Wide resident loop: ONE group across the whole chip for a single right-hand side of up to 512 RPT x 256 rows (RPT = 4 or 8
+// rows per thread: 2048 / 4096 rows per work-group), for systems the one-XCD loop above cannot hold -- BASELINE configs 2 and 3
+// (1M rows fp64 5-point, 250k rows complex64 7-point).  The matrix lives in REGISTERS (rows of at most U entries), the window
+// of beta d + r and q in LDS; members exchange through memory (write-through stores, sc1 loads: the cross-XCD form).  One
+// partial sum per work-group and reduction, so this loop is NOT bit-identical to the launched loops (it is held to the oracle
+// like them); the host recomputes the launched loops' r.r partials after a call, so the two can alternate on one handle.
+// =================================================================================================
+template <typename T> struct ResWideArgs {
+    int n, G, npack, it0, K, history_cap, wcap;
+    int d_ready;                    // the caller's d already is beta d + r (state of the three / four-launch loops): iteration it0 + 1 takes it as is
+    const T *vals;
+    const int *ptr, *cols;
+    T *x, *r, *d0, *d1;
+    T *alpha, *beta, *delta, *history;
+    int *iter;
+    unsigned *hdr;
+    u64 *slot_word, *gran;          // one slot; gran: [2][G * W]
+};
+
+// sum over the work-group in a fixed order (wave tree, then the 8 wave sums in order); every wave's outstanding stores are
+// acknowledged before the barrier; result valid in thread 0
+template <typename A> CG_DEV A wg_sum(A v, ResShared &sh) {
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    v = wave_sum(v);
+    if (lane == 0) as_acc<A>(sh.ws[wave]) = v;
+    drain_stores();
+    __syncthreads();
+    if (t == 0) {
+#pragma unroll
+        for (int i = 1; i < kResThreads / kWave; ++i) v = vadd(v, as_acc<A>(sh.ws[i]));
+    }
+    return v;
+}
+
+template <typename T, int RPT, int U>
+__global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideArgs<T> a) {
+    using A = typename VT<T>::acc;
+    constexpr int E = Pack<T>::N;
+    constexpr int W = sizeof(A) / 4;
+    constexpr int ROWS = kResThreads * RPT;          // rows per member
+    constexpr int PPT = RPT / E;                     // 16-byte packs of every vector per thread
+    static_assert(RPT % E == 0, "whole packs per thread");
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    T *qs = reinterpret_cast<T *>(dyn_smem);         // q of my rows
+    T *win = qs + ROWS;                              // beta d + r of the column range of my rows; last entry: the zero cell
+    __shared__ ResShared sh;
+    const int t = threadIdx.x;
+
+    if (t == 0) {
+        sh.ctl[1] = (int)atomicAdd(a.hdr + kHdrTicket, 1u);
+        sh.fail = 0;
+        sh.cmin = 0x7fffffff;
+        sh.cmax = 0;
+    }
+    __syncthreads();
+    const int m = __builtin_amdgcn_readfirstlane(sh.ctl[1]);
+    if (m >= a.G) return;
+    const bool leader = m == a.G - 1;                // drew the last ticket: every member is running
+    // ---- my rows: entries into registers (rows have at most U entries: the host checked)
+    const int R0 = m * ROWS;
+    constexpr int UP = (U + 1) / 2;
+    T mv[RPT][U];
+    int mo[RPT][U];                                  // set-up only; the loop reads the 16-bit window offsets packed in mo2
+    unsigned mo2[RPT][UP];
+    bool live[RPT];
+    int cmin = 0x7fffffff, cmax = 0;
+#pragma unroll
+    for (int h = 0; h < RPT; ++h) {
+        const int row = R0 + t + h * kResThreads;
+        live[h] = row < a.n;
+        const int rc = min(row, a.n - 1);
+        const int ps = a.ptr[rc], len = live[h] ? a.ptr[rc + 1] - ps : 0;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const bool real = j < len;
+            mv[h][j] = real ? a.vals[ps + j] : vzero<T>();
+            mo[h][j] = real ? a.cols[ps + j] : -1;
+            if (real) { cmin = min(cmin, mo[h][j]); cmax = max(cmax, mo[h][j]); }
+        }
+    }
+    atomicMin(&sh.cmin, cmin);
+    atomicMax(&sh.cmax, cmax);
+    __syncthreads();
+    const int rows_m = min(ROWS, a.n - R0);
+    const int w0 = min(sh.cmin, R0) & ~(E - 1);
+    const int wlen = max(sh.cmax, R0 + rows_m - 1) - w0 + 1;
+    const int wpacks = (wlen + E - 1) / E;
+    const int nlow = (R0 - w0) / E, hi0 = (R0 + rows_m - w0) / E, nhalo = nlow + (wpacks - hi0);
+    if (wlen + 1 > a.wcap) {                         // cannot happen: the host sized the window from the same pass
+        if (t == 0) atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrSweep);
+        return;
+    }
+    unsigned own_off[RPT];
+#pragma unroll
+    for (int h = 0; h < RPT; ++h) {
+        own_off[h] = (unsigned)(min(R0 + t + h * kResThreads, a.n - 1) - w0) * (unsigned)sizeof(T);
+#pragma unroll
+        for (int j = 0; j < U; ++j) mo[h][j] = (mo[h][j] >= 0 ? mo[h][j] - w0 : a.wcap - 1) * (int)sizeof(T);      // < 65536: the host checked
+#pragma unroll
+        for (int j = 0; j < UP; ++j) mo2[h][j] = (unsigned)mo[h][2 * j] | ((2 * j + 1 < U ? (unsigned)mo[h][2 * j + 1] : 0u) << 16);
+    }
+    if (t == 0) win[a.wcap - 1] = vzero<T>();
+    u64 *g_dq = a.gran, *g_rr = a.gran + (size_t)a.G * W;
+
+    // ---- start line: nobody touches the vectors before the whole group runs (a work-group queued behind other kernels)
+    if (t == 0) {
+        if (leader) {
+            __hip_atomic_store(a.slot_word, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const long long t0 = wall_clock64();
+            for (unsigned spins = 0;; ++spins) {
+                if ((ld_word(a.slot_word) >> 32) == 1ull) break;
+                if ((spins & 63) == 63 && (wall_clock64() - t0 > kResClaimTicks || ld_word(a.hdr + kHdrError) != 0)) {
+                    atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrClaim);
+                    sh.fail = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
+    __syncthreads();
+    if (sh.fail) return;
+
+    Pack<T> px[PPT], pr[PPT], pd[PPT];
+    bool pk[PPT];
+    unsigned poff[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int pl = t + j * kResThreads;          // local pack: local rows E pl .. E pl + E - 1
+        const int pack = m * (ROWS / E) + pl;
+        pk[j] = pack < a.npack;
+        poff[j] = (unsigned)pack * 16u;
+        if (pk[j]) {
+            px[j] = ld_pack(at_off(a.x, poff[j]));
+            pr[j] = ld_pack(at_off(a.r, poff[j]));
+            pd[j] = ld_pack(at_off((a.it0 & 1) ? a.d1 : a.d0, poff[j]));
+        }
+    }
+    T dlt = a.delta[0];
+    const unsigned tag0 = 1u << 20;
+    char *wb = reinterpret_cast<char *>(win);
+    const int ht = kResThreads - 1 - t;              // the last waves load the halo (wave 0 does the divisions)
+
+    for (int k = 0; k < a.K; ++k) {
+        const int it = a.it0 + k;
+        const T *dold_p = (it & 1) ? a.d1 : a.d0;
+        T *dnew_p = (it & 1) ? a.d0 : a.d1;
+        Pack<T> h_da, h_ra, h_db, h_rb;
+        int h_pa = 0, h_pb = 0;
+        bool h_two = false;
+        auto halo_prefetch = [&]() {
+            if (ht < nhalo) {
+                const int hq = ht + kResThreads;
+                h_two = hq < nhalo;
+                h_pa = ht < nlow ? ht : hi0 + (ht - nlow);
+                h_pb = h_two ? (hq < nlow ? hq : hi0 + (hq - nlow)) : h_pa;
+                h_da = ld_pack_coh(dold_p + w0 + h_pa * E); h_ra = ld_pack_coh(a.r + w0 + h_pa * E);
+                h_db = ld_pack_coh(dold_p + w0 + h_pb * E); h_rb = ld_pack_coh(a.r + w0 + h_pb * E);
+            }
+        };
+        T bt = vzero<T>();
+        const bool as_is = k == 0 && a.d_ready;      // uniform
+        if (it > 0 && k == 0) {                      // beta of a continued run from the stored scalars
+            bt = from_acc<T>(acc_div(to_acc(dlt), to_acc(a.history[it - 1])));
+            halo_prefetch();
+        } else if (it > 0) {
+            T dnT;
+            if (!group_scalars<A, T>(a.G, sh, a.hdr, bt, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * k, v); },
+                                     [&](A tot, T &b, T &dn) {
+                                         dn = from_acc<T>(tot);
+                                         b = from_acc<T>(acc_div(to_acc(dn), to_acc(dlt)));
+                                     }, true, halo_prefetch)) return;
+            dlt = dnT;
+            if (leader && t == 0) {
+                a.beta[0] = bt;
+                a.delta[0] = dnT;
+                if (it < a.history_cap) a.history[it] = dnT;
+            }
+        } else {
+            halo_prefetch();
+        }
+        // ---- d_new = beta d + r: my packs to memory (the neighbours' next halo) and into the window
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (pk[j]) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) pd[j].v[e] = as_is ? pd[j].v[e] : vaypx(bt, pd[j].v[e], pr[j].v[e]);
+                st_pack_coh<false>(at_off(dnew_p, poff[j]), pd[j]);
+                *reinterpret_cast<Pack<T> *>(wb + (size_t)(R0 - w0) * sizeof(T) + (size_t)(t + j * kResThreads) * 16) = pd[j];
+            }
+        if (ht < nhalo) {
+            Pack<T> oa, ob;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                oa.v[e] = as_is ? h_da.v[e] : vaypx(bt, h_da.v[e], h_ra.v[e]);
+                ob.v[e] = as_is ? h_db.v[e] : vaypx(bt, h_db.v[e], h_rb.v[e]);
+            }
+            *reinterpret_cast<Pack<T> *>(wb + (size_t)h_pa * 16) = oa;
+            if (h_two) *reinterpret_cast<Pack<T> *>(wb + (size_t)h_pb * 16) = ob;
+        }
+        for (int hp = ht + 2 * kResThreads; hp < nhalo; hp += 2 * kResThreads) {
+            const int hq = hp + kResThreads;
+            const bool two = hq < nhalo;
+            const int pa = hp < nlow ? hp : hi0 + (hp - nlow), pb = two ? (hq < nlow ? hq : hi0 + (hq - nlow)) : pa;
+            const Pack<T> da_ = ld_pack_coh(dold_p + w0 + pa * E), ra_ = ld_pack_coh(a.r + w0 + pa * E);
+            const Pack<T> db_ = ld_pack_coh(dold_p + w0 + pb * E), rb_ = ld_pack_coh(a.r + w0 + pb * E);
+            Pack<T> oa, ob;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                oa.v[e] = as_is ? da_.v[e] : vaypx(bt, da_.v[e], ra_.v[e]);
+                ob.v[e] = as_is ? db_.v[e] : vaypx(bt, db_.v[e], rb_.v[e]);
+            }
+            *reinterpret_cast<Pack<T> *>(wb + (size_t)pa * 16) = oa;
+            if (two) *reinterpret_cast<Pack<T> *>(wb + (size_t)pb * 16) = ob;
+        }
+        __syncthreads();
+        // ---- q = A d_new for my rows, d.q
+        A dot = vzero<A>();
+#pragma unroll
+        for (int h = 0; h < RPT; ++h) {
+            T sum = vzero<T>();
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const unsigned off = (j & 1) ? mo2[h][j >> 1] >> 16 : mo2[h][j >> 1] & 0xffffu;
+                sum = vfma(mv[h][j], *reinterpret_cast<const T *>(wb + off), sum);
+            }
+            qs[t + h * kResThreads] = sum;
+            if (live[h]) dot = vadd(dot, to_acc(vmul(*reinterpret_cast<const T *>(wb + own_off[h]), sum)));
+        }
+        A tot = wg_sum(dot, sh);
+        if (t == 0) put_granule<false>(g_dq + (size_t)m * W, tag0 + 2 * k + 1, tot);
+        T al, al_unused;
+        if (!group_scalars<A, T>(a.G, sh, a.hdr, al, al_unused, [&](int i, A &v) { return get_granule(g_dq + (size_t)i * W, tag0 + 2 * k + 1, v); },
+                                 [&](A dq, T &o, T &u) {
+                                     const T dqT = from_acc<T>(dq);
+                                     o = from_acc<T>(acc_div(to_acc(dlt), to_acc(dqT)));
+                                     u = o;
+                                 })) return;
+        if (leader && t == 0) a.alpha[0] = al;
+        A acc = vzero<A>();
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (pk[j]) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const T qv = qs[(t + j * kResThreads) * E + e];
+                    px[j].v[e] = vadd(px[j].v[e], vmul(al, pd[j].v[e]));
+                    pr[j].v[e] = vsub(pr[j].v[e], vmul(al, qv));
+                    acc = vadd(acc, to_acc(vmul(pr[j].v[e], pr[j].v[e])));
+                }
+                st_pack_coh<false>(at_off(a.r, poff[j]), pr[j]);
+            }
+        tot = wg_sum(acc, sh);
+        if (t == 0) put_granule<false>(g_rr + (size_t)m * W, tag0 + 2 * k + 2, tot);
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+        if (pk[j]) st_pack(at_off(a.x, poff[j]), px[j]);
+    if (leader) {
+        T bfin, dnT;
+        if (!group_scalars<A, T>(a.G, sh, a.hdr, bfin, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * a.K, v); },
+                                 [&](A tot, T &b, T &dn) {
+                                     dn = from_acc<T>(tot);
+                                     b = from_acc<T>(acc_div(to_acc(dn), to_acc(dlt)));
+                                 })) return;
+        if (t == 0) {
+            const int it = a.it0 + a.K;
+            a.beta[0] = bfin;
+            a.delta[0] = dnT;
+            if (it < a.history_cap) a.history[it] = dnT;
+            *a.iter = it;
+            atomicAdd(a.hdr + kHdrSolved, 1u);
+        }
+    }
+}
+
+// widest column range of a `rows`-row slice (see resident_window_kernel) and the longest row: out[0], out[1]
+__global__ __launch_bounds__(kResThreads) void resident_wide_scan_kernel(int n, int E, int rows, const int *__restrict__ ptr, const int *__restrict__ cols,
+                                                                         int *out) {
+    __shared__ int smin, smax, slen;
+    const int t = threadIdx.x, R0 = blockIdx.x * rows;
+    if (t == 0) { smin = 0x7fffffff; smax = 0; slen = 0; }
+    __syncthreads();
+    const int r1 = min(R0 + rows, n), p0 = ptr[R0], p1 = ptr[r1];
+    int cmin = 0x7fffffff, cmax = 0, len = 0;
+    for (int i = p0 + t; i < p1; i += kResThreads) { cmin = min(cmin, cols[i]); cmax = max(cmax, cols[i]); }
+    for (int r = R0 + t; r < r1; r += kResThreads) len = max(len, ptr[r + 1] - ptr[r]);
+    atomicMin(&smin, cmin);
+    atomicMax(&smax, cmax);
+    atomicMax(&slen, len);
+    __syncthreads();
+    if (t == 0) {
+        const int w0 = min(smin, R0) & ~(E - 1);
+        atomicMax(out, max(smax, r1 - 1) - w0 + 1);
+        atomicMax(out + 1, slen);
+    }
+}
+
 std::mutex g_resident_mutex;   // one resident launch at a time per process: two of them could hold each other's CUs while groups form
 
 // ... and per GPU across the processes of this host (MPI ranks of the reference's driver sharing one GPU each call cg()): an
@@ -776,6 +1076,106 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
         return fail(CGAMD_ERR_HIP, "resident loop: " + std::string(hdr[kHdrError] == kErrSweep ? "a partial sum" : hdr[kHdrError] == kErrClaim ? "a group's claim" : "completion") +
                                        " timed out (solved " + std::to_string(hdr[kHdrSolved]) + " of " + std::to_string(nrhs) +
                                        " right-hand sides); cgamd_tune(\"resident\", 0) selects the two-launch loop");
+    return CGAMD_OK;
+}
+
+
+// ---- wide resident loop: host side ---------------------------------------------------------------------------------------
+template <typename T, int RPT, int U>
+static int resident_wide_launch(const ResWideArgs<T> &a, size_t lds, int grid, hipStream_t st) {
+    auto kern = cg_resident_wide_kernel<T, RPT, U>;
+    static thread_local size_t lds_set = 0;
+    if (lds > 64 * 1024 && lds > lds_set) {
+        const size_t want = std::min<size_t>((lds + 8191) & ~(size_t)8191, 152 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("wide resident loop: hipFuncSetAttribute: ") + hipGetErrorString(e));
+        lds_set = want;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kResThreads), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("wide resident loop launch: ") + hipGetErrorString(e));
+    return CGAMD_OK;
+}
+
+// Does the wide loop apply?  One right-hand side, rows of at most 8 entries, the whole system on at most n_cus work-groups of
+// 2048 / 4096 rows, the column range of a slice (+ q) within LDS.  Synchronises `st` (one pass over the matrix).
+int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev, const int *cols_dev, int *scratch_dev, hipStream_t st,
+                       ResidentWidePlan *out) {
+    out->ok = false;
+    const int mode = tune().resident_wide;
+    if (mode == 0 || nrhs != 1 || dtype == 3 || n_cus < 8) return CGAMD_OK;
+    const int E = (int)(16 / dtype_size(dtype));
+    if (n % E) return CGAMD_OK;
+    for (int rpt : {4, 8}) {
+        if (rpt % E) continue;
+        const int rows = kResThreads * rpt, G = (n + rows - 1) / rows;
+        if (G > std::min(n_cus, 256)) continue;
+        int h[2] = {0, 0};
+        CG_HIP(hipMemsetAsync(scratch_dev, 0, 8, st));
+        hipLaunchKernelGGL(resident_wide_scan_kernel, dim3(G), dim3(kResThreads), 0, st, n, E, rows, ptr_dev, cols_dev, scratch_dev);
+        CG_HIP(hipMemcpyAsync(h, scratch_dev, 8, hipMemcpyDeviceToHost, st));
+        CG_HIP(hipStreamSynchronize(st));
+        const int unroll = h[1] <= 5 ? 5 : h[1] <= 7 ? 7 : 8;
+        if (h[1] > 8 || (rpt == 8 && unroll != 5)) continue;           // instances: (4, 5), (4, 7), (4, 8), (8, 5)
+        const size_t lds = ((size_t)rows + (size_t)h[0] + 8) * dtype_size(dtype);
+        if (lds > 150 * 1024 || ((size_t)h[0] + 8) * dtype_size(dtype) >= 65536) continue;      // 16-bit window offsets
+        out->rpt = rpt; out->unroll = unroll; out->G = G;
+        out->wcap = (h[0] + 3 + 4) & ~3;
+        out->lds_bytes = ((size_t)rows + out->wcap) * dtype_size(dtype);
+        const size_t W = acc_size(dtype) / 4;
+        out->sync_bytes = (((size_t)kHdrWords * 4 + 8 + 2 * (size_t)G * W * 8) + 15) & ~(size_t)15;
+        out->ok = true;
+        return CGAMD_OK;
+    }
+    return CGAMD_OK;
+}
+
+template <typename T>
+static int resident_wide_impl(const ResidentWidePlan &wp, int n, const void *vals, const int *ptr, const int *cols, void *x, void *r, void *d0,
+                              void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int grid, hipStream_t st) {
+    using A = typename VT<T>::acc;
+    ResWideArgs<T> a;
+    a.n = n; a.G = wp.G; a.npack = n / Pack<T>::N; a.it0 = it0; a.K = K; a.history_cap = sc.history_cap; a.wcap = wp.wcap;
+    a.d_ready = d_ready ? 1 : 0;
+    a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
+    a.x = static_cast<T *>(x); a.r = static_cast<T *>(r); a.d0 = static_cast<T *>(d0); a.d1 = static_cast<T *>(d1);
+    a.alpha = (T *)sc.alpha; a.beta = (T *)sc.beta; a.delta = (T *)sc.delta; a.history = (T *)sc.history; a.iter = sc.iter;
+    a.hdr = static_cast<unsigned *>(sync);
+    a.slot_word = reinterpret_cast<u64 *>(static_cast<char *>(sync) + kHdrWords * 4);
+    a.gran = a.slot_word + 1;
+    (void)sizeof(A);
+    CG_HIP(hipMemsetAsync(sync, 0, wp.sync_bytes, st));
+    if (wp.rpt == 8) return resident_wide_launch<T, 8, 5>(a, wp.lds_bytes, grid, st);
+    if constexpr (Pack<T>::N <= 4) {
+        if (wp.unroll == 5) return resident_wide_launch<T, 4, 5>(a, wp.lds_bytes, grid, st);
+        if (wp.unroll == 7) return resident_wide_launch<T, 4, 7>(a, wp.lds_bytes, grid, st);
+        return resident_wide_launch<T, 4, 8>(a, wp.lds_bytes, grid, st);
+    }
+    return fail(CGAMD_ERR_INVALID, "wide resident loop: no instance");
+}
+
+// K iterations of the single right-hand side in one chip-wide launch; synchronises `st`
+int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, const void *vals, const int *ptr, const int *cols, void *x, void *r,
+                         void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st) {
+    if (K < 1 || K >= (1 << 18)) return fail(CGAMD_ERR_INVALID, "wide resident loop: iteration count per launch out of range");
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    int device = 0;
+    CG_HIP(hipGetDevice(&device));
+    DeviceFileLock device_lock(device);
+    int rc;
+    switch (dtype) {
+    case 0: rc = resident_wide_impl<float>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
+    case 1: rc = resident_wide_impl<double>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
+    case 2: rc = resident_wide_impl<float2>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
+    default: return fail(CGAMD_ERR_INVALID, "wide resident loop: bad dtype");
+    }
+    if (rc) return rc;
+    unsigned hdr[kHdrWords];
+    CG_HIP(hipMemcpyAsync(hdr, sync, sizeof(hdr), hipMemcpyDeviceToHost, st));
+    CG_HIP(hipStreamSynchronize(st));
+    if (hdr[kHdrError] != 0 || hdr[kHdrSolved] != 1u)
+        return fail(CGAMD_ERR_HIP, "wide resident loop: " + std::string(hdr[kHdrError] == kErrSweep ? "a partial sum" : hdr[kHdrError] == kErrClaim ? "the start line" : "completion") +
+                                       " timed out; cgamd_tune(\"resident_wide\", 0) selects the launched loops");
     return CGAMD_OK;
 }
 

@@ -57,6 +57,9 @@ struct cgamd_solver {
     ResidentPlan res;
     void *res_sync = nullptr;
     int n_cus = 0;
+    // wide resident loop: one chip-wide group for a single right-hand side (resident.hip)
+    ResidentWidePlan resw;
+    void *resw_sync = nullptr;
 };
 
 static void destroy_graphs(cgamd_solver *s) {
@@ -160,8 +163,24 @@ static int enqueue_iteration(cgamd_solver *s, int k, hipStream_t st) {
 }
 
 // the resident loop applies where the two-launch loop does and the matrix slices fit LDS (needs the row pointers on the host)
+static int setup_resident_wide(cgamd_solver *s) {
+    s->resw.ok = false;
+    if (tune().resident_wide == 0 || s->nrhs != 1 || s->rm_ok || (s->flags & CGAMD_UNFUSED)) return CGAMD_OK;
+    if (!aligned16(s->x) || !aligned16(s->r) || !aligned16(s->d) || !aligned16(s->d2)) return CGAMD_OK;
+    if (!s->n_cus) CG_HIP(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device));
+    ResidentWidePlan wp;
+    if (int rc = resident_wide_plan(s->dtype, s->n, s->nrhs, s->n_cus, s->ptr, s->cols, s->sc.iter, s->ctx->stream, &wp)) return rc;
+    if (!wp.ok) return CGAMD_OK;
+    if (s->resw_sync && wp.sync_bytes > s->resw.sync_bytes) { (void)hipFree(s->resw_sync); s->resw_sync = nullptr; }
+    if (!s->resw_sync)
+        if (int rc = dmalloc(&s->resw_sync, wp.sync_bytes, "wide resident sync words")) return rc;
+    s->resw = wp;
+    return CGAMD_OK;
+}
+
 static int setup_resident(cgamd_solver *s) {
     s->res_ok = false;
+    if (int rc = setup_resident_wide(s)) return rc;
     if (!s->fused2 || tune().resident == 0 || s->n > 65536) return CGAMD_OK;
     std::vector<int> tmp;
     const int *ph = s->ptr_host.size() == (size_t)s->n + 1 ? s->ptr_host.data() : nullptr;
@@ -360,7 +379,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
         if (s->cols) (void)hipFree(s->cols);
     }
     void *bufs[] = {s->slab, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
-                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync};
+                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync, s->resw_sync};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;
@@ -457,6 +476,28 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
     int left = nIterations, k = s->iters;
     const bool use_graph = !(s->flags & CGAMD_NO_GRAPH) && !s->graph_failed;
     const bool two = fused2_now(s);
+    if (s->resw.ok && !(two && s->res_ok) && !s->rm && !s->mdiag && !(s->flags & (CGAMD_NO_GRAPH | CGAMD_UNFUSED)) &&
+        nIterations >= std::max(1, tune().resident_min)) {
+        // one chip-wide resident group (single right-hand side, matrix rows in registers).  d ping-pongs inside the launch; handles
+        // of the launched loops that keep d in one buffer get it back there, and the launched loops' r.r partials are rebuilt.
+        const bool keeps_new_d = !two;       // three / four-launch loops: between iterations d already is beta d + r
+        for (int left = nIterations; left > 0;) {
+            const int K = std::min(left, 1 << 15);
+            void *cur = dbuf(s, s->iters), *other = cur == s->d ? s->d2 : s->d;
+            void *d0 = (s->iters & 1) ? other : cur, *d1 = (s->iters & 1) ? cur : other;
+            if (int rc = run_cg_resident_wide(s->dtype, s->resw, s->n, s->vals, s->ptr, s->cols, s->x, s->r, d0, d1, keeps_new_d && s->iters > 0,
+                                              s->sc, s->iters, K, s->resw_sync, s->n_cus, st))
+                return rc;
+            void *fin = ((s->iters + K) & 1) ? d1 : d0;
+            s->iters += K;
+            left -= K;
+            if (fin != dbuf(s, s->iters))
+                CG_HIP(hipMemcpyAsync(dbuf(s, s->iters), fin, (size_t)s->n * dtype_size(s->dtype), hipMemcpyDeviceToDevice, st));
+            if (keeps_new_d)                 // d = beta d + r with the beta the launch recorded last (clcg.c:415)
+                if (int rc = launch_aypx(s->dtype, s->n, s->r, dbuf(s, s->iters), s->n, s->sc.beta, 1, st)) return rc;
+        }
+        return launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, 1, s->part_rr, s->vgrid, st);
+    }
     if (two && s->res_ok && !(s->flags & CGAMD_NO_GRAPH) && nIterations >= std::max(1, tune().resident_min)) {
         // small system: the whole call in one launch per 2^15 iterations (resident.hip; a launch stays well below the bound of its
         // waits); same state, same bits as the loop below
@@ -608,7 +649,9 @@ int cgamd_solver_loop_launches(cgamd_solver *s) {
     if (s->flags & CGAMD_UNFUSED) return 8;
     if (s->rm) return 5;
     if (s->mdiag) return 4;
-    if (fused2_now(s)) return (s->res_ok && !(s->flags & CGAMD_NO_GRAPH)) ? 0 : 2;
+    if (fused2_now(s) && s->res_ok && !(s->flags & CGAMD_NO_GRAPH)) return 0;
+    if (s->resw.ok && !(s->flags & CGAMD_NO_GRAPH)) return 1;       // chip-wide resident group (not bit-identical to the launched loops)
+    if (fused2_now(s)) return 2;
     return fold_alpha_ok(s->plan.n_partials) ? 3 : 4;
 }
 

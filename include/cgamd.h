@@ -149,7 +149,8 @@ int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS
  * last cgamd_solver_set_rhs) */
 int cgamd_solver_layout(cgamd_solver *s);
 /* launches per iteration of the loop cgamd_solver_iterate runs for this handle: 0 = the resident loop (small systems: every
- * iteration of a call of at least `resident_min` iterations inside ONE launch, csrc/resident.hip), 2 / 3 / 4 / 5 = the
+ * iteration of a call of at least `resident_min` iterations inside ONE launch, csrc/resident.hip), 1 = its chip-wide form for a
+ * single right-hand side (one launch per call as well; partial sums per work-group, so not bit-identical to the others), 2 / 3 / 4 / 5 = the
  * loops of DESIGN.md section 4, 8 = the reference's op structure (CGAMD_UNFUSED); negative: error */
 int cgamd_solver_loop_launches(cgamd_solver *s);
 int cgamd_transpose(cgamd_ctx *ctx, int dtype, int rows, int cols, const void *in, void *out);

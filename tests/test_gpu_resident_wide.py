@@ -1,0 +1,62 @@
+"""Chip-wide resident loop (csrc/resident.hip, cg_resident_wide_kernel): one group of up to 256 work-groups for a single
+right-hand side, the matrix in registers, all iterations of an iterate() call in one launch -- BASELINE configs 2 (1M rows,
+2-D 5-point, fp64) and 3 (250k rows, helmFE_var(500), complex64).  It forms one partial sum per work-group, so it is held
+to the oracle (fp64: 1e-10 on delta_k, as every loop) and to the launched loop within rounding, not to bit-identity."""
+import numpy as np
+import pytest
+
+import cg_numpy
+import cg_oracle
+from conftest import rand_vec
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(pkg, ctx, ip, ix, da, b, calls, wide):
+    lib = pkg._lib.load()
+    pkg._lib.check(lib.cgamd_tune(b"resident_wide", int(wide)))
+    try:
+        s = pkg.Solver(ctx, len(ip) - 1, len(ix), da, ip, ix, 1)
+        s.set_rhs(b, None)
+        kind = lib.cgamd_solver_loop_launches(s.handle)
+        for c in calls:
+            s.iterate(c)
+        out = dict(x=s.x(), h=s.history(), kind=kind)
+        s.close()
+        return out
+    finally:
+        pkg._lib.check(lib.cgamd_tune(b"resident_wide", 0))
+
+
+@pytest.mark.parametrize("dtype,kind,calls", [
+    (np.float64, "poisson300", [24]),            # 90 000 rows: 44 work-groups of 2048 rows
+    (np.float64, "poisson1000", [16, 3, 12]),    # config 2 at full size: 245 work-groups of 4096 rows; a launched call in between
+    (np.complex64, "helm500", [24]),             # config 3 at full size: 123 work-groups of 2048 rows, 7 entries per row
+    (np.float32, "poisson300", [9, 9]),
+])
+def test_wide_resident_loop_against_oracle_and_launched_loop(pkg, gpu, dtype, kind, calls):
+    ctx, queue, kernels = gpu
+    if kind == "helm500":
+        N = 500
+        ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    else:
+        ip, ix, da = cg_numpy.poisson2d(int(kind[7:]))
+    n = len(ip) - 1
+    wide_t = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    rng = np.random.default_rng(n)
+    b = (1.0 + rand_vec(rng, n, wide_t)).astype(dtype)
+    A = da.astype(dtype)
+    w = _run(pkg, ctx, ip, ix, A, b, calls, True)
+    l = _run(pkg, ctx, ip, ix, A, b, calls, False)
+    assert w["kind"] == 1 and l["kind"] >= 2
+    iters = sum(calls)
+    cg_oracle.set_threads(16)
+    xo, ho = cg_oracle.cg(ip, ix, da.astype(wide_t), b.astype(wide_t), n_iterations=iters, mode=cg_oracle.MODE_FAST)
+    tol = 1e-10 if np.dtype(dtype) == np.float64 else 2e-3
+    assert w["h"].shape == ho.shape
+    upto = ho.shape[0] if np.dtype(dtype) == np.float64 else 13
+    assert np.max((np.abs(w["h"][:, 0] - ho[:, 0]) / np.abs(ho[:, 0]))[:upto]) < tol
+    # the launched loop of the same precision: same recurrence, different summation grouping
+    assert np.max((np.abs(w["h"] - l["h"]) / np.abs(l["h"]))[:upto]) < (1e-11 if np.dtype(dtype) == np.float64 else 2e-3)
+    ex = np.linalg.norm(w["x"] - l["x"]) / np.linalg.norm(l["x"])
+    assert ex < (1e-10 if np.dtype(dtype) == np.float64 else 5e-3), ex
