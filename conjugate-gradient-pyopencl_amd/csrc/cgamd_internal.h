@@ -84,8 +84,8 @@ struct Tuning {
                             // all iterations of an iterate() call in ONE launch (resident.hip); 0 = never, 2 = always in the cross-XCD
                             // form (write-through stores; up to 65536 rows; slower than launches, kept for the any-placement tests)
     int resident_min = 8;   // ... for iterate() calls of at least this many iterations
-    int resident_wide = 0;  // single right-hand side, larger systems (rows of <= 8 entries, <= 256 work-groups of 2048 / 4096 rows): one
-                            // chip-wide resident group, matrix in registers; 1 = on
+    int resident_wide = 1;  // single right-hand side, systems the one-XCD loop cannot hold (rows of <= 8 entries, <= 256 work-groups of 2048 /
+                            // 4096 rows: up to ~1M rows): one chip-wide resident group, matrix in registers; 0 = launched loops
     int resident_window = 1; // ... staging the column range of a member's rows in LDS once per iteration (0 = per-non-zero gathers)
     int spmm_wide_max = -1; // multi-RHS, RHS-major: largest row_blocks x nRHS for the one-work-group-per-RHS form (-1 = 4096, 0 = never)
     int spmv_slice_kb = 0;  // largest 256-row LDS slice the one-lane-per-row kernel accepts, in KB (0 = kMaxSliceBytes)

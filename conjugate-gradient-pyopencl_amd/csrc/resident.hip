@@ -625,7 +625,57 @@ template <typename T> struct ResWideArgs {
     int *iter;
     unsigned *hdr;
     u64 *slot_word, *gran;          // one slot; gran: [2][G * W]
+    u64 *xres;                      // [16 XCDs][2 reductions][4 words]: the scalars an XCD's first work-group publishes for the others
 };
+
+// The two scalars of a reduction for a chip-wide group.  Only ONE work-group per XCD (its first arriver) polls the members'
+// partial sums in memory and does the arithmetic; it hands the results to the other work-groups of its XCD through that
+// XCD's L2 (plain store, sc1-load poll): G pollers on the fabric become 8 (at G = 245 the all-poll form costs ~10 us of
+// an iteration).  The members' vector stores are in memory before their partial sums are (write-through, drained), so a
+// work-group that learns the result from its XCD's poller may load them.
+template <typename A, typename T, typename F, typename G, typename M = NoMid>
+CG_DEV bool xcd_scalars(int P, ResShared &sh, unsigned *hdr, T &o0, T &o1, F fetch, G finish, bool xlead, bool xpublish, u64 *xslot,
+                        unsigned tag, bool has_mid = false, M mid = M()) {
+    const int t = threadIdx.x;
+    if (xlead) {
+        if (!group_scalars<A, T>(P, sh, hdr, o0, o1, fetch, finish, has_mid, mid)) return false;
+        if (xpublish && t == 0) {
+            u64 b0 = 0, b1 = 0;
+            __builtin_memcpy(&b0, &o0, sizeof(T));
+            __builtin_memcpy(&b1, &o1, sizeof(T));
+            const u64 tg = (u64)tag << 32;
+            st_word<true>(xslot + 0, tg | (b0 & 0xffffffffull));
+            st_word<true>(xslot + 1, tg | (b0 >> 32));
+            st_word<true>(xslot + 2, tg | (b1 & 0xffffffffull));
+            st_word<true>(xslot + 3, tg | (b1 >> 32));
+        }
+        return true;
+    }
+    if (t < kWave) {
+        const long long t0 = wall_clock64();
+        u64 w = 0;
+        for (unsigned spins = 0;; ++spins) {
+            w = ld_word(xslot + (t & 3));
+            if (__all((unsigned)(w >> 32) == tag)) break;
+            if ((spins & 63) == 63 && (wall_clock64() - t0 > kResSpinTicks || ld_word(hdr + kHdrError) != 0)) {
+                if (t == 0) { atomicCAS(hdr + kHdrError, 0u, (unsigned)kErrSweep); sh.fail = 1; }
+                break;
+            }
+        }
+        const u64 lo0 = __shfl(w, 0, kWave) & 0xffffffffull, hi0 = __shfl(w, 1, kWave) & 0xffffffffull;
+        const u64 lo1 = __shfl(w, 2, kWave) & 0xffffffffull, hi1 = __shfl(w, 3, kWave) & 0xffffffffull;
+        if (t == 0) {
+            const u64 b0 = lo0 | (hi0 << 32), b1 = lo1 | (hi1 << 32);
+            __builtin_memcpy(&sh.bcT[0], &b0, sizeof(T));
+            __builtin_memcpy(&sh.bcT[1], &b1, sizeof(T));
+        }
+    }
+    __syncthreads();
+    if (has_mid) mid();
+    o0 = *reinterpret_cast<const T *>(&sh.bcT[0]);
+    o1 = *reinterpret_cast<const T *>(&sh.bcT[1]);
+    return sh.fail == 0;
+}
 
 // sum over the work-group in a fixed order (wave tree, then the 8 wave sums in order); every wave's outstanding stores are
 // acknowledged before the barrier; result valid in thread 0
@@ -666,6 +716,16 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
     const int m = __builtin_amdgcn_readfirstlane(sh.ctl[1]);
     if (m >= a.G) return;
     const bool leader = m == a.G - 1;                // drew the last ticket: every member is running
+    if (t == 0) {                                    // the first member on an XCD polls for all of them (xcd_scalars)
+        const unsigned xcc = xcc_id();
+        sh.ctl[0] = (int)xcc;
+        sh.ctl[2] = (int)atomicAdd(a.hdr + kHdrTicket + 8 + (xcc & 7u), 1u);
+    }
+    __syncthreads();
+    // small groups: every member polls for itself (the extra hop costs more than the pollers: 90k rows, G = 22: 5.9 against 7.1 us)
+    const bool xlead = a.G <= 32 || __builtin_amdgcn_readfirstlane(sh.ctl[2]) == 0;
+    const bool xpublish = a.G > 32;
+    u64 *xs_rr = a.xres + (size_t)(__builtin_amdgcn_readfirstlane(sh.ctl[0]) & 15) * 8, *xs_dq = xs_rr + 4;
     // ---- my rows: entries into registers (rows have at most U entries: the host checked)
     const int R0 = m * ROWS;
     constexpr int UP = (U + 1) / 2;
@@ -776,11 +836,11 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             halo_prefetch();
         } else if (it > 0) {
             T dnT;
-            if (!group_scalars<A, T>(a.G, sh, a.hdr, bt, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * k, v); },
-                                     [&](A tot, T &b, T &dn) {
-                                         dn = from_acc<T>(tot);
-                                         b = from_acc<T>(acc_div(to_acc(dn), to_acc(dlt)));
-                                     }, true, halo_prefetch)) return;
+            if (!xcd_scalars<A, T>(a.G, sh, a.hdr, bt, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * k, v); },
+                                   [&](A tot, T &b, T &dn) {
+                                       dn = from_acc<T>(tot);
+                                       b = from_acc<T>(acc_div(to_acc(dn), to_acc(dlt)));
+                                   }, xlead, xpublish, xs_rr, tag0 + 2 * k, true, halo_prefetch)) return;
             dlt = dnT;
             if (leader && t == 0) {
                 a.beta[0] = bt;
@@ -841,12 +901,12 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         A tot = wg_sum(dot, sh);
         if (t == 0) put_granule<false>(g_dq + (size_t)m * W, tag0 + 2 * k + 1, tot);
         T al, al_unused;
-        if (!group_scalars<A, T>(a.G, sh, a.hdr, al, al_unused, [&](int i, A &v) { return get_granule(g_dq + (size_t)i * W, tag0 + 2 * k + 1, v); },
-                                 [&](A dq, T &o, T &u) {
-                                     const T dqT = from_acc<T>(dq);
-                                     o = from_acc<T>(acc_div(to_acc(dlt), to_acc(dqT)));
-                                     u = o;
-                                 })) return;
+        if (!xcd_scalars<A, T>(a.G, sh, a.hdr, al, al_unused, [&](int i, A &v) { return get_granule(g_dq + (size_t)i * W, tag0 + 2 * k + 1, v); },
+                               [&](A dq, T &o, T &u) {
+                                   const T dqT = from_acc<T>(dq);
+                                   o = from_acc<T>(acc_div(to_acc(dlt), to_acc(dqT)));
+                                   u = o;
+                               }, xlead, xpublish, xs_dq, tag0 + 2 * k + 1)) return;
         if (leader && t == 0) a.alpha[0] = al;
         A acc = vzero<A>();
 #pragma unroll
@@ -1123,7 +1183,7 @@ int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev
         out->wcap = (h[0] + 3 + 4) & ~3;
         out->lds_bytes = ((size_t)rows + out->wcap) * dtype_size(dtype);
         const size_t W = acc_size(dtype) / 4;
-        out->sync_bytes = (((size_t)kHdrWords * 4 + 8 + 2 * (size_t)G * W * 8) + 15) & ~(size_t)15;
+        out->sync_bytes = (((size_t)kHdrWords * 4 + 8 + 2 * (size_t)G * W * 8 + 16 * 8 * 8) + 15) & ~(size_t)15;
         out->ok = true;
         return CGAMD_OK;
     }
@@ -1143,7 +1203,7 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, const void *val
     a.hdr = static_cast<unsigned *>(sync);
     a.slot_word = reinterpret_cast<u64 *>(static_cast<char *>(sync) + kHdrWords * 4);
     a.gran = a.slot_word + 1;
-    (void)sizeof(A);
+    a.xres = a.gran + 2 * (size_t)wp.G * (sizeof(A) / 4);
     CG_HIP(hipMemsetAsync(sync, 0, wp.sync_bytes, st));
     if (wp.rpt == 8) return resident_wide_launch<T, 8, 5>(a, wp.lds_bytes, grid, st);
     if constexpr (Pack<T>::N <= 4) {

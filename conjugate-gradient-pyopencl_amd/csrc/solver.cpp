@@ -165,7 +165,7 @@ static int enqueue_iteration(cgamd_solver *s, int k, hipStream_t st) {
 // the resident loop applies where the two-launch loop does and the matrix slices fit LDS (needs the row pointers on the host)
 static int setup_resident_wide(cgamd_solver *s) {
     s->resw.ok = false;
-    if (tune().resident_wide == 0 || s->nrhs != 1 || s->rm_ok || (s->flags & CGAMD_UNFUSED)) return CGAMD_OK;
+    if (tune().resident_wide == 0 || tune().resident == 0 || s->nrhs != 1 || s->rm_ok || (s->flags & CGAMD_UNFUSED)) return CGAMD_OK;
     if (!aligned16(s->x) || !aligned16(s->r) || !aligned16(s->d) || !aligned16(s->d2)) return CGAMD_OK;
     if (!s->n_cus) CG_HIP(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device));
     ResidentWidePlan wp;

@@ -135,28 +135,46 @@ def test_size_below_256_and_odd_sizes(pkg, gpu):
 
 
 def test_long_run_reproducible_across_graph_replays(pkg, gpu):
-    """300 iterations in 6 graph-replayed batches: bitwise reproducible run to run, and equal to plain launches"""
+    """300 iterations in 6 batches.  Launched loops (tuning knob resident = 0): graph-replayed batches are bitwise reproducible run
+    to run and equal to plain launches.  Default (490k rows, one right-hand side: the chip-wide resident loop): bitwise
+    reproducible run to run, and equal to the launched loops within rounding while the residual is alive."""
     import torch
     ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
     N = 700
     indptr, indices, data = pkg.generators.poisson2d(ctx, N, dtype=np.float64)
     n = N * N
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(11)
     b = torch.rand(n, dtype=torch.float64, device=dev, generator=g)
-    out = []
-    for flags in (0, 0, pkg._lib.NO_GRAPH):
-        s = pkg.Solver(ctx, n, indices.numel(), data, indptr, indices, 1, flags=pkg._lib.MATRIX_ON_DEVICE | flags, dtype=np.float64)
+
+    def run(flags, resident):
+        pkg._lib.check(lib.cgamd_tune(b"resident", resident))
+        try:
+            s = pkg.Solver(ctx, n, indices.numel(), data, indptr, indices, 1, flags=pkg._lib.MATRIX_ON_DEVICE | flags, dtype=np.float64)
+        finally:
+            pkg._lib.check(lib.cgamd_tune(b"resident", 1))
         torch.cuda.synchronize()
         s.set_rhs(b, None, on_device=True)
+        kind = lib.cgamd_solver_loop_launches(s.handle)
         for _ in range(6):
             s.iterate(50)
         x = s.x(torch.empty(n, dtype=torch.float64, device=dev))
-        out.append((x.clone(), s.history().copy()))
+        out = (x.clone(), s.history().copy(), kind)
         s.close()
+        return out
+
+    launched = [run(0, 0), run(0, 0), run(pkg._lib.NO_GRAPH, 0)]
+    assert all(o[2] >= 2 for o in launched)
     for k in (1, 2):
-        assert torch.equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1])
-    assert out[0][1].shape == (301, 1) and np.all(np.isfinite(out[0][1]))
+        assert torch.equal(launched[0][0], launched[k][0]) and np.array_equal(launched[0][1], launched[k][1])
+    assert launched[0][1].shape == (301, 1) and np.all(np.isfinite(launched[0][1]))
+    wide = [run(0, 1), run(0, 1)]
+    assert all(o[2] == 1 for o in wide)
+    assert torch.equal(wide[0][0], wide[1][0]) and np.array_equal(wide[0][1], wide[1][1])
+    hl, hw = launched[0][1][:, 0], wide[0][1][:, 0]
+    live = hl > 1e-6 * hl[0]
+    assert np.max(np.abs(hw - hl)[live] / hl[live]) < 1e-9
 
 
 def test_as_prec_shaped_batched_solve(pkg, gpu, golden):

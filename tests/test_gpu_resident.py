@@ -96,7 +96,7 @@ def _run(pkg, ctx, ip, ix, da, B, X0, nrhs, calls, knobs):
         return out
     finally:
         for k in knobs:
-            pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_min": 8, "resident_window": 1}.get(k, 0)))
+            pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_min": 8, "resident_window": 1, "resident_wide": 1}.get(k, 0)))
 
 
 CASES = [
@@ -183,8 +183,11 @@ def test_resident_loop_does_not_apply(pkg, gpu):
     ctx, queue, kernels = gpu
     lib = pkg._lib.load()
     ip, ix, da = cg_numpy.poisson2d(200)                    # 40000 rows: a group would span two XCDs
-    s = pkg.Solver(ctx, 40000, len(ix), da, ip, ix, 1)
+    s = pkg.Solver(ctx, 40000, len(ix), da, ip, ix, 2)
     assert lib.cgamd_solver_loop_launches(s.handle) == 2
+    s.close()
+    s = pkg.Solver(ctx, 40000, len(ix), da, ip, ix, 1)      # ... a single right-hand side takes the chip-wide form instead
+    assert lib.cgamd_solver_loop_launches(s.handle) == 1
     s.close()
     ip, ix, da = cg_numpy.poisson2d(37)                     # 1369 rows: odd, no 16-byte packs per right-hand side
     s = pkg.Solver(ctx, 1369, len(ix), da, ip, ix, 2)

@@ -25,7 +25,7 @@ def _run(pkg, ctx, ip, ix, da, b, calls, wide):
         s.close()
         return out
     finally:
-        pkg._lib.check(lib.cgamd_tune(b"resident_wide", 0))
+        pkg._lib.check(lib.cgamd_tune(b"resident_wide", 1))
 
 
 @pytest.mark.parametrize("dtype,kind,calls", [
