@@ -625,7 +625,7 @@ template <typename T> struct ResWideArgs {
     int *iter;
     unsigned *hdr;
     u64 *slot_word, *gran;          // one slot; gran: [2][G * W]
-    u64 *xres;                      // [16 XCDs][2 reductions][4 words]: the scalars an XCD's first work-group publishes for the others
+    u64 *xres;                      // [16 XCDs][2 reductions][8 words]: the scalars an XCD's first work-group publishes for the others
 };
 
 // The two scalars of a reduction for a chip-wide group.  Only ONE work-group per XCD (its first arriver) polls the members'
@@ -639,15 +639,13 @@ CG_DEV bool xcd_scalars(int P, ResShared &sh, unsigned *hdr, T &o0, T &o1, F fet
     const int t = threadIdx.x;
     if (xlead) {
         if (!group_scalars<A, T>(P, sh, hdr, o0, o1, fetch, finish, has_mid, mid)) return false;
-        if (xpublish && t == 0) {
-            u64 b0 = 0, b1 = 0;
-            __builtin_memcpy(&b0, &o0, sizeof(T));
-            __builtin_memcpy(&b1, &o1, sizeof(T));
+        if (xpublish && t == 0) {            // 32 payload bits per word under the tag: 2 scalars x sizeof(T) / 4 words (<= 8)
+            unsigned bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            __builtin_memcpy(bits, &o0, sizeof(T));
+            __builtin_memcpy(bits + 4, &o1, sizeof(T));
             const u64 tg = (u64)tag << 32;
-            st_word<true>(xslot + 0, tg | (b0 & 0xffffffffull));
-            st_word<true>(xslot + 1, tg | (b0 >> 32));
-            st_word<true>(xslot + 2, tg | (b1 & 0xffffffffull));
-            st_word<true>(xslot + 3, tg | (b1 >> 32));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st_word<true>(xslot + i, tg | bits[i]);
         }
         return true;
     }
@@ -655,19 +653,19 @@ CG_DEV bool xcd_scalars(int P, ResShared &sh, unsigned *hdr, T &o0, T &o1, F fet
         const long long t0 = wall_clock64();
         u64 w = 0;
         for (unsigned spins = 0;; ++spins) {
-            w = ld_word(xslot + (t & 3));
+            w = ld_word(xslot + (t & 7));
             if (__all((unsigned)(w >> 32) == tag)) break;
             if ((spins & 63) == 63 && (wall_clock64() - t0 > kResSpinTicks || ld_word(hdr + kHdrError) != 0)) {
                 if (t == 0) { atomicCAS(hdr + kHdrError, 0u, (unsigned)kErrSweep); sh.fail = 1; }
                 break;
             }
         }
-        const u64 lo0 = __shfl(w, 0, kWave) & 0xffffffffull, hi0 = __shfl(w, 1, kWave) & 0xffffffffull;
-        const u64 lo1 = __shfl(w, 2, kWave) & 0xffffffffull, hi1 = __shfl(w, 3, kWave) & 0xffffffffull;
+        unsigned bits[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bits[i] = (unsigned)__shfl(w, i, kWave);
         if (t == 0) {
-            const u64 b0 = lo0 | (hi0 << 32), b1 = lo1 | (hi1 << 32);
-            __builtin_memcpy(&sh.bcT[0], &b0, sizeof(T));
-            __builtin_memcpy(&sh.bcT[1], &b1, sizeof(T));
+            __builtin_memcpy(&sh.bcT[0], bits, sizeof(T));
+            __builtin_memcpy(&sh.bcT[1], bits + 4, sizeof(T));
         }
     }
     __syncthreads();
@@ -725,7 +723,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
     // small groups: every member polls for itself (the extra hop costs more than the pollers: 90k rows, G = 22: 5.9 against 7.1 us)
     const bool xlead = a.G <= 32 || __builtin_amdgcn_readfirstlane(sh.ctl[2]) == 0;
     const bool xpublish = a.G > 32;
-    u64 *xs_rr = a.xres + (size_t)(__builtin_amdgcn_readfirstlane(sh.ctl[0]) & 15) * 8, *xs_dq = xs_rr + 4;
+    u64 *xs_rr = a.xres + (size_t)(__builtin_amdgcn_readfirstlane(sh.ctl[0]) & 15) * 16, *xs_dq = xs_rr + 8;
     // ---- my rows: entries into registers (rows have at most U entries: the host checked)
     const int R0 = m * ROWS;
     constexpr int UP = (U + 1) / 2;
@@ -1163,11 +1161,11 @@ int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev
                        ResidentWidePlan *out) {
     out->ok = false;
     const int mode = tune().resident_wide;
-    if (mode == 0 || nrhs != 1 || dtype == 3 || n_cus < 8) return CGAMD_OK;
+    if (mode == 0 || nrhs != 1 || n_cus < 8) return CGAMD_OK;
     const int E = (int)(16 / dtype_size(dtype));
     if (n % E) return CGAMD_OK;
-    for (int rpt : {4, 8}) {
-        if (rpt % E) continue;
+    for (int rpt : {2, 4, 8}) {
+        if (rpt % E || (rpt == 2) != (dtype == 3)) continue;       // complex128 (16-byte values): two rows per thread, the others 4 or 8
         const int rows = kResThreads * rpt, G = (n + rows - 1) / rows;
         if (G > std::min(n_cus, 256)) continue;
         int h[2] = {0, 0};
@@ -1183,7 +1181,7 @@ int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev
         out->wcap = (h[0] + 3 + 4) & ~3;
         out->lds_bytes = ((size_t)rows + out->wcap) * dtype_size(dtype);
         const size_t W = acc_size(dtype) / 4;
-        out->sync_bytes = (((size_t)kHdrWords * 4 + 8 + 2 * (size_t)G * W * 8 + 16 * 8 * 8) + 15) & ~(size_t)15;
+        out->sync_bytes = (((size_t)kHdrWords * 4 + 8 + 2 * (size_t)G * W * 8 + 16 * 16 * 8) + 15) & ~(size_t)15;
         out->ok = true;
         return CGAMD_OK;
     }
@@ -1205,8 +1203,13 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, const void *val
     a.gran = a.slot_word + 1;
     a.xres = a.gran + 2 * (size_t)wp.G * (sizeof(A) / 4);
     CG_HIP(hipMemsetAsync(sync, 0, wp.sync_bytes, st));
-    if (wp.rpt == 8) return resident_wide_launch<T, 8, 5>(a, wp.lds_bytes, grid, st);
-    if constexpr (Pack<T>::N <= 4) {
+    if constexpr (sizeof(T) == 16) {
+        if (wp.unroll == 5) return resident_wide_launch<T, 2, 5>(a, wp.lds_bytes, grid, st);
+        if (wp.unroll == 7) return resident_wide_launch<T, 2, 7>(a, wp.lds_bytes, grid, st);
+        return resident_wide_launch<T, 2, 8>(a, wp.lds_bytes, grid, st);
+    } else if (wp.rpt == 8) {
+        return resident_wide_launch<T, 8, 5>(a, wp.lds_bytes, grid, st);
+    } else {
         if (wp.unroll == 5) return resident_wide_launch<T, 4, 5>(a, wp.lds_bytes, grid, st);
         if (wp.unroll == 7) return resident_wide_launch<T, 4, 7>(a, wp.lds_bytes, grid, st);
         return resident_wide_launch<T, 4, 8>(a, wp.lds_bytes, grid, st);
@@ -1227,6 +1230,7 @@ int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, const voi
     case 0: rc = resident_wide_impl<float>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
     case 1: rc = resident_wide_impl<double>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
     case 2: rc = resident_wide_impl<float2>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
+    case 3: rc = resident_wide_impl<double2>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
     default: return fail(CGAMD_ERR_INVALID, "wide resident loop: bad dtype");
     }
     if (rc) return rc;

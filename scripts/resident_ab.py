@@ -28,8 +28,8 @@ pkg = importlib.import_module("conjugate-gradient-pyopencl_amd")
 lib = pkg._lib.load()
 ctx = pkg.Context(0)
 dev = torch.device("cuda", 0)
-dt = {"c64": np.complex64, "f64": np.float64, "f32": np.float32}[args.dtype]
-if args.dtype == "c64":
+dt = {"c64": np.complex64, "c128": np.complex128, "f64": np.float64, "f32": np.float32}[args.dtype]
+if args.dtype in ("c64", "c128"):
     hp, hx, hd = cg_numpy.helm_fe_var(args.N, 12.0, np.ones((args.N - 1, args.N - 1)), 0.15, args.N, args.N)
 else:
     hp, hx, hd = cg_numpy.poisson2d(args.N)

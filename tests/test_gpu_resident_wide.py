@@ -33,6 +33,7 @@ def _run(pkg, ctx, ip, ix, da, b, calls, wide):
     (np.float64, "poisson1000", [16, 3, 12]),    # config 2 at full size: 245 work-groups of 4096 rows; a launched call in between
     (np.complex64, "helm500", [24]),             # config 3 at full size: 123 work-groups of 2048 rows, 7 entries per row
     (np.float32, "poisson300", [9, 9]),
+    (np.complex128, "helm500", [12, 12]),        # config 3 in the build's wide type: 245 work-groups of 1024 rows
 ])
 def test_wide_resident_loop_against_oracle_and_launched_loop(pkg, gpu, dtype, kind, calls):
     ctx, queue, kernels = gpu
@@ -52,11 +53,12 @@ def test_wide_resident_loop_against_oracle_and_launched_loop(pkg, gpu, dtype, ki
     iters = sum(calls)
     cg_oracle.set_threads(16)
     xo, ho = cg_oracle.cg(ip, ix, da.astype(wide_t), b.astype(wide_t), n_iterations=iters, mode=cg_oracle.MODE_FAST)
-    tol = 1e-10 if np.dtype(dtype) == np.float64 else 2e-3
+    tol = 1e-10 if np.dtype(dtype) in (np.dtype(np.float64), np.dtype(np.complex128)) else 2e-3
     assert w["h"].shape == ho.shape
-    upto = ho.shape[0] if np.dtype(dtype) == np.float64 else 13
+    wide64 = np.dtype(dtype) in (np.dtype(np.float64), np.dtype(np.complex128))
+    upto = ho.shape[0] if wide64 else 13
     assert np.max((np.abs(w["h"][:, 0] - ho[:, 0]) / np.abs(ho[:, 0]))[:upto]) < tol
     # the launched loop of the same precision: same recurrence, different summation grouping
-    assert np.max((np.abs(w["h"] - l["h"]) / np.abs(l["h"]))[:upto]) < (1e-11 if np.dtype(dtype) == np.float64 else 2e-3)
+    assert np.max((np.abs(w["h"] - l["h"]) / np.abs(l["h"]))[:upto]) < (1e-11 if wide64 else 2e-3)
     ex = np.linalg.norm(w["x"] - l["x"]) / np.linalg.norm(l["x"])
-    assert ex < (1e-10 if np.dtype(dtype) == np.float64 else 5e-3), ex
+    assert ex < (1e-10 if wide64 else 5e-3), ex
