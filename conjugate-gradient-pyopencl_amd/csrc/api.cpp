@@ -59,6 +59,8 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "resident_min") g_tune.resident_min = value;
     else if (k == "resident_window") g_tune.resident_window = value;
     else if (k == "resident_wide") g_tune.resident_wide = value;
+    else if (k == "resident_wide_rpt") g_tune.resident_wide_rpt = value;
+    else if (k == "resident_wide_min") g_tune.resident_wide_min = value;
     else if (k == "vec_nt") g_tune.vec_nt = value;
     else if (k == "vec_skew") g_tune.vec_skew = value & ~15;
     else known = false;

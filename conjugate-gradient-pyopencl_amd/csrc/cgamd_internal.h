@@ -86,6 +86,9 @@ struct Tuning {
     int resident_min = 8;   // ... for iterate() calls of at least this many iterations
     int resident_wide = 1;  // single right-hand side, systems the one-XCD loop cannot hold (rows of <= 8 entries, <= 256 work-groups of 2048 /
                             // 4096 rows: up to ~1M rows): one chip-wide resident group, matrix in registers; 0 = launched loops
+    int resident_wide_min = 16; // ... for iterate() calls of at least this many iterations (a launch costs ~70-150 us of set-up: break-even
+                               // against the launched loops at 4 / 12 / 24 iterations for 1M / 250k / 90k rows, scripts/short_calls.py)
+    int resident_wide_rpt = 0; // rows per thread of the chip-wide loop: 0 = the smallest that fits (4, then 8), or 4 / 8
     int resident_window = 1; // ... staging the column range of a member's rows in LDS once per iteration (0 = per-non-zero gathers)
     int spmm_wide_max = -1; // multi-RHS, RHS-major: largest row_blocks x nRHS for the one-work-group-per-RHS form (-1 = 4096, 0 = never)
     int spmv_slice_kb = 0;  // largest 256-row LDS slice the one-lane-per-row kernel accepts, in KB (0 = kMaxSliceBytes)

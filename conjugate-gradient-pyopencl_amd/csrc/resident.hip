@@ -1161,11 +1161,14 @@ int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev
                        ResidentWidePlan *out) {
     out->ok = false;
     const int mode = tune().resident_wide;
-    if (mode == 0 || nrhs != 1 || n_cus < 8) return CGAMD_OK;
+    // systems the one-XCD loop could hold by size stay with the loops that are bit-identical to each other
+    if (mode == 0 || nrhs != 1 || n_cus < 8 || n <= 32768) return CGAMD_OK;
     const int E = (int)(16 / dtype_size(dtype));
     if (n % E) return CGAMD_OK;
+    const int forced = tune().resident_wide_rpt;
     for (int rpt : {2, 4, 8}) {
         if (rpt % E || (rpt == 2) != (dtype == 3)) continue;       // complex128 (16-byte values): two rows per thread, the others 4 or 8
+        if (forced > 0 && dtype != 3 && rpt != forced) continue;
         const int rows = kResThreads * rpt, G = (n + rows - 1) / rows;
         if (G > std::min(n_cus, 256)) continue;
         int h[2] = {0, 0};

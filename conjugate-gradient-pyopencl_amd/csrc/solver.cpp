@@ -477,7 +477,7 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
     const bool use_graph = !(s->flags & CGAMD_NO_GRAPH) && !s->graph_failed;
     const bool two = fused2_now(s);
     if (s->resw.ok && !(two && s->res_ok) && !s->rm && !s->mdiag && !(s->flags & (CGAMD_NO_GRAPH | CGAMD_UNFUSED)) &&
-        nIterations >= std::max(1, tune().resident_min)) {
+        nIterations >= std::max(1, tune().resident_wide_min)) {
         // one chip-wide resident group (single right-hand side, matrix rows in registers).  d ping-pongs inside the launch; handles
         // of the launched loops that keep d in one buffer get it back there, and the launched loops' r.r partials are rebuilt.
         const bool keeps_new_d = !two;       // three / four-launch loops: between iterations d already is beta d + r
