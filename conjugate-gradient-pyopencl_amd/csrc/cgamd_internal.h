@@ -88,6 +88,9 @@ struct Tuning {
                             // 4096 rows: up to ~1M rows): one chip-wide resident group, matrix in registers; 0 = launched loops
     int resident_wide_min = 16; // ... for iterate() calls of at least this many iterations (a launch costs ~70-150 us of set-up: break-even
                                // against the launched loops at 4 / 12 / 24 iterations for 1M / 250k / 90k rows, scripts/short_calls.py)
+    int resident_claim_ms = 15000; // resident loops: how long work-groups wait for their group to fill (CUs held by other kernels) before the
+                               // launch gives up untouched and the handle goes back to the launched loops
+    int resident_test_short_grid = 0; // test hook: launch one work-group too few, so that no group can fill
     int resident_wide_rpt = 0; // rows per thread of the chip-wide loop: 0 = the smallest that fits (4, then 8), or 4 / 8
     int resident_window = 1; // ... staging the column range of a member's rows in LDS once per iteration (0 = per-non-zero gathers)
     int spmm_wide_max = -1; // multi-RHS, RHS-major: largest row_blocks x nRHS for the one-work-group-per-RHS form (-1 = 4096, 0 = never)
@@ -225,7 +228,7 @@ int resident_max_window(int dtype, int n, const int *ptr_dev, const int *cols_de
 // sync: rp.sync_bytes of device memory.
 int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
                     void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
-                    int n_cus, hipStream_t st);
+                    int n_cus, hipStream_t st, bool *untouched = nullptr);
 
 // wide resident loop (resident.hip): one chip-wide group for ONE right-hand side, matrix rows in registers
 struct ResidentWidePlan {
@@ -239,7 +242,8 @@ int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev
 // already beta d + r (three / four-launch loops); on exit d is always the direction of the last iteration (two-launch
 // convention) and the launched loops' r.r partials are NOT maintained -- the caller converts / rebuilds
 int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, const void *vals, const int *ptr, const int *cols, void *x, void *r,
-                         void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st);
+                         void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st,
+                         bool *untouched = nullptr);
 
 // [rows][cols] -> [cols][rows]: RHS-major (the reference ABI) <-> row-major
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);

@@ -45,7 +45,6 @@ constexpr int kResThreads = 512;                // threads per work-group
 constexpr int kResMaxRows = 65536;              // 256 d.q partials: one per polling thread
 constexpr int kResRows = 1024;                  // rows per member: every thread walks two (4 virtual blocks of 256 rows)
 constexpr long long kResSpinTicks = 400000000;  // a partial sum that does not arrive: 4 s of the 100 MHz wall clock
-constexpr long long kResClaimTicks = 1500000000; // a group that does not fill (its work-groups queue behind other kernels): 15 s
 
 // header words (unsigned), zeroed before every launch
 enum { kHdrTicket = 0 /* [16] */, kHdrNextRhs = 16, kHdrSolved = 17, kHdrError = 18, kHdrWords = 32 };
@@ -66,6 +65,7 @@ template <typename T> struct ResArgs {
     u64 *slot_word;                 // [slots] {claim sequence, rhs}; slot = xcc * lg + group of that XCD
     u64 *gran;                      // [slots][2][gran_stride] granule words
     int gran_stride, lg;            // lg: groups per ticket counter (per XCD when LOCAL)
+    long long claim_ticks;          // bound (100 MHz ticks) of the wait for a group to fill while nothing has started
     long long *prof;                // diagnostics (CGAMD_RESIDENT_PROF=1): phase times of one work-group, s_memtime ticks
 };
 #define RES_STAMP(i)                                                                   \
@@ -360,7 +360,9 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
                     const u64 w = ld_word(a.slot_word + slot);
                     if ((unsigned)(w >> 32) == seq) { rhs = (int)(unsigned)w; break; }
                     if (ld_word(a.hdr + kHdrSolved) >= (unsigned)a.nrhs) break;           // every solve is done: nothing left for anyone
-                    if ((spins & 63) == 63 && (wall_clock64() - t0 > kResClaimTicks || ld_word(a.hdr + kHdrError) != 0)) {
+                    // gives up only while NO group has claimed anything: then no vector has been touched and the host can take the
+                    // launched loops instead; once a group works, the others wait for it however long its solves take
+                    if ((spins & 63) == 63 && ((wall_clock64() - t0 > a.claim_ticks && ld_word(a.hdr + kHdrNextRhs) == 0) || ld_word(a.hdr + kHdrError) != 0)) {
                         atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrClaim);
                         break;
                     }
@@ -617,6 +619,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
 // =================================================================================================
 template <typename T> struct ResWideArgs {
     int n, G, npack, it0, K, history_cap, wcap;
+    long long claim_ticks;          // bound of the wait at the start line
     int d_ready;                    // the caller's d already is beta d + r (state of the three / four-launch loops): iteration it0 + 1 takes it as is
     const T *vals;
     const int *ptr, *cols;
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             const long long t0 = wall_clock64();
             for (unsigned spins = 0;; ++spins) {
                 if ((ld_word(a.slot_word) >> 32) == 1ull) break;
-                if ((spins & 63) == 63 && (wall_clock64() - t0 > kResClaimTicks || ld_word(a.hdr + kHdrError) != 0)) {
+                if ((spins & 63) == 63 && (wall_clock64() - t0 > a.claim_ticks || ld_word(a.hdr + kHdrError) != 0)) {
                     atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrClaim);
                     sh.fail = 1;
                     break;
@@ -1087,6 +1090,7 @@ static int resident_impl(const ResidentPlan &rp, int n, int nrhs, const void *va
     a.gran = a.slot_word + rp.slots;
     a.gran_stride = row_blocks * W;
     a.lg = rp.lg;
+    a.claim_ticks = (long long)std::max(1, tune().resident_claim_ms) * 100000;
     if (getenv("CGAMD_RESIDENT_PROF") && !g_prof_dev) CG_HIP(hipMalloc(&g_prof_dev, 64));
     a.prof = g_prof_dev;
     if (g_prof_dev) CG_HIP(hipMemsetAsync(g_prof_dev, 0, 64, st));
@@ -1111,13 +1115,15 @@ int resident_max_window(int dtype, int n, const int *ptr, const int *cols, int *
 // K iterations of every right-hand side in one launch; synchronises `st` and reports a time-out inside the launch
 int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
                     void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
-                    int n_cus, hipStream_t st) {
+                    int n_cus, hipStream_t st, bool *untouched) {
     if (K < 1 || K >= (1 << 18)) return fail(CGAMD_ERR_INVALID, "resident loop: iteration count per launch out of range");
     std::lock_guard<std::mutex> lock(g_resident_mutex);
     int device = 0;
     CG_HIP(hipGetDevice(&device));
     DeviceFileLock device_lock(device);
-    const int grid = n_cus;            // one work-group per CU; groups form from whatever is running (see the header comment)
+    // one work-group per CU; groups form from whatever is running (see the header comment).  Test hook: a grid too small for any group.
+    const int grid = tune().resident_test_short_grid ? std::max(1, rp.G - 1) : n_cus;
+    if (untouched) *untouched = false;
     int rc;
     switch (dtype) {
     case 0: rc = resident_impl<float>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st); break;
@@ -1130,6 +1136,10 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
     CG_HIP(hipMemcpyAsync(hdr, sync, sizeof(hdr), hipMemcpyDeviceToHost, st));
     CG_HIP(hipStreamSynchronize(st));
     if (getenv("CGAMD_RESIDENT_PROF")) resident_print_prof(K, st);
+    if (untouched && hdr[kHdrError] == kErrClaim && hdr[kHdrSolved] == 0 && hdr[kHdrNextRhs] == 0) {
+        *untouched = true;          // no group ever filled: nothing was read or written
+        return fail(CGAMD_ERR_STATE, "resident loop: no group of work-groups became resident within " + std::to_string(tune().resident_claim_ms) + " ms");
+    }
     if (hdr[kHdrError] != 0 || hdr[kHdrSolved] != (unsigned)nrhs)
         return fail(CGAMD_ERR_HIP, "resident loop: " + std::string(hdr[kHdrError] == kErrSweep ? "a partial sum" : hdr[kHdrError] == kErrClaim ? "a group's claim" : "completion") +
                                        " timed out (solved " + std::to_string(hdr[kHdrSolved]) + " of " + std::to_string(nrhs) +
@@ -1198,6 +1208,7 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, const void *val
     ResWideArgs<T> a;
     a.n = n; a.G = wp.G; a.npack = n / Pack<T>::N; a.it0 = it0; a.K = K; a.history_cap = sc.history_cap; a.wcap = wp.wcap;
     a.d_ready = d_ready ? 1 : 0;
+    a.claim_ticks = (long long)std::max(1, tune().resident_claim_ms) * 100000;
     a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
     a.x = static_cast<T *>(x); a.r = static_cast<T *>(r); a.d0 = static_cast<T *>(d0); a.d1 = static_cast<T *>(d1);
     a.alpha = (T *)sc.alpha; a.beta = (T *)sc.beta; a.delta = (T *)sc.delta; a.history = (T *)sc.history; a.iter = sc.iter;
@@ -1222,8 +1233,11 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, const void *val
 
 // K iterations of the single right-hand side in one chip-wide launch; synchronises `st`
 int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, const void *vals, const int *ptr, const int *cols, void *x, void *r,
-                         void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st) {
+                         void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st,
+                         bool *untouched) {
     if (K < 1 || K >= (1 << 18)) return fail(CGAMD_ERR_INVALID, "wide resident loop: iteration count per launch out of range");
+    if (untouched) *untouched = false;
+    if (tune().resident_test_short_grid) n_cus = std::max(1, wp.G - 1);      // test hook: the group can never fill
     std::lock_guard<std::mutex> lock(g_resident_mutex);
     int device = 0;
     CG_HIP(hipGetDevice(&device));
@@ -1240,6 +1254,10 @@ int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, const voi
     unsigned hdr[kHdrWords];
     CG_HIP(hipMemcpyAsync(hdr, sync, sizeof(hdr), hipMemcpyDeviceToHost, st));
     CG_HIP(hipStreamSynchronize(st));
+    if (untouched && hdr[kHdrError] == kErrClaim && hdr[kHdrSolved] == 0) {
+        *untouched = true;          // the group never passed its start line: nothing was read or written
+        return fail(CGAMD_ERR_STATE, "wide resident loop: the group did not become resident within " + std::to_string(tune().resident_claim_ms) + " ms");
+    }
     if (hdr[kHdrError] != 0 || hdr[kHdrSolved] != 1u)
         return fail(CGAMD_ERR_HIP, "wide resident loop: " + std::string(hdr[kHdrError] == kErrSweep ? "a partial sum" : hdr[kHdrError] == kErrClaim ? "the start line" : "completion") +
                                        " timed out; cgamd_tune(\"resident_wide\", 0) selects the launched loops");

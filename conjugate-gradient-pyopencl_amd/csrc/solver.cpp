@@ -485,9 +485,14 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
             const int K = std::min(left, 1 << 15);
             void *cur = dbuf(s, s->iters), *other = cur == s->d ? s->d2 : s->d;
             void *d0 = (s->iters & 1) ? other : cur, *d1 = (s->iters & 1) ? cur : other;
+            bool untouched = false;
             if (int rc = run_cg_resident_wide(s->dtype, s->resw, s->n, s->vals, s->ptr, s->cols, s->x, s->r, d0, d1, keeps_new_d && s->iters > 0,
-                                              s->sc, s->iters, K, s->resw_sync, s->n_cus, st))
-                return rc;
+                                              s->sc, s->iters, K, s->resw_sync, s->n_cus, st, &untouched)) {
+                if (!untouched) return rc;
+                s->resw.ok = false;          // the chip is shared with something that does not yield: this handle keeps the launched loops
+                if (int rc2 = launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, 1, s->part_rr, s->vgrid, st)) return rc2;
+                return cgamd_solver_iterate(s, left);
+            }
             void *fin = ((s->iters + K) & 1) ? d1 : d0;
             s->iters += K;
             left -= K;
@@ -503,9 +508,13 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
         // waits); same state, same bits as the loop below
         for (int left = nIterations; left > 0;) {
             const int K = std::min(left, 1 << 15);
+            bool untouched = false;
             if (int rc = run_cg_resident(s->dtype, s->res, s->n, s->nrhs, s->vals, s->ptr, s->cols, s->x, s->r, s->d, s->d2, s->part_rr,
-                                         s->vgrid, s->plan.n_partials, s->sc, s->iters, K, s->res_sync, s->n_cus, st))
-                return rc;
+                                         s->vgrid, s->plan.n_partials, s->sc, s->iters, K, s->res_sync, s->n_cus, st, &untouched)) {
+                if (!untouched) return rc;
+                s->res_ok = false;           // no group could form (CUs held by other work): this handle keeps the launched loops
+                return cgamd_solver_iterate(s, left);
+            }
             s->iters += K;
             left -= K;
         }

@@ -62,3 +62,36 @@ def test_wide_resident_loop_against_oracle_and_launched_loop(pkg, gpu, dtype, ki
     assert np.max((np.abs(w["h"] - l["h"]) / np.abs(l["h"]))[:upto]) < (1e-11 if wide64 else 2e-3)
     ex = np.linalg.norm(w["x"] - l["x"]) / np.linalg.norm(l["x"])
     assert ex < (1e-10 if wide64 else 5e-3), ex
+
+
+@pytest.mark.parametrize("n_side,nrhs,want_kind", [(128, 3, 0), (300, 1, 1)])
+def test_resident_launch_that_cannot_form_its_group_falls_back_untouched(pkg, gpu, n_side, nrhs, want_kind):
+    """CUs held by other work: a resident launch whose group never fills gives up before touching anything (bounded wait), and
+    the handle continues with the launched loops -- same result as if the resident loop had been switched off.  Provoked with the
+    test hook that launches one work-group too few."""
+    ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
+    ip, ix, da = cg_numpy.poisson2d(n_side)
+    n = n_side * n_side
+    b = np.tile(np.linspace(1.0, 2.0, n), nrhs)
+
+    def run(knobs):
+        for k, v in knobs.items():
+            pkg._lib.check(lib.cgamd_tune(k.encode(), v))
+        try:
+            s = pkg.Solver(ctx, n, len(ix), da, ip, ix, nrhs)
+            s.set_rhs(b, None)
+            before = lib.cgamd_solver_loop_launches(s.handle)
+            s.iterate(20)
+            s.iterate(20)
+            out = (s.x(), s.history(), before, lib.cgamd_solver_loop_launches(s.handle))
+            s.close()
+            return out
+        finally:
+            for k in knobs:
+                pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_claim_ms": 15000}.get(k, 0)))
+
+    x0, h0, _, k0 = run({"resident": 0})
+    x1, h1, before, after = run({"resident_test_short_grid": 1, "resident_claim_ms": 40})
+    assert before == want_kind and after == k0 >= 2          # resident loop chosen at first, launched loops after the failed launch
+    assert np.array_equal(h1, h0) and np.array_equal(x1, x0)
