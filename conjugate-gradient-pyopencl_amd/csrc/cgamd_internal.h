@@ -230,10 +230,10 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
                     void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
                     int n_cus, hipStream_t st, bool *untouched = nullptr);
 
-// wide resident loop (resident.hip): one chip-wide group for ONE right-hand side, matrix rows in registers
+// wide resident loop (resident.hip): chip-wide groups (one right-hand side each at a time), matrix rows in registers
 struct ResidentWidePlan {
     bool ok = false;
-    int rpt = 0, unroll = 0, G = 0, wcap = 0;
+    int rpt = 0, unroll = 0, G = 0, NG = 1, wcap = 0;      // NG concurrent groups of G work-groups
     size_t lds_bytes = 0, sync_bytes = 0;
 };
 int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev, const int *cols_dev, int *scratch_dev, hipStream_t st,
@@ -241,8 +241,8 @@ int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev
 // state in and out: x, r, d of iteration k in (k & 1 ? d1 : d0), delta / beta / alpha / history / iter; d_ready: on entry d is
 // already beta d + r (three / four-launch loops); on exit d is always the direction of the last iteration (two-launch
 // convention) and the launched loops' r.r partials are NOT maintained -- the caller converts / rebuilds
-int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, const void *vals, const int *ptr, const int *cols, void *x, void *r,
-                         void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st,
+int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x,
+                         void *r, void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st,
                          bool *untouched = nullptr);
 
 // [rows][cols] -> [cols][rows]: RHS-major (the reference ABI) <-> row-major

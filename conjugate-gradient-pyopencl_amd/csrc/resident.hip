@@ -618,7 +618,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
 // like them); the host recomputes the launched loops' r.r partials after a call, so the two can alternate on one handle.
 // =================================================================================================
 template <typename T> struct ResWideArgs {
-    int n, G, npack, it0, K, history_cap, wcap;
+    int n, nrhs, G, NG, npack, it0, K, history_cap, wcap;     // NG groups of G members; a group solves one right-hand side at a time
     long long claim_ticks;          // bound of the wait at the start line
     int d_ready;                    // the caller's d already is beta d + r (state of the three / four-launch loops): iteration it0 + 1 takes it as is
     const T *vals;
@@ -627,8 +627,9 @@ template <typename T> struct ResWideArgs {
     T *alpha, *beta, *delta, *history;
     int *iter;
     unsigned *hdr;
-    u64 *slot_word, *gran;          // one slot; gran: [2][G * W]
-    u64 *xres;                      // [16 XCDs][2 reductions][8 words]: the scalars an XCD's first work-group publishes for the others
+    u64 *slot_word, *gran;          // slot_word[NG]; gran: [NG][2][G * W]
+    u64 *xres;                      // [NG][16 XCDs][2 reductions][8 words]: the scalars an XCD's first work-group publishes for the others
+    unsigned *xcnt;                 // [NG][8] arrivals of a group's members per XCD
 };
 
 // The two scalars of a reduction for a chip-wide group.  Only ONE work-group per XCD (its first arriver) polls the members'
@@ -714,19 +715,20 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         sh.cmax = 0;
     }
     __syncthreads();
-    const int m = __builtin_amdgcn_readfirstlane(sh.ctl[1]);
-    if (m >= a.G) return;
-    const bool leader = m == a.G - 1;                // drew the last ticket: every member is running
-    if (t == 0) {                                    // the first member on an XCD polls for all of them (xcd_scalars)
+    const int ticket = __builtin_amdgcn_readfirstlane(sh.ctl[1]);
+    const int grp = ticket / a.G, m = ticket - grp * a.G;     // tickets [g G, g G + G) are group g: one right-hand side at a time each
+    if (grp >= a.NG) return;
+    const bool leader = m == a.G - 1;                // drew the group's last ticket: every member is running
+    if (t == 0) {                                    // the first member of the group on an XCD polls for the others there (xcd_scalars)
         const unsigned xcc = xcc_id();
         sh.ctl[0] = (int)xcc;
-        sh.ctl[2] = (int)atomicAdd(a.hdr + kHdrTicket + 8 + (xcc & 7u), 1u);
+        sh.ctl[2] = (int)atomicAdd(a.xcnt + grp * 8 + (xcc & 7u), 1u);
     }
     __syncthreads();
     // small groups: every member polls for itself (the extra hop costs more than the pollers: 90k rows, G = 22: 5.9 against 7.1 us)
     const bool xlead = a.G <= 32 || __builtin_amdgcn_readfirstlane(sh.ctl[2]) == 0;
     const bool xpublish = a.G > 32;
-    u64 *xs_rr = a.xres + (size_t)(__builtin_amdgcn_readfirstlane(sh.ctl[0]) & 15) * 16, *xs_dq = xs_rr + 8;
+    u64 *xs_rr = a.xres + ((size_t)grp * 16 + (size_t)(__builtin_amdgcn_readfirstlane(sh.ctl[0]) & 15)) * 16, *xs_dq = xs_rr + 8;
     // ---- my rows: entries into registers (rows have at most U entries: the host checked)
     const int R0 = m * ROWS;
     constexpr int UP = (U + 1) / 2;
@@ -771,27 +773,40 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         for (int j = 0; j < UP; ++j) mo2[h][j] = (unsigned)mo[h][2 * j] | ((2 * j + 1 < U ? (unsigned)mo[h][2 * j + 1] : 0u) << 16);
     }
     if (t == 0) win[a.wcap - 1] = vzero<T>();
-    u64 *g_dq = a.gran, *g_rr = a.gran + (size_t)a.G * W;
+    u64 *g_dq = a.gran + (size_t)grp * 2 * a.G * W, *g_rr = g_dq + (size_t)a.G * W;
+    u64 *slot = a.slot_word + grp;
+    char *wb = reinterpret_cast<char *>(win);
+    const int ht = kResThreads - 1 - t;              // the last waves load the halo (wave 0 does the divisions)
 
-    // ---- start line: nobody touches the vectors before the whole group runs (a work-group queued behind other kernels)
+    for (unsigned seq = 1;; ++seq) {
+    // ---- which right-hand side: the leader claims, the others wait for its word.  The first word is also the start line: nobody
+    // touches a vector before the whole group runs (a work-group queued behind other kernels)
     if (t == 0) {
+        int rhs = -1;
         if (leader) {
-            __hip_atomic_store(a.slot_word, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rhs = (int)atomicAdd(a.hdr + kHdrNextRhs, 1u);
+            __hip_atomic_store(slot, ((u64)seq << 32) | (unsigned)rhs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             const long long t0 = wall_clock64();
             for (unsigned spins = 0;; ++spins) {
-                if ((ld_word(a.slot_word) >> 32) == 1ull) break;
-                if ((spins & 63) == 63 && (wall_clock64() - t0 > a.claim_ticks || ld_word(a.hdr + kHdrError) != 0)) {
+                const u64 w = ld_word(slot);
+                if ((unsigned)(w >> 32) == seq) { rhs = (int)(unsigned)w; break; }
+                if (ld_word(a.hdr + kHdrSolved) >= (unsigned)a.nrhs) break;
+                if ((spins & 63) == 63 && ((wall_clock64() - t0 > a.claim_ticks && ld_word(a.hdr + kHdrNextRhs) == 0) || ld_word(a.hdr + kHdrError) != 0)) {
                     atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrClaim);
-                    sh.fail = 1;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(8);
             }
         }
+        sh.ctl[3] = rhs;
     }
     __syncthreads();
-    if (sh.fail) return;
+    const int rhs = __builtin_amdgcn_readfirstlane(sh.ctl[3]);
+    __syncthreads();
+    if (rhs < 0 || rhs >= a.nrhs) return;
+    const long long voff = (long long)rhs * a.n;
+    T *xr = a.x + voff, *rr = a.r + voff, *d0r = a.d0 + voff, *d1r = a.d1 + voff;
 
     Pack<T> px[PPT], pr[PPT], pd[PPT];
     bool pk[PPT];
@@ -803,20 +818,18 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         pk[j] = pack < a.npack;
         poff[j] = (unsigned)pack * 16u;
         if (pk[j]) {
-            px[j] = ld_pack(at_off(a.x, poff[j]));
-            pr[j] = ld_pack(at_off(a.r, poff[j]));
-            pd[j] = ld_pack(at_off((a.it0 & 1) ? a.d1 : a.d0, poff[j]));
+            px[j] = ld_pack(at_off(xr, poff[j]));
+            pr[j] = ld_pack(at_off(rr, poff[j]));
+            pd[j] = ld_pack(at_off((a.it0 & 1) ? d1r : d0r, poff[j]));
         }
     }
-    T dlt = a.delta[0];
-    const unsigned tag0 = 1u << 20;
-    char *wb = reinterpret_cast<char *>(win);
-    const int ht = kResThreads - 1 - t;              // the last waves load the halo (wave 0 does the divisions)
+    T dlt = a.delta[rhs];
+    const unsigned tag0 = seq << 20;
 
     for (int k = 0; k < a.K; ++k) {
         const int it = a.it0 + k;
-        const T *dold_p = (it & 1) ? a.d1 : a.d0;
-        T *dnew_p = (it & 1) ? a.d0 : a.d1;
+        const T *dold_p = (it & 1) ? d1r : d0r;
+        T *dnew_p = (it & 1) ? d0r : d1r;
         Pack<T> h_da, h_ra, h_db, h_rb;
         int h_pa = 0, h_pb = 0;
         bool h_two = false;
@@ -826,14 +839,14 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                 h_two = hq < nhalo;
                 h_pa = ht < nlow ? ht : hi0 + (ht - nlow);
                 h_pb = h_two ? (hq < nlow ? hq : hi0 + (hq - nlow)) : h_pa;
-                h_da = ld_pack_coh(dold_p + w0 + h_pa * E); h_ra = ld_pack_coh(a.r + w0 + h_pa * E);
-                h_db = ld_pack_coh(dold_p + w0 + h_pb * E); h_rb = ld_pack_coh(a.r + w0 + h_pb * E);
+                h_da = ld_pack_coh(dold_p + w0 + h_pa * E); h_ra = ld_pack_coh(rr + w0 + h_pa * E);
+                h_db = ld_pack_coh(dold_p + w0 + h_pb * E); h_rb = ld_pack_coh(rr + w0 + h_pb * E);
             }
         };
         T bt = vzero<T>();
         const bool as_is = k == 0 && a.d_ready;      // uniform
         if (it > 0 && k == 0) {                      // beta of a continued run from the stored scalars
-            bt = from_acc<T>(acc_div(to_acc(dlt), to_acc(a.history[it - 1])));
+            bt = from_acc<T>(acc_div(to_acc(dlt), to_acc(a.history[(long long)(it - 1) * a.nrhs + rhs])));
             halo_prefetch();
         } else if (it > 0) {
             T dnT;
@@ -844,9 +857,9 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                                    }, xlead, xpublish, xs_rr, tag0 + 2 * k, true, halo_prefetch)) return;
             dlt = dnT;
             if (leader && t == 0) {
-                a.beta[0] = bt;
-                a.delta[0] = dnT;
-                if (it < a.history_cap) a.history[it] = dnT;
+                a.beta[rhs] = bt;
+                a.delta[rhs] = dnT;
+                if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = dnT;
             }
         } else {
             halo_prefetch();
@@ -874,8 +887,8 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             const int hq = hp + kResThreads;
             const bool two = hq < nhalo;
             const int pa = hp < nlow ? hp : hi0 + (hp - nlow), pb = two ? (hq < nlow ? hq : hi0 + (hq - nlow)) : pa;
-            const Pack<T> da_ = ld_pack_coh(dold_p + w0 + pa * E), ra_ = ld_pack_coh(a.r + w0 + pa * E);
-            const Pack<T> db_ = ld_pack_coh(dold_p + w0 + pb * E), rb_ = ld_pack_coh(a.r + w0 + pb * E);
+            const Pack<T> da_ = ld_pack_coh(dold_p + w0 + pa * E), ra_ = ld_pack_coh(rr + w0 + pa * E);
+            const Pack<T> db_ = ld_pack_coh(dold_p + w0 + pb * E), rb_ = ld_pack_coh(rr + w0 + pb * E);
             Pack<T> oa, ob;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -908,7 +921,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                                    o = from_acc<T>(acc_div(to_acc(dlt), to_acc(dqT)));
                                    u = o;
                                }, xlead, xpublish, xs_dq, tag0 + 2 * k + 1)) return;
-        if (leader && t == 0) a.alpha[0] = al;
+        if (leader && t == 0) a.alpha[rhs] = al;
         A acc = vzero<A>();
 #pragma unroll
         for (int j = 0; j < PPT; ++j)
@@ -920,14 +933,14 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                     pr[j].v[e] = vsub(pr[j].v[e], vmul(al, qv));
                     acc = vadd(acc, to_acc(vmul(pr[j].v[e], pr[j].v[e])));
                 }
-                st_pack_coh<false>(at_off(a.r, poff[j]), pr[j]);
+                st_pack_coh<false>(at_off(rr, poff[j]), pr[j]);
             }
         tot = wg_sum(acc, sh);
         if (t == 0) put_granule<false>(g_rr + (size_t)m * W, tag0 + 2 * k + 2, tot);
     }
 #pragma unroll
     for (int j = 0; j < PPT; ++j)
-        if (pk[j]) st_pack(at_off(a.x, poff[j]), px[j]);
+        if (pk[j]) st_pack(at_off(xr, poff[j]), px[j]);
     if (leader) {
         T bfin, dnT;
         if (!group_scalars<A, T>(a.G, sh, a.hdr, bfin, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * a.K, v); },
@@ -937,12 +950,14 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                                  })) return;
         if (t == 0) {
             const int it = a.it0 + a.K;
-            a.beta[0] = bfin;
-            a.delta[0] = dnT;
-            if (it < a.history_cap) a.history[it] = dnT;
-            *a.iter = it;
+            a.beta[rhs] = bfin;
+            a.delta[rhs] = dnT;
+            if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = dnT;
+            if (rhs == 0) *a.iter = it;
             atomicAdd(a.hdr + kHdrSolved, 1u);
         }
+    }
+    __syncthreads();                                 // qs / sh words of this solve are done with before the next claim
     }
 }
 
@@ -1165,48 +1180,60 @@ static int resident_wide_launch(const ResWideArgs<T> &a, size_t lds, int grid, h
     return CGAMD_OK;
 }
 
-// Does the wide loop apply?  One right-hand side, rows of at most 8 entries, the whole system on at most n_cus work-groups of
-// 2048 / 4096 rows, the column range of a slice (+ q) within LDS.  Synchronises `st` (one pass over the matrix).
+// Does the wide loop apply?  Rows of at most 8 entries, a right-hand side on G <= n_cus work-groups of 2048 / 4096 rows (1024:
+// complex128), the column range of a slice (+ q) within LDS; several right-hand sides run as NG = n_cus / G concurrent groups, each
+// solving one after the other (with fewer than 4 groups at most two each: beyond that the launched loops, which stream the
+// matrix once for all right-hand sides, are faster).
+// Synchronises `st` (a pass over the matrix per candidate).
 int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev, const int *cols_dev, int *scratch_dev, hipStream_t st,
                        ResidentWidePlan *out) {
     out->ok = false;
     const int mode = tune().resident_wide;
     // systems the one-XCD loop could hold by size stay with the loops that are bit-identical to each other
-    if (mode == 0 || nrhs != 1 || n_cus < 8 || n <= 32768) return CGAMD_OK;
+    if (mode == 0 || nrhs < 1 || n_cus < 8 || n <= 32768) return CGAMD_OK;
     const int E = (int)(16 / dtype_size(dtype));
     if (n % E) return CGAMD_OK;
     const int forced = tune().resident_wide_rpt;
+    ResidentWidePlan best;
+    int best_rounds = 1 << 30;
     for (int rpt : {2, 4, 8}) {
         if (rpt % E || (rpt == 2) != (dtype == 3)) continue;       // complex128 (16-byte values): two rows per thread, the others 4 or 8
         if (forced > 0 && dtype != 3 && rpt != forced) continue;
         const int rows = kResThreads * rpt, G = (n + rows - 1) / rows;
         if (G > std::min(n_cus, 256)) continue;
+        const int NG = std::min(std::min(n_cus, 256) / G, nrhs), rounds = (nrhs + NG - 1) / NG;
+        // a round of NG solves costs about what ONE launched iteration of a few right-hand sides does: with >= 4 groups the loop wins at
+        // any number of rounds (90k rows: 0.8 us per right-hand side against 2.0); with fewer (250k rows: 2 groups) only up to two
+        if ((rounds > 2 && NG < 4) || rounds >= best_rounds) continue;
         int h[2] = {0, 0};
         CG_HIP(hipMemsetAsync(scratch_dev, 0, 8, st));
         hipLaunchKernelGGL(resident_wide_scan_kernel, dim3(G), dim3(kResThreads), 0, st, n, E, rows, ptr_dev, cols_dev, scratch_dev);
         CG_HIP(hipMemcpyAsync(h, scratch_dev, 8, hipMemcpyDeviceToHost, st));
         CG_HIP(hipStreamSynchronize(st));
         const int unroll = h[1] <= 5 ? 5 : h[1] <= 7 ? 7 : 8;
-        if (h[1] > 8 || (rpt == 8 && unroll != 5)) continue;           // instances: (4, 5), (4, 7), (4, 8), (8, 5)
+        if (h[1] > 8 || (rpt == 8 && unroll != 5)) continue;           // instances: (2 | 4, 5 | 7 | 8), (8, 5)
         const size_t lds = ((size_t)rows + (size_t)h[0] + 8) * dtype_size(dtype);
         if (lds > 150 * 1024 || ((size_t)h[0] + 8) * dtype_size(dtype) >= 65536) continue;      // 16-bit window offsets
-        out->rpt = rpt; out->unroll = unroll; out->G = G;
-        out->wcap = (h[0] + 3 + 4) & ~3;
-        out->lds_bytes = ((size_t)rows + out->wcap) * dtype_size(dtype);
+        best.rpt = rpt; best.unroll = unroll; best.G = G; best.NG = NG;
+        best.wcap = (h[0] + 3 + 4) & ~3;
+        best.lds_bytes = ((size_t)rows + best.wcap) * dtype_size(dtype);
         const size_t W = acc_size(dtype) / 4;
-        out->sync_bytes = (((size_t)kHdrWords * 4 + 8 + 2 * (size_t)G * W * 8 + 16 * 16 * 8) + 15) & ~(size_t)15;
-        out->ok = true;
-        return CGAMD_OK;
+        // header | slot words [NG] | granules [NG][2][G W] | XCD results [NG][16][2][8] | XCD arrival counters [NG][8]
+        best.sync_bytes = (((size_t)kHdrWords * 4 + (size_t)NG * (8 + 2 * (size_t)G * W * 8 + 16 * 16 * 8 + 8 * 4)) + 15) & ~(size_t)15;
+        best.ok = true;
+        best_rounds = rounds;
     }
+    if (best.ok) *out = best;
     return CGAMD_OK;
 }
 
 template <typename T>
-static int resident_wide_impl(const ResidentWidePlan &wp, int n, const void *vals, const int *ptr, const int *cols, void *x, void *r, void *d0,
-                              void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int grid, hipStream_t st) {
+static int resident_wide_impl(const ResidentWidePlan &wp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
+                              void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int grid, hipStream_t st) {
     using A = typename VT<T>::acc;
     ResWideArgs<T> a;
-    a.n = n; a.G = wp.G; a.npack = n / Pack<T>::N; a.it0 = it0; a.K = K; a.history_cap = sc.history_cap; a.wcap = wp.wcap;
+    a.n = n; a.nrhs = nrhs; a.G = wp.G; a.NG = wp.NG; a.npack = n / Pack<T>::N; a.it0 = it0; a.K = K; a.history_cap = sc.history_cap;
+    a.wcap = wp.wcap;
     a.d_ready = d_ready ? 1 : 0;
     a.claim_ticks = (long long)std::max(1, tune().resident_claim_ms) * 100000;
     a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
@@ -1214,8 +1241,9 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, const void *val
     a.alpha = (T *)sc.alpha; a.beta = (T *)sc.beta; a.delta = (T *)sc.delta; a.history = (T *)sc.history; a.iter = sc.iter;
     a.hdr = static_cast<unsigned *>(sync);
     a.slot_word = reinterpret_cast<u64 *>(static_cast<char *>(sync) + kHdrWords * 4);
-    a.gran = a.slot_word + 1;
-    a.xres = a.gran + 2 * (size_t)wp.G * (sizeof(A) / 4);
+    a.gran = a.slot_word + wp.NG;
+    a.xres = a.gran + (size_t)wp.NG * 2 * (size_t)wp.G * (sizeof(A) / 4);
+    a.xcnt = reinterpret_cast<unsigned *>(a.xres + (size_t)wp.NG * 16 * 16);
     CG_HIP(hipMemsetAsync(sync, 0, wp.sync_bytes, st));
     if constexpr (sizeof(T) == 16) {
         if (wp.unroll == 5) return resident_wide_launch<T, 2, 5>(a, wp.lds_bytes, grid, st);
@@ -1232,33 +1260,34 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, const void *val
 }
 
 // K iterations of the single right-hand side in one chip-wide launch; synchronises `st`
-int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, const void *vals, const int *ptr, const int *cols, void *x, void *r,
-                         void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st,
+int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x,
+                         void *r, void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st,
                          bool *untouched) {
     if (K < 1 || K >= (1 << 18)) return fail(CGAMD_ERR_INVALID, "wide resident loop: iteration count per launch out of range");
     if (untouched) *untouched = false;
-    if (tune().resident_test_short_grid) n_cus = std::max(1, wp.G - 1);      // test hook: the group can never fill
+    if (tune().resident_test_short_grid) n_cus = std::max(1, wp.G - 1);      // test hook: no group can ever fill
+    else n_cus = wp.NG * wp.G;                                               // exactly the groups' work-groups
     std::lock_guard<std::mutex> lock(g_resident_mutex);
     int device = 0;
     CG_HIP(hipGetDevice(&device));
     DeviceFileLock device_lock(device);
     int rc;
     switch (dtype) {
-    case 0: rc = resident_wide_impl<float>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
-    case 1: rc = resident_wide_impl<double>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
-    case 2: rc = resident_wide_impl<float2>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
-    case 3: rc = resident_wide_impl<double2>(wp, n, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
+    case 0: rc = resident_wide_impl<float>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
+    case 1: rc = resident_wide_impl<double>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
+    case 2: rc = resident_wide_impl<float2>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
+    case 3: rc = resident_wide_impl<double2>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
     default: return fail(CGAMD_ERR_INVALID, "wide resident loop: bad dtype");
     }
     if (rc) return rc;
     unsigned hdr[kHdrWords];
     CG_HIP(hipMemcpyAsync(hdr, sync, sizeof(hdr), hipMemcpyDeviceToHost, st));
     CG_HIP(hipStreamSynchronize(st));
-    if (untouched && hdr[kHdrError] == kErrClaim && hdr[kHdrSolved] == 0) {
-        *untouched = true;          // the group never passed its start line: nothing was read or written
+    if (untouched && hdr[kHdrError] == kErrClaim && hdr[kHdrSolved] == 0 && hdr[kHdrNextRhs] == 0) {
+        *untouched = true;          // no group ever passed its start line: nothing was read or written
         return fail(CGAMD_ERR_STATE, "wide resident loop: the group did not become resident within " + std::to_string(tune().resident_claim_ms) + " ms");
     }
-    if (hdr[kHdrError] != 0 || hdr[kHdrSolved] != 1u)
+    if (hdr[kHdrError] != 0 || hdr[kHdrSolved] != (unsigned)nrhs)
         return fail(CGAMD_ERR_HIP, "wide resident loop: " + std::string(hdr[kHdrError] == kErrSweep ? "a partial sum" : hdr[kHdrError] == kErrClaim ? "the start line" : "completion") +
                                        " timed out; cgamd_tune(\"resident_wide\", 0) selects the launched loops");
     return CGAMD_OK;

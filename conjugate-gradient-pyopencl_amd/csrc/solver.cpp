@@ -165,7 +165,7 @@ static int enqueue_iteration(cgamd_solver *s, int k, hipStream_t st) {
 // the resident loop applies where the two-launch loop does and the matrix slices fit LDS (needs the row pointers on the host)
 static int setup_resident_wide(cgamd_solver *s) {
     s->resw.ok = false;
-    if (tune().resident_wide == 0 || tune().resident == 0 || s->nrhs != 1 || s->rm_ok || (s->flags & CGAMD_UNFUSED)) return CGAMD_OK;
+    if (tune().resident_wide == 0 || tune().resident == 0 || s->rm_ok || (s->flags & CGAMD_UNFUSED)) return CGAMD_OK;
     if (!aligned16(s->x) || !aligned16(s->r) || !aligned16(s->d) || !aligned16(s->d2)) return CGAMD_OK;
     if (!s->n_cus) CG_HIP(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device));
     ResidentWidePlan wp;
@@ -486,22 +486,22 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
             void *cur = dbuf(s, s->iters), *other = cur == s->d ? s->d2 : s->d;
             void *d0 = (s->iters & 1) ? other : cur, *d1 = (s->iters & 1) ? cur : other;
             bool untouched = false;
-            if (int rc = run_cg_resident_wide(s->dtype, s->resw, s->n, s->vals, s->ptr, s->cols, s->x, s->r, d0, d1, keeps_new_d && s->iters > 0,
-                                              s->sc, s->iters, K, s->resw_sync, s->n_cus, st, &untouched)) {
+            if (int rc = run_cg_resident_wide(s->dtype, s->resw, s->n, s->nrhs, s->vals, s->ptr, s->cols, s->x, s->r, d0, d1,
+                                              keeps_new_d && s->iters > 0, s->sc, s->iters, K, s->resw_sync, s->n_cus, st, &untouched)) {
                 if (!untouched) return rc;
                 s->resw.ok = false;          // the chip is shared with something that does not yield: this handle keeps the launched loops
-                if (int rc2 = launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, 1, s->part_rr, s->vgrid, st)) return rc2;
+                if (int rc2 = launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, s->nrhs, s->part_rr, s->vgrid, st)) return rc2;
                 return cgamd_solver_iterate(s, left);
             }
             void *fin = ((s->iters + K) & 1) ? d1 : d0;
             s->iters += K;
             left -= K;
             if (fin != dbuf(s, s->iters))
-                CG_HIP(hipMemcpyAsync(dbuf(s, s->iters), fin, (size_t)s->n * dtype_size(s->dtype), hipMemcpyDeviceToDevice, st));
+                CG_HIP(hipMemcpyAsync(dbuf(s, s->iters), fin, (size_t)s->n * s->nrhs * dtype_size(s->dtype), hipMemcpyDeviceToDevice, st));
             if (keeps_new_d)                 // d = beta d + r with the beta the launch recorded last (clcg.c:415)
-                if (int rc = launch_aypx(s->dtype, s->n, s->r, dbuf(s, s->iters), s->n, s->sc.beta, 1, st)) return rc;
+                if (int rc = launch_aypx(s->dtype, s->n, s->r, dbuf(s, s->iters), s->n, s->sc.beta, s->nrhs, st)) return rc;
         }
-        return launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, 1, s->part_rr, s->vgrid, st);
+        return launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, s->nrhs, s->part_rr, s->vgrid, st);
     }
     if (two && s->res_ok && !(s->flags & CGAMD_NO_GRAPH) && nIterations >= std::max(1, tune().resident_min)) {
         // small system: the whole call in one launch per 2^15 iterations (resident.hip; a launch stays well below the bound of its

@@ -183,11 +183,11 @@ def test_resident_loop_does_not_apply(pkg, gpu):
     ctx, queue, kernels = gpu
     lib = pkg._lib.load()
     ip, ix, da = cg_numpy.poisson2d(200)                    # 40000 rows: a group would span two XCDs
-    s = pkg.Solver(ctx, 40000, len(ix), da, ip, ix, 2)
-    assert lib.cgamd_solver_loop_launches(s.handle) == 2
-    s.close()
-    s = pkg.Solver(ctx, 40000, len(ix), da, ip, ix, 1)      # ... a single right-hand side takes the chip-wide form instead
+    s = pkg.Solver(ctx, 40000, len(ix), da, ip, ix, 2)      # ... it takes the chip-wide form (one group per right-hand side, at most two rounds)
     assert lib.cgamd_solver_loop_launches(s.handle) == 1
+    s.close()
+    s = pkg.Solver(ctx, 40000, len(ix), da, ip, ix, 2, flags=pkg._lib.NO_GRAPH)     # plain launches requested
+    assert lib.cgamd_solver_loop_launches(s.handle) == 2
     s.close()
     ip, ix, da = cg_numpy.poisson2d(37)                     # 1369 rows: odd, no 16-byte packs per right-hand side
     s = pkg.Solver(ctx, 1369, len(ix), da, ip, ix, 2)

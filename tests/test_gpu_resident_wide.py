@@ -12,11 +12,11 @@ from conftest import rand_vec
 pytestmark = pytest.mark.gpu
 
 
-def _run(pkg, ctx, ip, ix, da, b, calls, wide):
+def _run(pkg, ctx, ip, ix, da, b, calls, wide, nrhs=1):
     lib = pkg._lib.load()
     pkg._lib.check(lib.cgamd_tune(b"resident_wide", int(wide)))
     try:
-        s = pkg.Solver(ctx, len(ip) - 1, len(ix), da, ip, ix, 1)
+        s = pkg.Solver(ctx, len(ip) - 1, len(ix), da, ip, ix, nrhs)
         s.set_rhs(b, None)
         kind = lib.cgamd_solver_loop_launches(s.handle)
         for c in calls:
@@ -95,3 +95,39 @@ def test_resident_launch_that_cannot_form_its_group_falls_back_untouched(pkg, gp
     x1, h1, before, after = run({"resident_test_short_grid": 1, "resident_claim_ms": 40})
     assert before == want_kind and after == k0 >= 2          # resident loop chosen at first, launched loops after the failed launch
     assert np.array_equal(h1, h0) and np.array_equal(x1, x0)
+
+
+@pytest.mark.parametrize("dtype,kind,nrhs,calls", [
+    (np.float64, "poisson300", 9, [20, 4, 17]),      # 22 work-groups per right-hand side, 9 groups at once; a launched call in between
+    (np.complex64, "helm200", 9, [24]),              # 40 000 rows x 9 (a larger as_prec shape): 20 work-groups each
+    (np.complex64, "helm500", 2, [20]),              # config 3 x 2: two groups of 123 work-groups, one poller per XCD and group
+    (np.float64, "poisson300", 20, [18]),            # more right-hand sides than groups (11): two solves per group
+])
+def test_wide_resident_loop_with_several_right_hand_sides(pkg, gpu, dtype, kind, nrhs, calls):
+    """one chip-wide group per right-hand side, several at once; every right-hand side against the oracle and the launched loops"""
+    ctx, queue, kernels = gpu
+    if kind.startswith("helm"):
+        N = int(kind[4:])
+        ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    else:
+        ip, ix, da = cg_numpy.poisson2d(int(kind[7:]))
+    n = len(ip) - 1
+    wide_t = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    rng = np.random.default_rng(n + nrhs)
+    b = np.concatenate([(r + 1) * 0.5 + rand_vec(rng, n, wide_t) for r in range(nrhs)]).astype(dtype)
+    A = da.astype(dtype)
+    w = _run(pkg, ctx, ip, ix, A, b, calls, True, nrhs)
+    l = _run(pkg, ctx, ip, ix, A, b, calls, False, nrhs)
+    assert w["kind"] == 1 and l["kind"] >= 2
+    iters = sum(calls)
+    cg_oracle.set_threads(16)
+    xo, ho = cg_oracle.cg(ip, ix, da.astype(wide_t), b.astype(wide_t), nrhs=nrhs, n_iterations=iters, mode=cg_oracle.MODE_FAST)
+    f64 = np.dtype(dtype) == np.float64
+    upto = ho.shape[0] if f64 else 13
+    assert w["h"].shape == ho.shape
+    assert np.max((np.abs(w["h"] - ho) / np.abs(ho))[:upto]) < (1e-10 if f64 else 2e-3)
+    assert np.max((np.abs(w["h"] - l["h"]) / np.abs(l["h"]))[:upto]) < (1e-11 if f64 else 2e-3)
+    for r in range(nrhs):
+        sl = slice(r * n, (r + 1) * n)
+        ex = np.linalg.norm(w["x"][sl] - l["x"][sl]) / np.linalg.norm(l["x"][sl])
+        assert ex < (1e-10 if f64 else 5e-3), (r, ex)
