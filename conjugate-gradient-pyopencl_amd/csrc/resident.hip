@@ -630,6 +630,8 @@ template <typename T> struct ResWideArgs {
     u64 *slot_word, *gran;          // slot_word[NG]; gran: [NG][2][G * W]
     u64 *xres;                      // [NG][16 XCDs][2 reductions][8 words]: the scalars an XCD's first work-group publishes for the others
     unsigned *xcnt;                 // [NG][8] arrivals of a group's members per XCD
+    unsigned *marks;                // [NG] members whose column marks are in
+    unsigned *need;                 // bitmap over the rows: somebody's row references this column from another member's slice
 };
 
 // The two scalars of a reduction for a chip-wide group.  Only ONE work-group per XCD (its first arriver) polls the members'
@@ -748,12 +750,33 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             const bool real = j < len;
             mv[h][j] = real ? a.vals[ps + j] : vzero<T>();
             mo[h][j] = real ? a.cols[ps + j] : -1;
-            if (real) { cmin = min(cmin, mo[h][j]); cmax = max(cmax, mo[h][j]); }
+            if (real) {
+                cmin = min(cmin, mo[h][j]);
+                cmax = max(cmax, mo[h][j]);
+                // a column in another member's slice: that member must publish the entry every iteration (the others never leave its registers)
+                if (mo[h][j] < R0 || mo[h][j] >= R0 + ROWS) atomicOr(a.need + (mo[h][j] >> 5), 1u << (mo[h][j] & 31));
+            }
         }
     }
     atomicMin(&sh.cmin, cmin);
     atomicMax(&sh.cmax, cmax);
+    drain_stores();                                  // this wave's marks are performed
     __syncthreads();
+    if (t == 0) {                                    // ... and every member's, before anybody reads the bitmap
+        atomicAdd(a.marks + grp, 1u);
+        const long long t0 = wall_clock64();
+        for (unsigned spins = 0;; ++spins) {
+            if (ld_word(a.marks + grp) >= (unsigned)a.G) break;
+            if ((spins & 63) == 63 && ((wall_clock64() - t0 > a.claim_ticks && ld_word(a.hdr + kHdrNextRhs) == 0) || ld_word(a.hdr + kHdrError) != 0)) {
+                atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrClaim);
+                sh.fail = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (sh.fail) return;
     const int rows_m = min(ROWS, a.n - R0);
     const int w0 = min(sh.cmin, R0) & ~(E - 1);
     const int wlen = max(sh.cmax, R0 + rows_m - 1) - w0 + 1;
@@ -809,7 +832,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
     T *xr = a.x + voff, *rr = a.r + voff, *d0r = a.d0 + voff, *d1r = a.d1 + voff;
 
     Pack<T> px[PPT], pr[PPT], pd[PPT];
-    bool pk[PPT];
+    bool pk[PPT], pub[PPT];
     unsigned poff[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -817,6 +840,8 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         const int pack = m * (ROWS / E) + pl;
         pk[j] = pack < a.npack;
         poff[j] = (unsigned)pack * 16u;
+        // published every iteration only if another member reads one of its rows (E <= 4 consecutive bits of one bitmap word)
+        pub[j] = pk[j] && ((ld_word(a.need + ((pack * E) >> 5)) >> ((pack * E) & 31)) & ((1u << E) - 1u)) != 0;
         if (pk[j]) {
             px[j] = ld_pack(at_off(xr, poff[j]));
             pr[j] = ld_pack(at_off(rr, poff[j]));
@@ -870,7 +895,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             if (pk[j]) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) pd[j].v[e] = as_is ? pd[j].v[e] : vaypx(bt, pd[j].v[e], pr[j].v[e]);
-                st_pack_coh<false>(at_off(dnew_p, poff[j]), pd[j]);
+                if (pub[j]) st_pack_coh<false>(at_off(dnew_p, poff[j]), pd[j]);
                 *reinterpret_cast<Pack<T> *>(wb + (size_t)(R0 - w0) * sizeof(T) + (size_t)(t + j * kResThreads) * 16) = pd[j];
             }
         if (ht < nhalo) {
@@ -933,14 +958,20 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                     pr[j].v[e] = vsub(pr[j].v[e], vmul(al, qv));
                     acc = vadd(acc, to_acc(vmul(pr[j].v[e], pr[j].v[e])));
                 }
-                st_pack_coh<false>(at_off(rr, poff[j]), pr[j]);
+                if (pub[j]) st_pack_coh<false>(at_off(rr, poff[j]), pr[j]);
             }
         tot = wg_sum(acc, sh);
         if (t == 0) put_granule<false>(g_rr + (size_t)m * W, tag0 + 2 * k + 2, tot);
     }
 #pragma unroll
     for (int j = 0; j < PPT; ++j)
-        if (pk[j]) st_pack(at_off(xr, poff[j]), px[j]);
+        if (pk[j]) {                                 // the whole state back to memory: x, and what was not published on the way
+            st_pack(at_off(xr, poff[j]), px[j]);
+            if (!pub[j]) {
+                st_pack(at_off(rr, poff[j]), pr[j]);
+                st_pack(at_off(((a.it0 + a.K) & 1) ? d1r : d0r, poff[j]), pd[j]);
+            }
+        }
     if (leader) {
         T bfin, dnT;
         if (!group_scalars<A, T>(a.G, sh, a.hdr, bfin, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * a.K, v); },
@@ -1219,7 +1250,9 @@ int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev
         best.lds_bytes = ((size_t)rows + best.wcap) * dtype_size(dtype);
         const size_t W = acc_size(dtype) / 4;
         // header | slot words [NG] | granules [NG][2][G W] | XCD results [NG][16][2][8] | XCD arrival counters [NG][8]
-        best.sync_bytes = (((size_t)kHdrWords * 4 + (size_t)NG * (8 + 2 * (size_t)G * W * 8 + 16 * 16 * 8 + 8 * 4)) + 15) & ~(size_t)15;
+        //   | marks [NG] | bitmap of published rows [n / 32]
+        best.sync_bytes = (((size_t)kHdrWords * 4 + (size_t)NG * (8 + 2 * (size_t)G * W * 8 + 16 * 16 * 8 + 8 * 4) + (size_t)((NG + 3) & ~3) * 4 +
+                            ((size_t)n / 32 + 2) * 4) + 15) & ~(size_t)15;
         best.ok = true;
         best_rounds = rounds;
     }
@@ -1244,6 +1277,8 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, int nrhs, const
     a.gran = a.slot_word + wp.NG;
     a.xres = a.gran + (size_t)wp.NG * 2 * (size_t)wp.G * (sizeof(A) / 4);
     a.xcnt = reinterpret_cast<unsigned *>(a.xres + (size_t)wp.NG * 16 * 16);
+    a.marks = a.xcnt + (size_t)wp.NG * 8;
+    a.need = a.marks + ((wp.NG + 3) & ~3);
     CG_HIP(hipMemsetAsync(sync, 0, wp.sync_bytes, st));
     if constexpr (sizeof(T) == 16) {
         if (wp.unroll == 5) return resident_wide_launch<T, 2, 5>(a, wp.lds_bytes, grid, st);
