@@ -236,8 +236,8 @@ struct ResidentWidePlan {
     int rpt = 0, unroll = 0, G = 0, NG = 1, wcap = 0;      // NG concurrent groups of G work-groups
     size_t lds_bytes = 0, sync_bytes = 0;
 };
-int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev, const int *cols_dev, int *scratch_dev, hipStream_t st,
-                       ResidentWidePlan *out);
+int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, const int *ptr_dev, const int *cols_dev, int *scratch_dev,
+                       hipStream_t st, ResidentWidePlan *out);
 // state in and out: x, r, d of iteration k in (k & 1 ? d1 : d0), delta / beta / alpha / history / iter; d_ready: on entry d is
 // already beta d + r (three / four-launch loops); on exit d is always the direction of the last iteration (two-launch
 // convention) and the launched loops' r.r partials are NOT maintained -- the caller converts / rebuilds

@@ -1213,11 +1213,10 @@ static int resident_wide_launch(const ResWideArgs<T> &a, size_t lds, int grid, h
 
 // Does the wide loop apply?  Rows of at most 8 entries, a right-hand side on G <= n_cus work-groups of 2048 / 4096 rows (1024:
 // complex128), the column range of a slice (+ q) within LDS; several right-hand sides run as NG = n_cus / G concurrent groups, each
-// solving one after the other (with fewer than 4 groups at most two each: beyond that the launched loops, which stream the
-// matrix once for all right-hand sides, are faster).
+// solving one after the other where that beats the launched loops' streaming cost per right-hand side (a small model, below).
 // Synchronises `st` (a pass over the matrix per candidate).
-int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev, const int *cols_dev, int *scratch_dev, hipStream_t st,
-                       ResidentWidePlan *out) {
+int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, const int *ptr_dev, const int *cols_dev, int *scratch_dev,
+                       hipStream_t st, ResidentWidePlan *out) {
     out->ok = false;
     const int mode = tune().resident_wide;
     // systems the one-XCD loop could hold by size stay with the loops that are bit-identical to each other
@@ -1233,9 +1232,16 @@ int resident_wide_plan(int dtype, int n, int nrhs, int n_cus, const int *ptr_dev
         const int rows = kResThreads * rpt, G = (n + rows - 1) / rows;
         if (G > std::min(n_cus, 256)) continue;
         const int NG = std::min(std::min(n_cus, 256) / G, nrhs), rounds = (nrhs + NG - 1) / NG;
-        // a round of NG solves costs about what ONE launched iteration of a few right-hand sides does: with >= 4 groups the loop wins at
-        // any number of rounds (90k rows: 0.8 us per right-hand side against 2.0); with fewer (250k rows: 2 groups) only up to two
-        if ((rounds > 2 && NG < 4) || rounds >= best_rounds) continue;
+        // Several rounds: a group's iteration costs t_w ~ 8 + 0.011 G us whatever the size (nothing streams from memory), i.e. t_w / NG
+        // per right-hand side, while a launched iteration streams ~10 vector passes per right-hand side plus its share of the matrix at
+        // ~5 TB/s (90k rows x 20 fp64: 0.75 against 2.0 us measured; 1M rows x 32 fp64: 10.7 against 16.3; 250k x 9 complex64: 6.1
+        // against 5.5 -> launched).
+        if (rounds > 1) {
+            const double t_wide = (8.0 + 0.011 * G) / NG;
+            const double t_launched = (10.0 * n * (double)dtype_size(dtype) + (double)nnz * (dtype_size(dtype) + 4) / nrhs) / 5.0e6;
+            if (t_wide * 1.1 >= t_launched) continue;
+        }
+        if (rounds >= best_rounds) continue;
         int h[2] = {0, 0};
         CG_HIP(hipMemsetAsync(scratch_dev, 0, 8, st));
         hipLaunchKernelGGL(resident_wide_scan_kernel, dim3(G), dim3(kResThreads), 0, st, n, E, rows, ptr_dev, cols_dev, scratch_dev);

@@ -165,16 +165,18 @@ static int enqueue_iteration(cgamd_solver *s, int k, hipStream_t st) {
 // the resident loop applies where the two-launch loop does and the matrix slices fit LDS (needs the row pointers on the host)
 static int setup_resident_wide(cgamd_solver *s) {
     s->resw.ok = false;
-    if (tune().resident_wide == 0 || tune().resident == 0 || s->rm_ok || (s->flags & CGAMD_UNFUSED)) return CGAMD_OK;
+    if (tune().resident_wide == 0 || tune().resident == 0 || (s->flags & CGAMD_UNFUSED)) return CGAMD_OK;
+    if (s->rm_ok && tune().spmm_rowmajor >= 2) return CGAMD_OK;      // the row-major loop was asked for
     if (!aligned16(s->x) || !aligned16(s->r) || !aligned16(s->d) || !aligned16(s->d2)) return CGAMD_OK;
     if (!s->n_cus) CG_HIP(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device));
     ResidentWidePlan wp;
-    if (int rc = resident_wide_plan(s->dtype, s->n, s->nrhs, s->n_cus, s->ptr, s->cols, s->sc.iter, s->ctx->stream, &wp)) return rc;
+    if (int rc = resident_wide_plan(s->dtype, s->n, s->nnz, s->nrhs, s->n_cus, s->ptr, s->cols, s->sc.iter, s->ctx->stream, &wp)) return rc;
     if (!wp.ok) return CGAMD_OK;
     if (s->resw_sync && wp.sync_bytes > s->resw.sync_bytes) { (void)hipFree(s->resw_sync); s->resw_sync = nullptr; }
     if (!s->resw_sync)
         if (int rc = dmalloc(&s->resw_sync, wp.sync_bytes, "wide resident sync words")) return rc;
     s->resw = wp;
+    s->rm_ok = false;       // the chip-wide resident groups keep the caller's RHS-major layout (and beat the row-major loop: 1M x 32 fp64)
     return CGAMD_OK;
 }
 
@@ -263,7 +265,9 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     // one (measured in one process at N = 1M, profiles/r2_experiments/spmm_ab12.log: f64 x 32 +8 %; f64 x 16, f32 x 32 equal within
     // 1 %, complex64 x 16 slower).  spmm_rowmajor = 2 takes it for every supported type, 0 never.
     const int rm_knob = tune().spmm_rowmajor;
-    const bool rm_wins = dtype == CGAMD_F64 && nRHS == 32;
+    // (up to 32768 rows the resident loop is several times faster than any launched loop; between that and ~1M rows the chip-wide
+    // resident groups take over when they apply, setup_resident_wide)
+    const bool rm_wins = dtype == CGAMD_F64 && nRHS == 32 && size > 32768;
     s->rm_ok = nRHS > 1 && (rm_knob >= 2 || (rm_knob == 1 && rm_wins)) && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS, size);
     if (s->rm_ok) s->rm_vgrid = rm_vec_grid((long long)size * nRHS, dtype);
     int rc = CGAMD_OK;
