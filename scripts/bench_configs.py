@@ -114,6 +114,12 @@ if "asprec" in which:
     da = torch.from_numpy(hd.astype(np.complex64)).to(dev)
     for nrhs in (9, 1):
         run(f"as_prec shape: helmFE_var(128) c64 n=16384 nrhs={nrhs}", ip, ix, da, np.complex64, nrhs, iters=2560, reps=30)
+if "mid" in which:
+    # between the reference's sub-domain size and config 3: chip-wide resident groups, one per right-hand side
+    ip, ix, da = pkg.generators.poisson2d(ctx, 300, dtype=np.float64)
+    run("mid-size: 2D 5-pt 90000 rows f64 nrhs=9", ip, ix, da, np.float64, 9, iters=1000, reps=20)
+    ip, ix, da = pkg.generators.helm_fe_var(ctx, 200, 12.0, None, 0.15, dtype=np.complex64)
+    run("mid-size: helmFE_var(200) c64 40000 rows nrhs=9", ip, ix, da, np.complex64, 9, iters=1000, reps=20)
 if "report" in which:
     # context only: the one matrix of the upstream report that can be regenerated offline --
     # helm_fem: complex, n = 16 384, nnz = 113 666 = helmFE_var(N=128); the report ran 5000 iterations in fp32 complex and
