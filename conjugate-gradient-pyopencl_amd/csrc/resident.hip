@@ -1247,8 +1247,9 @@ int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, con
         hipLaunchKernelGGL(resident_wide_scan_kernel, dim3(G), dim3(kResThreads), 0, st, n, E, rows, ptr_dev, cols_dev, scratch_dev);
         CG_HIP(hipMemcpyAsync(h, scratch_dev, 8, hipMemcpyDeviceToHost, st));
         CG_HIP(hipStreamSynchronize(st));
-        const int unroll = h[1] <= 5 ? 5 : h[1] <= 7 ? 7 : 8;
-        if (h[1] > 8 || (rpt == 8 && unroll != 5)) continue;           // instances: (2 | 4, 5 | 7 | 8), (8, 5)
+        const int unroll = h[1] <= 5 ? 5 : h[1] <= 7 ? 7 : h[1] <= 8 ? 8 : 10;
+        if (h[1] > 10 || (rpt == 8 && unroll != 5)) continue;          // instances: (2 | 4, 5 | 7 | 8 | 10), (8, 5)
+        if (dtype == 2 && unroll == 10) continue;                      // (complex64 with 10 entries per row spills: launched loops)
         const size_t lds = ((size_t)rows + (size_t)h[0] + 8) * dtype_size(dtype);
         if (lds > 150 * 1024 || ((size_t)h[0] + 8) * dtype_size(dtype) >= 65536) continue;      // 16-bit window offsets
         best.rpt = rpt; best.unroll = unroll; best.G = G; best.NG = NG;
@@ -1289,13 +1290,15 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, int nrhs, const
     if constexpr (sizeof(T) == 16) {
         if (wp.unroll == 5) return resident_wide_launch<T, 2, 5>(a, wp.lds_bytes, grid, st);
         if (wp.unroll == 7) return resident_wide_launch<T, 2, 7>(a, wp.lds_bytes, grid, st);
-        return resident_wide_launch<T, 2, 8>(a, wp.lds_bytes, grid, st);
+        if (wp.unroll == 8) return resident_wide_launch<T, 2, 8>(a, wp.lds_bytes, grid, st);
+        return resident_wide_launch<T, 2, 10>(a, wp.lds_bytes, grid, st);
     } else if (wp.rpt == 8) {
         return resident_wide_launch<T, 8, 5>(a, wp.lds_bytes, grid, st);
     } else {
         if (wp.unroll == 5) return resident_wide_launch<T, 4, 5>(a, wp.lds_bytes, grid, st);
         if (wp.unroll == 7) return resident_wide_launch<T, 4, 7>(a, wp.lds_bytes, grid, st);
-        return resident_wide_launch<T, 4, 8>(a, wp.lds_bytes, grid, st);
+        if (wp.unroll == 8) return resident_wide_launch<T, 4, 8>(a, wp.lds_bytes, grid, st);
+        return resident_wide_launch<T, 4, 10>(a, wp.lds_bytes, grid, st);
     }
     return fail(CGAMD_ERR_INVALID, "wide resident loop: no instance");
 }

@@ -34,12 +34,21 @@ def _run(pkg, ctx, ip, ix, da, b, calls, wide, nrhs=1):
     (np.complex64, "helm500", [24]),             # config 3 at full size: 123 work-groups of 2048 rows, 7 entries per row
     (np.float32, "poisson300", [20, 16]),
     (np.complex128, "helm500", [16, 16]),        # config 3 in the build's wide type: 245 work-groups of 1024 rows
+    (np.float64, "ninepoint300", [24]),          # 9 entries per row (bilinear elements): the 10-entry instance
 ])
 def test_wide_resident_loop_against_oracle_and_launched_loop(pkg, gpu, dtype, kind, calls):
     ctx, queue, kernels = gpu
     if kind == "helm500":
         N = 500
         ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    elif kind.startswith("ninepoint"):
+        import scipy.sparse as sp
+        N = int(kind[9:])
+        T1 = sp.diags([np.ones(N - 1), np.ones(N), np.ones(N - 1)], [-1, 0, 1])
+        A9 = sp.csr_matrix(sp.identity(N * N) * 3.0 - sp.kron(T1, T1) / 3.0)      # 8/3 on the diagonal, -1/3 to the 8 neighbours
+        A9.sort_indices()
+        ip, ix, da = A9.indptr.astype(np.int32), A9.indices.astype(np.int32), A9.data.copy()
+        assert np.diff(ip).max() == 9
     else:
         ip, ix, da = cg_numpy.poisson2d(int(kind[7:]))
     n = len(ip) - 1
