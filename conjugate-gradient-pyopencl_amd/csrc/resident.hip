@@ -632,6 +632,7 @@ template <typename T> struct ResWideArgs {
     unsigned *xcnt;                 // [NG][8] arrivals of a group's members per XCD
     unsigned *marks;                // [NG] members whose column marks are in
     unsigned *need;                 // bitmap over the rows: somebody's row references this column from another member's slice
+    long long *prof;                // diagnostics (CGAMD_RESIDENT_PROF=1)
 };
 
 // The two scalars of a reduction for a chip-wide group.  Only ONE work-group per XCD (its first arriver) polls the members'
@@ -851,8 +852,10 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
     T dlt = a.delta[rhs];
     const unsigned tag0 = seq << 20;
 
+    long long stamp = clock64();
     for (int k = 0; k < a.K; ++k) {
         const int it = a.it0 + k;
+        RES_STAMP(0)
         const T *dold_p = (it & 1) ? d1r : d0r;
         T *dnew_p = (it & 1) ? d0r : d1r;
         Pack<T> h_da, h_ra, h_db, h_rb;
@@ -889,6 +892,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         } else {
             halo_prefetch();
         }
+        RES_STAMP(1)
         // ---- d_new = beta d + r: my packs to memory (the neighbours' next halo) and into the window
 #pragma unroll
         for (int j = 0; j < PPT; ++j)
@@ -924,6 +928,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             if (two) *reinterpret_cast<Pack<T> *>(wb + (size_t)pb * 16) = ob;
         }
         __syncthreads();
+        RES_STAMP(2)
         // ---- q = A d_new for my rows, d.q
         A dot = vzero<A>();
 #pragma unroll
@@ -937,8 +942,10 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             qs[t + h * kResThreads] = sum;
             if (live[h]) dot = vadd(dot, to_acc(vmul(*reinterpret_cast<const T *>(wb + own_off[h]), sum)));
         }
+        RES_STAMP(3)
         A tot = wg_sum(dot, sh);
         if (t == 0) put_granule<false>(g_dq + (size_t)m * W, tag0 + 2 * k + 1, tot);
+        RES_STAMP(4)
         T al, al_unused;
         if (!xcd_scalars<A, T>(a.G, sh, a.hdr, al, al_unused, [&](int i, A &v) { return get_granule(g_dq + (size_t)i * W, tag0 + 2 * k + 1, v); },
                                [&](A dq, T &o, T &u) {
@@ -946,6 +953,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                                    o = from_acc<T>(acc_div(to_acc(dlt), to_acc(dqT)));
                                    u = o;
                                }, xlead, xpublish, xs_dq, tag0 + 2 * k + 1)) return;
+        RES_STAMP(5)
         if (leader && t == 0) a.alpha[rhs] = al;
         A acc = vzero<A>();
 #pragma unroll
@@ -960,8 +968,10 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                 }
                 if (pub[j]) st_pack_coh<false>(at_off(rr, poff[j]), pr[j]);
             }
+        RES_STAMP(6)
         tot = wg_sum(acc, sh);
         if (t == 0) put_granule<false>(g_rr + (size_t)m * W, tag0 + 2 * k + 2, tot);
+        RES_STAMP(7)
     }
 #pragma unroll
     for (int j = 0; j < PPT; ++j)
@@ -1095,6 +1105,14 @@ static void resident_print_prof(int K, hipStream_t st) {
     fprintf(stderr, "resident prof (s_memtime ticks per iteration, %d iterations): loop-top %.0f  beta-poll %.0f  gather+fma %.0f  reduce+put %.0f  "
                     "alpha-poll %.0f  update %.0f  reduce+put %.0f\n", K, (double)h[0] / K, (double)h[1] / K, (double)h[2] / K, (double)h[3] / K,
             (double)h[4] / K, (double)h[5] / K, (double)h[6] / K);
+}
+
+static void resident_print_prof_wide(int K, hipStream_t st) {
+    long long h[8] = {0};
+    if (!g_prof_dev || hipMemcpyAsync(h, g_prof_dev, 64, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
+    fprintf(stderr, "wide resident prof (s_memtime ticks per iteration, %d iterations): loop-top %.0f  beta %.0f  window %.0f  rows %.0f  sum+put %.0f  "
+                    "alpha %.0f  update %.0f  sum+put %.0f\n", K, (double)h[0] / K, (double)h[1] / K, (double)h[2] / K, (double)h[3] / K,
+            (double)h[4] / K, (double)h[5] / K, (double)h[6] / K, (double)h[7] / K);
 }
 
 template <typename T, bool LOCAL, int UNROLL, bool WINDOW>
@@ -1286,6 +1304,9 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, int nrhs, const
     a.xcnt = reinterpret_cast<unsigned *>(a.xres + (size_t)wp.NG * 16 * 16);
     a.marks = a.xcnt + (size_t)wp.NG * 8;
     a.need = a.marks + ((wp.NG + 3) & ~3);
+    if (getenv("CGAMD_RESIDENT_PROF") && !g_prof_dev) CG_HIP(hipMalloc(&g_prof_dev, 64));
+    a.prof = g_prof_dev;
+    if (g_prof_dev) CG_HIP(hipMemsetAsync(g_prof_dev, 0, 64, st));
     CG_HIP(hipMemsetAsync(sync, 0, wp.sync_bytes, st));
     if constexpr (sizeof(T) == 16) {
         if (wp.unroll == 5) return resident_wide_launch<T, 2, 5>(a, wp.lds_bytes, grid, st);
@@ -1327,6 +1348,7 @@ int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs,
     unsigned hdr[kHdrWords];
     CG_HIP(hipMemcpyAsync(hdr, sync, sizeof(hdr), hipMemcpyDeviceToHost, st));
     CG_HIP(hipStreamSynchronize(st));
+    if (getenv("CGAMD_RESIDENT_PROF")) resident_print_prof_wide(K, st);
     if (untouched && hdr[kHdrError] == kErrClaim && hdr[kHdrSolved] == 0 && hdr[kHdrNextRhs] == 0) {
         *untouched = true;          // no group ever passed its start line: nothing was read or written
         return fail(CGAMD_ERR_STATE, "wide resident loop: the group did not become resident within " + std::to_string(tune().resident_claim_ms) + " ms");
