@@ -792,7 +792,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
     for (int h = 0; h < RPT; ++h) {
         own_off[h] = (unsigned)(min(R0 + t + h * kResThreads, a.n - 1) - w0) * (unsigned)sizeof(T);
 #pragma unroll
-        for (int j = 0; j < U; ++j) mo[h][j] = (mo[h][j] >= 0 ? mo[h][j] - w0 : a.wcap - 1) * (int)sizeof(T);      // < 65536: the host checked
+        for (int j = 0; j < U; ++j) mo[h][j] = mo[h][j] >= 0 ? mo[h][j] - w0 : a.wcap - 1;      // window entry, < 65536 (LDS holds fewer)
 #pragma unroll
         for (int j = 0; j < UP; ++j) mo2[h][j] = (unsigned)mo[h][2 * j] | ((2 * j + 1 < U ? (unsigned)mo[h][2 * j + 1] : 0u) << 16);
     }
@@ -936,8 +936,8 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             T sum = vzero<T>();
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                const unsigned off = (j & 1) ? mo2[h][j >> 1] >> 16 : mo2[h][j >> 1] & 0xffffu;
-                sum = vfma(mv[h][j], *reinterpret_cast<const T *>(wb + off), sum);
+                const unsigned idx = (j & 1) ? mo2[h][j >> 1] >> 16 : mo2[h][j >> 1] & 0xffffu;
+                sum = vfma(mv[h][j], win[idx], sum);
             }
             qs[t + h * kResThreads] = sum;
             if (live[h]) dot = vadd(dot, to_acc(vmul(*reinterpret_cast<const T *>(wb + own_off[h]), sum)));
@@ -1269,7 +1269,7 @@ int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, con
         if (h[1] > 10 || (rpt == 8 && unroll != 5)) continue;          // instances: (2 | 4, 5 | 7 | 8 | 10), (8, 5)
         if (dtype == 2 && unroll == 10) continue;                      // (complex64 with 10 entries per row spills: launched loops)
         const size_t lds = ((size_t)rows + (size_t)h[0] + 8) * dtype_size(dtype);
-        if (lds > 150 * 1024 || ((size_t)h[0] + 8) * dtype_size(dtype) >= 65536) continue;      // 16-bit window offsets
+        if (lds > 150 * 1024 || (size_t)h[0] + 8 >= 65536) continue;      // 16-bit window indices
         best.rpt = rpt; best.unroll = unroll; best.G = G; best.NG = NG;
         best.wcap = (h[0] + 3 + 4) & ~3;
         best.lds_bytes = ((size_t)rows + best.wcap) * dtype_size(dtype);

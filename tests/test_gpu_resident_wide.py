@@ -35,12 +35,16 @@ def _run(pkg, ctx, ip, ix, da, b, calls, wide, nrhs=1):
     (np.float32, "poisson300", [20, 16]),
     (np.complex128, "helm500", [16, 16]),        # config 3 in the build's wide type: 245 work-groups of 1024 rows
     (np.float64, "ninepoint300", [24]),          # 9 entries per row (bilinear elements): the 10-entry instance
+    (np.float64, "lap3d64", [24]),               # 3-D 7-point 64^3: 128 work-groups, windows of 2 x 4096 halo rows
 ])
 def test_wide_resident_loop_against_oracle_and_launched_loop(pkg, gpu, dtype, kind, calls):
     ctx, queue, kernels = gpu
     if kind == "helm500":
         N = 500
         ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    elif kind.startswith("lap3d"):
+        N = int(kind[5:])
+        ip, ix, da = cg_numpy.laplace3d(N, N, N)
     elif kind.startswith("ninepoint"):
         import scipy.sparse as sp
         N = int(kind[9:])
