@@ -29,7 +29,9 @@ lib = pkg._lib.load()
 ctx = pkg.Context(0)
 dev = torch.device("cuda", 0)
 dt = {"c64": np.complex64, "c128": np.complex128, "f64": np.float64, "f32": np.float32}[args.dtype]
-if args.dtype in ("c64", "c128"):
+if args.N < 0:          # 3-D 7-point Laplacian (-N)^3
+    hp, hx, hd = cg_numpy.laplace3d(-args.N, -args.N, -args.N)
+elif args.dtype in ("c64", "c128"):
     hp, hx, hd = cg_numpy.helm_fe_var(args.N, 12.0, np.ones((args.N - 1, args.N - 1)), 0.15, args.N, args.N)
 else:
     hp, hx, hd = cg_numpy.poisson2d(args.N)
