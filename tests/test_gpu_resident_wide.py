@@ -36,12 +36,18 @@ def _run(pkg, ctx, ip, ix, da, b, calls, wide, nrhs=1):
     (np.complex128, "helm500", [16, 16]),        # config 3 in the build's wide type: 245 work-groups of 1024 rows
     (np.float64, "ninepoint300", [24]),          # 9 entries per row (bilinear elements): the 10-entry instance
     (np.float64, "lap3d64", [24]),               # 3-D 7-point 64^3: 128 work-groups, windows of 2 x 4096 halo rows
+    (np.float64, "band50000", [20]),             # irregular rows (1 .. 7 entries, unsorted, some diagonal-only), last member partial
+    (np.complex64, "band50000", [20]),
 ])
 def test_wide_resident_loop_against_oracle_and_launched_loop(pkg, gpu, dtype, kind, calls):
     ctx, queue, kernels = gpu
     if kind == "helm500":
         N = 500
         ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    elif kind.startswith("band"):
+        from test_gpu_resident import _banded_spd
+        ip, ix, da = _banded_spd(int(kind[4:]), 3, 0.8, 50)
+        assert np.diff(ip).max() <= 7 and np.diff(ip).min() == 1
     elif kind.startswith("lap3d"):
         N = int(kind[5:])
         ip, ix, da = cg_numpy.laplace3d(N, N, N)
