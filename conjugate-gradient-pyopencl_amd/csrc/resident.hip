@@ -1098,7 +1098,7 @@ bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const
     return true;
 }
 
-static long long *g_prof_dev = nullptr;     // diagnostics only
+static long long *g_prof_dev = nullptr;     // diagnostics only (CGAMD_RESIDENT_PROF=1; single device, single thread)
 static void resident_print_prof(int K, hipStream_t st) {
     long long h[8] = {0};
     if (!g_prof_dev || hipMemcpyAsync(h, g_prof_dev, 64, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
@@ -1118,12 +1118,10 @@ static void resident_print_prof_wide(int K, hipStream_t st) {
 template <typename T, bool LOCAL, int UNROLL, bool WINDOW>
 static int resident_launch_inst(const ResArgs<T> &a, size_t lds, int grid, hipStream_t st) {
     auto kern = cg_resident_kernel<T, LOCAL, UNROLL, WINDOW>;
-    static thread_local size_t lds_set = 0;
-    if (lds > 64 * 1024 && lds > lds_set) {
+    if (lds > 64 * 1024) {      // per launch: the attribute belongs to the current device's copy of the function (a thread may serve several)
         const size_t want = std::min<size_t>((lds + 8191) & ~(size_t)8191, 152 * 1024);      // + the static words: below the 160 KB of a CU
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("resident loop: hipFuncSetAttribute: ") + hipGetErrorString(e));
-        lds_set = want;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kResThreads), lds, st, a);
     hipError_t e = hipGetLastError();
@@ -1216,12 +1214,10 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
 template <typename T, int RPT, int U>
 static int resident_wide_launch(const ResWideArgs<T> &a, size_t lds, int grid, hipStream_t st) {
     auto kern = cg_resident_wide_kernel<T, RPT, U>;
-    static thread_local size_t lds_set = 0;
-    if (lds > 64 * 1024 && lds > lds_set) {
+    if (lds > 64 * 1024) {
         const size_t want = std::min<size_t>((lds + 8191) & ~(size_t)8191, 152 * 1024);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("wide resident loop: hipFuncSetAttribute: ") + hipGetErrorString(e));
-        lds_set = want;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kResThreads), lds, st, a);
     hipError_t e = hipGetLastError();
