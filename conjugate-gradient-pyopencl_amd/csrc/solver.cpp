@@ -485,8 +485,10 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
         // one chip-wide resident group (single right-hand side, matrix rows in registers).  d ping-pongs inside the launch; handles
         // of the launched loops that keep d in one buffer get it back there, and the launched loops' r.r partials are rebuilt.
         const bool keeps_new_d = !two;       // three / four-launch loops: between iterations d already is beta d + r
+        // a launch stays around a second at most (groups solve their right-hand sides in turn, ~10 us per iteration)
+        const int rounds_w = (s->nrhs + s->resw.NG - 1) / s->resw.NG, kmax_w = std::min(1 << 15, std::max(64, 100000 / rounds_w));
         for (int left = nIterations; left > 0;) {
-            const int K = std::min(left, 1 << 15);
+            const int K = std::min(left, kmax_w);
             void *cur = dbuf(s, s->iters), *other = cur == s->d ? s->d2 : s->d;
             void *d0 = (s->iters & 1) ? other : cur, *d1 = (s->iters & 1) ? cur : other;
             bool untouched = false;
@@ -510,8 +512,10 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
     if (two && s->res_ok && !(s->flags & CGAMD_NO_GRAPH) && nIterations >= std::max(1, tune().resident_min)) {
         // small system: the whole call in one launch per 2^15 iterations (resident.hip; a launch stays well below the bound of its
         // waits); same state, same bits as the loop below
+        const int groups_r = std::max(1, 8 * s->res.lg), rounds_r = (s->nrhs + groups_r - 1) / groups_r;
+        const int kmax_r = std::min(1 << 15, std::max(64, 200000 / rounds_r));      // a launch stays around a second at most
         for (int left = nIterations; left > 0;) {
-            const int K = std::min(left, 1 << 15);
+            const int K = std::min(left, kmax_r);
             bool untouched = false;
             if (int rc = run_cg_resident(s->dtype, s->res, s->n, s->nrhs, s->vals, s->ptr, s->cols, s->x, s->r, s->d, s->d2, s->part_rr,
                                          s->vgrid, s->plan.n_partials, s->sc, s->iters, K, s->res_sync, s->n_cus, st, &untouched)) {

@@ -200,3 +200,17 @@ def test_resident_loop_does_not_apply(pkg, gpu):
     s = pkg.Solver(ctx, 1600, len(ix), da, ip, ix, 1, flags=pkg._lib.UNFUSED)
     assert lib.cgamd_solver_loop_launches(s.handle) == 8
     s.close()
+
+
+def test_long_call_is_cut_into_several_resident_launches(pkg, gpu):
+    """iterate(40000): more than one launch's worth of iterations (2^15 per launch); the cuts leave no trace in the bits"""
+    ctx, queue, kernels = gpu
+    ip, ix, da = _system("poisson40")
+    n, nrhs = len(ip) - 1, 2
+    rng = np.random.default_rng(1)
+    B = rand_vec(rng, n * nrhs, np.float64)
+    res = _run(pkg, ctx, ip, ix, da, B, None, nrhs, [40000], {})
+    two = _run(pkg, ctx, ip, ix, da, B, None, nrhs, [40000], {"resident": 0})
+    assert res["kind"] == 0 and two["kind"] == 2 and res["h"].shape == (40001, nrhs)
+    for key in ("h", "x", "r", "d"):
+        assert np.array_equal(res[key], two[key], equal_nan=True), key
