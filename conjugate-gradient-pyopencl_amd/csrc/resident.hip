@@ -1024,7 +1024,10 @@ __global__ __launch_bounds__(kResThreads) void resident_wide_scan_kernel(int n, 
     }
 }
 
-std::mutex g_resident_mutex;   // one resident launch at a time per process: two of them could hold each other's CUs while groups form
+// one resident launch at a time per GPU and process: two of them could hold each other's CUs while groups form (threads that drive
+// different GPUs -- the reference's RHS-sharded multi-device mode -- do not wait for each other)
+std::mutex g_resident_mutex[64];
+std::mutex &resident_mutex(int device) { return g_resident_mutex[(unsigned)device & 63u]; }
 
 // ... and per GPU across the processes of this host (MPI ranks of the reference's driver sharing one GPU each call cg()): an
 // advisory lock on a file named after the device's PCI bus id, held from launch to completion.  Best effort: without a
@@ -1179,9 +1182,9 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
                     void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
                     int n_cus, hipStream_t st, bool *untouched) {
     if (K < 1 || K >= (1 << 18)) return fail(CGAMD_ERR_INVALID, "resident loop: iteration count per launch out of range");
-    std::lock_guard<std::mutex> lock(g_resident_mutex);
     int device = 0;
     CG_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(resident_mutex(device));
     DeviceFileLock device_lock(device);
     // one work-group per CU; groups form from whatever is running (see the header comment).  Test hook: a grid too small for any group.
     const int grid = tune().resident_test_short_grid ? std::max(1, rp.G - 1) : n_cus;
@@ -1328,9 +1331,9 @@ int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs,
     if (untouched) *untouched = false;
     if (tune().resident_test_short_grid) n_cus = std::max(1, wp.G - 1);      // test hook: no group can ever fill
     else n_cus = wp.NG * wp.G;                                               // exactly the groups' work-groups
-    std::lock_guard<std::mutex> lock(g_resident_mutex);
     int device = 0;
     CG_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(resident_mutex(device));
     DeviceFileLock device_lock(device);
     int rc;
     switch (dtype) {
