@@ -731,7 +731,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
     // small groups: every member polls for itself (the extra hop costs more than the pollers: 90k rows, G = 22: 5.9 against 7.1 us)
     const bool xlead = a.G <= 32 || __builtin_amdgcn_readfirstlane(sh.ctl[2]) == 0;
     const bool xpublish = a.G > 32;
-    u64 *xs_rr = a.xres + ((size_t)grp * 16 + (size_t)(__builtin_amdgcn_readfirstlane(sh.ctl[0]) & 15)) * 16, *xs_dq = xs_rr + 8;
+    u64 *xs_rr = a.xres + ((size_t)grp * 16 + (size_t)(__builtin_amdgcn_readfirstlane(sh.ctl[0]) & 7)) * 16, *xs_dq = xs_rr + 8;   // same & 7 as the counter
     // ---- my rows: entries into registers (rows have at most U entries: the host checked)
     const int R0 = m * ROWS;
     constexpr int UP = (U + 1) / 2;
