@@ -18,6 +18,7 @@ DTYPE_CODE = {np.dtype(np.float32): F32, np.dtype(np.float64): F64,
 CODE_DTYPE = {v: k for k, v in DTYPE_CODE.items()}
 
 MATRIX_ON_DEVICE, NO_GRAPH, UNFUSED, DIST_GRAPH, DIST_NO_OVERLAP, DIST_P2P, DIST_P2P_STAGED = 1, 2, 4, 8, 32, 64, 128
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_IO, ERR_COMM, ERR_STATE = range(8)      # cgamd_status (include/cgamd.h)
 
 
 class CgAmdError(RuntimeError):
@@ -89,6 +90,7 @@ def load():
         "cgamd_solver_spmm_rowmajor": (ci, [vp, vp, vp, ci]),
         "cgamd_solver_layout": (ci, [vp]),
         "cgamd_solver_loop_launches": (ci, [vp]),
+        "cgamd_solver_iterate_tol": (ci, [vp, ci, ctypes.c_double, ctypes.POINTER(ci)]),
         "cgamd_transpose": (ci, [vp, ci, ci, ci, vp, vp]),
         "cgamd_solver_spmv_bytes": (ll, [vp]),
         "cgamd_solver_iter_bytes": (ll, [vp, ci]),

@@ -331,6 +331,12 @@ class Solver:
         Returns (x, iterations_run, history).  Single right-hand side."""
         if self.n_rhs != 1:
             raise ValueError("solve_tol handles one right-hand side")
+        if self._lib.cgamd_solver_loop_launches(self.handle) < 2:
+            # resident loop: the stop happens on the device, in the iteration the reference stops in (no read-backs, no re-run)
+            self.set_rhs(b, x0)
+            run_ = ctypes.c_int(0)
+            if self._lib.cgamd_solver_iterate_tol(self.handle, int(maxit), float(tol), ctypes.byref(run_)) == 0:
+                return self.x(), int(run_.value), self.history()
 
         def run(limit, stop_early):
             self.set_rhs(b, x0)
@@ -357,6 +363,12 @@ class Solver:
         iteration that met the tolerance by re-running exactly that many iterations when the check overshot it."""
         if self.n_rhs != 1:
             raise ValueError("pcg handles one right-hand side")
+        if M is None and int(maxit) > 0 and self._lib.cgamd_solver_loop_launches(self.handle) < 2:
+            self.set_preconditioner(None)
+            self.set_rhs(b, x0)             # resident loop: the stop happens on the device (Solver.solve_tol)
+            run_ = ctypes.c_int(0)
+            if self._lib.cgamd_solver_iterate_tol(self.handle, int(maxit), float(tol), ctypes.byref(run_)) == 0:
+                return self.x(), int(run_.value) - 1
         self.set_preconditioner(M)
         try:
             def run(limit, stop_early):

@@ -228,7 +228,7 @@ int resident_max_window(int dtype, int n, const int *ptr_dev, const int *cols_de
 // sync: rp.sync_bytes of device memory.
 int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
                     void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
-                    int n_cus, hipStream_t st, bool *untouched = nullptr);
+                    int n_cus, hipStream_t st, bool *untouched = nullptr, double tol = 0., int *stopped_at = nullptr);
 
 // wide resident loop (resident.hip): chip-wide groups (one right-hand side each at a time), matrix rows in registers
 struct ResidentWidePlan {
@@ -243,7 +243,7 @@ int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, con
 // convention) and the launched loops' r.r partials are NOT maintained -- the caller converts / rebuilds
 int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x,
                          void *r, void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st,
-                         bool *untouched = nullptr);
+                         bool *untouched = nullptr, double tol = 0., int *stopped_at = nullptr);
 
 // [rows][cols] -> [cols][rows]: RHS-major (the reference ABI) <-> row-major
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);

@@ -47,7 +47,8 @@ constexpr int kResRows = 1024;                  // rows per member: every thread
 constexpr long long kResSpinTicks = 400000000;  // a partial sum that does not arrive: 4 s of the 100 MHz wall clock
 
 // header words (unsigned), zeroed before every launch
-enum { kHdrTicket = 0 /* [16] */, kHdrNextRhs = 16, kHdrSolved = 17, kHdrError = 18, kHdrWords = 32 };
+enum { kHdrTicket = 0 /* [16] */, kHdrNextRhs = 16, kHdrSolved = 17, kHdrError = 18, kHdrStop = 19 /* iterations run + 1 when the tolerance stopped the solve */,
+       kHdrWords = 32 };
 // error codes
 enum { kErrClaim = 1, kErrSweep = 2 };
 
@@ -66,6 +67,7 @@ template <typename T> struct ResArgs {
     u64 *gran;                      // [slots][2][gran_stride] granule words
     int gran_stride, lg;            // lg: groups per ticket counter (per XCD when LOCAL)
     long long claim_ticks;          // bound (100 MHz ticks) of the wait for a group to fill while nothing has started
+    double tol;                     // > 0 (one right-hand side): stop before the first iteration whose sqrt|r.r| < tol (or is NaN)
     long long *prof;                // diagnostics (CGAMD_RESIDENT_PROF=1): phase times of one work-group, s_memtime ticks
 };
 #define RES_STAMP(i)                                                                   \
@@ -116,6 +118,11 @@ template <typename T> CG_DEV Pack<T> ld_pack_coh(const T *p) {      // 16 bytes 
     u.w[1] = ld_word(reinterpret_cast<const u64 *>(p) + 1);
     return u.v;
 }
+// sqrt|delta| as the reference's tolerance test forms it (p_h-PY_C-CL.py:1364-1366: sqrt(abs(vdot(r, r))))
+CG_DEV double res_norm(float v) { return sqrt(fabs((double)v)); }
+CG_DEV double res_norm(double v) { return sqrt(fabs(v)); }
+CG_DEV double res_norm(float2 v) { return sqrt(hypot((double)v.x, (double)v.y)); }
+CG_DEV double res_norm(double2 v) { return sqrt(hypot(v.x, v.y)); }
 CG_DEV void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- granules: a partial sum as 32-bit pieces, each in an 8-byte word under the tag of its phase -----------------------
@@ -388,6 +395,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
         const unsigned tag0 = seq << 20;
 
         long long stamp = clock64();
+        int stopped_at = -1;
         for (int k = 0; k < a.K; ++k) {
             const int it = a.it0 + k;
             RES_STAMP(0)
@@ -437,6 +445,10 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
                     a.delta[rhs] = dnT;
                     if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = dnT;
                 }
+            }
+            if (a.tol > 0. && it > 0 && !(res_norm(dlt) >= a.tol)) {     // (the reference tests after an iteration: never before the first)      // uniform: every member holds the same delta
+                stopped_at = it;
+                break;
             }
             if (halo_prefetch_late) halo_prefetch();
             RES_STAMP(1)
@@ -589,6 +601,14 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
             // no barrier here: qs and sh.ws are rewritten only behind the barrier of the next prologue's group_sum
         }
         if (packer) st_pack(at_off(xr, pack_off), px);
+        if (stopped_at >= 0) {       // the tolerance is met after `stopped_at` iterations: delta / beta / history are already recorded
+            if (leader && t == 0) {
+                if (rhs == 0) *a.iter = stopped_at;
+                a.hdr[kHdrStop] = (unsigned)stopped_at + 1u;
+                atomicAdd(a.hdr + kHdrSolved, 1u);
+            }
+            continue;
+        }
         // ---- delta / beta / history of the last iteration (cg_tail_kernel), by the leader's work-group
         if (leader) {
             T bfin, dnT;
@@ -620,6 +640,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
 template <typename T> struct ResWideArgs {
     int n, nrhs, G, NG, npack, it0, K, history_cap, wcap;     // NG groups of G members; a group solves one right-hand side at a time
     long long claim_ticks;          // bound of the wait at the start line
+    double tol;                     // > 0 (one right-hand side): stop before the first iteration whose sqrt|r.r| < tol (or is NaN)
     int d_ready;                    // the caller's d already is beta d + r (state of the three / four-launch loops): iteration it0 + 1 takes it as is
     const T *vals;
     const int *ptr, *cols;
@@ -853,6 +874,8 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
     const unsigned tag0 = seq << 20;
 
     long long stamp = clock64();
+    int it_end = a.it0 + a.K;                        // iterations run when this solve ends (earlier if the tolerance is met)
+    bool stopped = false;
     for (int k = 0; k < a.K; ++k) {
         const int it = a.it0 + k;
         RES_STAMP(0)
@@ -891,6 +914,11 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             }
         } else {
             halo_prefetch();
+        }
+        if (a.tol > 0. && it > 0 && !(res_norm(dlt) >= a.tol)) {     // (the reference tests after an iteration: never before the first)      // uniform: every member holds the same delta
+            it_end = it;
+            stopped = true;
+            break;
         }
         RES_STAMP(1)
         // ---- d_new = beta d + r: my packs to memory (the neighbours' next halo) and into the window
@@ -979,10 +1007,16 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             st_pack(at_off(xr, poff[j]), px[j]);
             if (!pub[j]) {
                 st_pack(at_off(rr, poff[j]), pr[j]);
-                st_pack(at_off(((a.it0 + a.K) & 1) ? d1r : d0r, poff[j]), pd[j]);
+                st_pack(at_off((it_end & 1) ? d1r : d0r, poff[j]), pd[j]);
             }
         }
-    if (leader) {
+    if (stopped) {                                   // delta / beta / history of iteration it_end are already recorded
+        if (leader && t == 0) {
+            if (rhs == 0) *a.iter = it_end;
+            a.hdr[kHdrStop] = (unsigned)it_end + 1u;
+            atomicAdd(a.hdr + kHdrSolved, 1u);
+        }
+    } else if (leader) {
         T bfin, dnT;
         if (!group_scalars<A, T>(a.G, sh, a.hdr, bfin, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, tag0 + 2 * a.K, v); },
                                  [&](A tot, T &b, T &dn) {
@@ -1140,7 +1174,7 @@ static int resident_launch_u(const ResidentPlan &rp, const ResArgs<T> &a, int gr
 template <typename T>
 static int resident_impl(const ResidentPlan &rp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
                          void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
-                         int grid, hipStream_t st) {
+                         int grid, hipStream_t st, double tol) {
     using A = typename VT<T>::acc;
     constexpr int W = sizeof(A) / 4;
     ResArgs<T> a;
@@ -1156,6 +1190,7 @@ static int resident_impl(const ResidentPlan &rp, int n, int nrhs, const void *va
     a.gran_stride = row_blocks * W;
     a.lg = rp.lg;
     a.claim_ticks = (long long)std::max(1, tune().resident_claim_ms) * 100000;
+    a.tol = tol;
     if (getenv("CGAMD_RESIDENT_PROF") && !g_prof_dev) CG_HIP(hipMalloc(&g_prof_dev, 64));
     a.prof = g_prof_dev;
     if (g_prof_dev) CG_HIP(hipMemsetAsync(g_prof_dev, 0, 64, st));
@@ -1180,8 +1215,10 @@ int resident_max_window(int dtype, int n, const int *ptr, const int *cols, int *
 // K iterations of every right-hand side in one launch; synchronises `st` and reports a time-out inside the launch
 int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
                     void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
-                    int n_cus, hipStream_t st, bool *untouched) {
+                    int n_cus, hipStream_t st, bool *untouched, double tol, int *stopped_at) {
     if (K < 1 || K >= (1 << 18)) return fail(CGAMD_ERR_INVALID, "resident loop: iteration count per launch out of range");
+    if (tol > 0. && nrhs != 1) return fail(CGAMD_ERR_INVALID, "resident loop: the tolerance stop handles one right-hand side");
+    if (stopped_at) *stopped_at = -1;
     int device = 0;
     CG_HIP(hipGetDevice(&device));
     std::lock_guard<std::mutex> lock(resident_mutex(device));
@@ -1191,9 +1228,9 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
     if (untouched) *untouched = false;
     int rc;
     switch (dtype) {
-    case 0: rc = resident_impl<float>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st); break;
-    case 1: rc = resident_impl<double>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st); break;
-    case 2: rc = resident_impl<float2>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st); break;
+    case 0: rc = resident_impl<float>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st, tol); break;
+    case 1: rc = resident_impl<double>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st, tol); break;
+    case 2: rc = resident_impl<float2>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st, tol); break;
     default: return fail(CGAMD_ERR_INVALID, "resident loop: bad dtype");
     }
     if (rc) return rc;
@@ -1205,6 +1242,7 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
         *untouched = true;          // no group ever filled: nothing was read or written
         return fail(CGAMD_ERR_STATE, "resident loop: no group of work-groups became resident within " + std::to_string(tune().resident_claim_ms) + " ms");
     }
+    if (stopped_at && hdr[kHdrStop] != 0) *stopped_at = (int)hdr[kHdrStop] - 1;
     if (hdr[kHdrError] != 0 || hdr[kHdrSolved] != (unsigned)nrhs)
         return fail(CGAMD_ERR_HIP, "resident loop: " + std::string(hdr[kHdrError] == kErrSweep ? "a partial sum" : hdr[kHdrError] == kErrClaim ? "a group's claim" : "completion") +
                                        " timed out (solved " + std::to_string(hdr[kHdrSolved]) + " of " + std::to_string(nrhs) +
@@ -1286,12 +1324,13 @@ int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, con
 
 template <typename T>
 static int resident_wide_impl(const ResidentWidePlan &wp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x, void *r,
-                              void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int grid, hipStream_t st) {
+                              void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int grid, hipStream_t st, double tol) {
     using A = typename VT<T>::acc;
     ResWideArgs<T> a;
     a.n = n; a.nrhs = nrhs; a.G = wp.G; a.NG = wp.NG; a.npack = n / Pack<T>::N; a.it0 = it0; a.K = K; a.history_cap = sc.history_cap;
     a.wcap = wp.wcap;
     a.d_ready = d_ready ? 1 : 0;
+    a.tol = tol;
     a.claim_ticks = (long long)std::max(1, tune().resident_claim_ms) * 100000;
     a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
     a.x = static_cast<T *>(x); a.r = static_cast<T *>(r); a.d0 = static_cast<T *>(d0); a.d1 = static_cast<T *>(d1);
@@ -1326,8 +1365,10 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, int nrhs, const
 // K iterations of the single right-hand side in one chip-wide launch; synchronises `st`
 int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x,
                          void *r, void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st,
-                         bool *untouched) {
+                         bool *untouched, double tol, int *stopped_at) {
     if (K < 1 || K >= (1 << 18)) return fail(CGAMD_ERR_INVALID, "wide resident loop: iteration count per launch out of range");
+    if (tol > 0. && nrhs != 1) return fail(CGAMD_ERR_INVALID, "wide resident loop: the tolerance stop handles one right-hand side");
+    if (stopped_at) *stopped_at = -1;
     if (untouched) *untouched = false;
     if (tune().resident_test_short_grid) n_cus = std::max(1, wp.G - 1);      // test hook: no group can ever fill
     else n_cus = wp.NG * wp.G;                                               // exactly the groups' work-groups
@@ -1337,10 +1378,10 @@ int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs,
     DeviceFileLock device_lock(device);
     int rc;
     switch (dtype) {
-    case 0: rc = resident_wide_impl<float>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
-    case 1: rc = resident_wide_impl<double>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
-    case 2: rc = resident_wide_impl<float2>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
-    case 3: rc = resident_wide_impl<double2>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st); break;
+    case 0: rc = resident_wide_impl<float>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st, tol); break;
+    case 1: rc = resident_wide_impl<double>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st, tol); break;
+    case 2: rc = resident_wide_impl<float2>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st, tol); break;
+    case 3: rc = resident_wide_impl<double2>(wp, n, nrhs, vals, ptr, cols, x, r, d0, d1, d_ready, sc, it0, K, sync, n_cus, st, tol); break;
     default: return fail(CGAMD_ERR_INVALID, "wide resident loop: bad dtype");
     }
     if (rc) return rc;
@@ -1352,6 +1393,7 @@ int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs,
         *untouched = true;          // no group ever passed its start line: nothing was read or written
         return fail(CGAMD_ERR_STATE, "wide resident loop: the group did not become resident within " + std::to_string(tune().resident_claim_ms) + " ms");
     }
+    if (stopped_at && hdr[kHdrStop] != 0) *stopped_at = (int)hdr[kHdrStop] - 1;
     if (hdr[kHdrError] != 0 || hdr[kHdrSolved] != (unsigned)nrhs)
         return fail(CGAMD_ERR_HIP, "wide resident loop: " + std::string(hdr[kHdrError] == kErrSweep ? "a partial sum" : hdr[kHdrError] == kErrClaim ? "the start line" : "completion") +
                                        " timed out; cgamd_tune(\"resident_wide\", 0) selects the launched loops");

@@ -60,6 +60,9 @@ struct cgamd_solver {
     // wide resident loop: one chip-wide group for a single right-hand side (resident.hip)
     ResidentWidePlan resw;
     void *resw_sync = nullptr;
+    // cgamd_solver_iterate_tol: tolerance of the device-side stop for the call in progress (0 = none), and what it reported
+    double tol_req = 0.;
+    bool tol_served = false, tol_stopped = false;
 };
 
 static void destroy_graphs(cgamd_solver *s) {
@@ -481,7 +484,7 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
     const bool use_graph = !(s->flags & CGAMD_NO_GRAPH) && !s->graph_failed;
     const bool two = fused2_now(s);
     if (s->resw.ok && !(two && s->res_ok) && !s->rm && !s->mdiag && !(s->flags & (CGAMD_NO_GRAPH | CGAMD_UNFUSED)) &&
-        nIterations >= std::max(1, tune().resident_wide_min)) {
+        (nIterations >= std::max(1, tune().resident_wide_min) || s->tol_req > 0.)) {
         // one chip-wide resident group (single right-hand side, matrix rows in registers).  d ping-pongs inside the launch; handles
         // of the launched loops that keep d in one buffer get it back there, and the launched loops' r.r partials are rebuilt.
         const bool keeps_new_d = !two;       // three / four-launch loops: between iterations d already is beta d + r
@@ -492,24 +495,31 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
             void *cur = dbuf(s, s->iters), *other = cur == s->d ? s->d2 : s->d;
             void *d0 = (s->iters & 1) ? other : cur, *d1 = (s->iters & 1) ? cur : other;
             bool untouched = false;
+            int stop = -1;
+            s->tol_served = s->tol_req > 0.;
             if (int rc = run_cg_resident_wide(s->dtype, s->resw, s->n, s->nrhs, s->vals, s->ptr, s->cols, s->x, s->r, d0, d1,
-                                              keeps_new_d && s->iters > 0, s->sc, s->iters, K, s->resw_sync, s->n_cus, st, &untouched)) {
+                                              keeps_new_d && s->iters > 0, s->sc, s->iters, K, s->resw_sync, s->n_cus, st, &untouched, s->tol_req,
+                                              &stop)) {
                 if (!untouched) return rc;
                 s->resw.ok = false;          // the chip is shared with something that does not yield: this handle keeps the launched loops
                 if (int rc2 = launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, s->nrhs, s->part_rr, s->vgrid, st)) return rc2;
                 return cgamd_solver_iterate(s, left);
             }
-            void *fin = ((s->iters + K) & 1) ? d1 : d0;
-            s->iters += K;
-            left -= K;
-            if (fin != dbuf(s, s->iters))
-                CG_HIP(hipMemcpyAsync(dbuf(s, s->iters), fin, (size_t)s->n * s->nrhs * dtype_size(s->dtype), hipMemcpyDeviceToDevice, st));
-            if (keeps_new_d)                 // d = beta d + r with the beta the launch recorded last (clcg.c:415)
-                if (int rc = launch_aypx(s->dtype, s->n, s->r, dbuf(s, s->iters), s->n, s->sc.beta, s->nrhs, st)) return rc;
+            const int done = stop >= 0 ? stop - s->iters : K;      // the tolerance may end the solve before K iterations
+            void *fin = ((s->iters + done) & 1) ? d1 : d0;
+            s->iters += done;
+            left = stop >= 0 ? 0 : left - K;
+            s->tol_stopped = stop >= 0;
+            if (done > 0) {                  // (a stop before the first iteration leaves d as the caller had it)
+                if (fin != dbuf(s, s->iters))
+                    CG_HIP(hipMemcpyAsync(dbuf(s, s->iters), fin, (size_t)s->n * s->nrhs * dtype_size(s->dtype), hipMemcpyDeviceToDevice, st));
+                if (keeps_new_d)             // d = beta d + r with the beta the launch recorded last (clcg.c:415)
+                    if (int rc = launch_aypx(s->dtype, s->n, s->r, dbuf(s, s->iters), s->n, s->sc.beta, s->nrhs, st)) return rc;
+            }
         }
         return launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, s->nrhs, s->part_rr, s->vgrid, st);
     }
-    if (two && s->res_ok && !(s->flags & CGAMD_NO_GRAPH) && nIterations >= std::max(1, tune().resident_min)) {
+    if (two && s->res_ok && !(s->flags & CGAMD_NO_GRAPH) && (nIterations >= std::max(1, tune().resident_min) || s->tol_req > 0.)) {
         // small system: the whole call in one launch per 2^15 iterations (resident.hip; a launch stays well below the bound of its
         // waits); same state, same bits as the loop below
         const int groups_r = std::max(1, 8 * s->res.lg), rounds_r = (s->nrhs + groups_r - 1) / groups_r;
@@ -517,11 +527,18 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
         for (int left = nIterations; left > 0;) {
             const int K = std::min(left, kmax_r);
             bool untouched = false;
+            int stop = -1;
+            s->tol_served = s->tol_req > 0.;
             if (int rc = run_cg_resident(s->dtype, s->res, s->n, s->nrhs, s->vals, s->ptr, s->cols, s->x, s->r, s->d, s->d2, s->part_rr,
-                                         s->vgrid, s->plan.n_partials, s->sc, s->iters, K, s->res_sync, s->n_cus, st, &untouched)) {
+                                         s->vgrid, s->plan.n_partials, s->sc, s->iters, K, s->res_sync, s->n_cus, st, &untouched, s->tol_req, &stop)) {
                 if (!untouched) return rc;
                 s->res_ok = false;           // no group could form (CUs held by other work): this handle keeps the launched loops
                 return cgamd_solver_iterate(s, left);
+            }
+            if (stop >= 0) {             // the tolerance ended the solve: the launched loops' r.r partials of that state are rebuilt
+                s->iters = stop;
+                s->tol_stopped = true;
+                return launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, s->nrhs, s->part_rr, s->vgrid, st);
             }
             s->iters += K;
             left -= K;
@@ -549,6 +566,34 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
         }
     s->iters = k;
     if (two && nIterations > 0) return launch_cg_tail(s->dtype, s->part_rr, s->vgrid, s->nrhs, s->sc, st);
+    return CGAMD_OK;
+}
+
+// Tolerance-stopping run ON THE DEVICE (one right-hand side, handles that take a resident loop): iterations until
+// sqrt|r.r| < tol (or NaN), at most maxIterations -- the reference's NumPy sub-solver with `tol` (p_h-PY_C-CL.py:1338-1369) and
+// PCG's stopping rule without preconditioner (helmFE_var.py:575-577).  Every member of the resident group sees the same delta and
+// leaves the loop in the same iteration, so x is the iterate of exactly *iterations_run iterations; no read-back per check, no
+// re-run.  CGAMD_ERR_STATE when the handle has no resident loop (the caller then checks the history from the host).
+int cgamd_solver_iterate_tol(cgamd_solver *s, int maxIterations, double tol, int *iterations_run) {
+    if (!s || !iterations_run) return fail(CGAMD_ERR_INVALID, "iterate_tol: null argument");
+    if (!(tol > 0.) || maxIterations < 0) return fail(CGAMD_ERR_INVALID, "iterate_tol: tol must be positive, maxIterations >= 0");
+    if (!s->rhs_set) return fail(CGAMD_ERR_STATE, "iterate_tol: call set_rhs first");
+    if (s->nrhs != 1) return fail(CGAMD_ERR_STATE, "iterate_tol: one right-hand side");
+    {
+        TuneScope ts(&s->tune);
+        const bool local = fused2_now(s) && s->res_ok, wide = s->resw.ok && !s->rm && !s->mdiag;
+        if ((!local && !wide) || (s->flags & (CGAMD_NO_GRAPH | CGAMD_UNFUSED)))
+            return fail(CGAMD_ERR_STATE, "iterate_tol: this handle runs a launched loop (check the history from the host)");
+    }
+    const int start = s->iters;
+    s->tol_req = tol;
+    s->tol_served = s->tol_stopped = false;
+    int rc = maxIterations > 0 ? cgamd_solver_iterate(s, maxIterations) : CGAMD_OK;
+    const bool served = s->tol_served || maxIterations == 0;
+    s->tol_req = 0.;
+    if (rc) return rc;
+    if (!served) return fail(CGAMD_ERR_STATE, "iterate_tol: the resident loop was not available for this call");
+    *iterations_run = s->iters - start;
     return CGAMD_OK;
 }
 

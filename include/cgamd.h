@@ -119,6 +119,10 @@ int cgamd_solver_reload_matrix(cgamd_solver *s, const void *aValues, const int *
 int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_device);
 /* enqueue exactly nIterations iterations (reference clcg.c:297-419); asynchronous, no host sync */
 int cgamd_solver_iterate(cgamd_solver *s, int nIterations);
+/* Tolerance stop on the device (one right-hand side; handles whose loop is resident, cgamd_solver_loop_launches() < 2): runs until
+ * sqrt|r.r| < tol (or NaN), at most maxIterations; *iterations_run = iterations of this call; x is the iterate of exactly that
+ * many (reference: the `tol` loop of p_h-PY_C-CL.py:1338-1369).  CGAMD_ERR_STATE if the handle runs a launched loop. */
+int cgamd_solver_iterate_tol(cgamd_solver *s, int maxIterations, double tol, int *iterations_run);
 /* nIterations iterations with plain launches and a HIP event pair around every SpMV launch on the solver's stream;
  * returns the average in-loop SpMV duration (and optionally the average iteration time), in ms.  Synchronises. */
 int cgamd_solver_iterate_timed(cgamd_solver *s, int nIterations, float *spmv_ms_avg, float *iter_ms_avg);
