@@ -178,3 +178,26 @@ def test_two_threads_on_the_handle_api_without_a_gpu(pkg):
     assert lib.cgamd_tune(b"vec_grid", 0) == 0
     assert not errors, errors
     assert seen == {0: True, 1: True}
+
+
+def test_generator_size_queries_without_gpu(pkg, golden):
+    """non-zero counts of the device generators are closed-form and answered without a GPU (aPointers == NULL): checked against the
+    reference's own matrices (golden) and SURVEY App. B's formula 7 N^2 - 8 N + 2"""
+    import ctypes
+    lib = pkg._lib.load()
+    out = ctypes.c_longlong()
+    g = golden["generators"]
+    for N in (4, 8, 16, 500):
+        pkg._lib.check(lib.cgamd_gen_helm_fe_var(None, pkg._lib.C64, N, 12.0, None, 0.15, N, N, None, None, None, ctypes.byref(out)))
+        assert out.value == 7 * N * N - 8 * N + 2
+        if N <= 16:
+            assert out.value == len(g[f"helm_const_N{N}_indices"])
+    pkg._lib.check(lib.cgamd_gen_helm_fe_var(None, pkg._lib.C64, 20, 7.0, None, 0.2, 10, 7, None, None, None, ctypes.byref(out)))
+    assert out.value == len(g["helm_rect_indices"])
+    d = golden["driver_generators"]
+    N, k, eps, eta, L, Nh, Nv = d["local_rect_params"]
+    pkg._lib.check(lib.cgamd_gen_local_rect(None, pkg._lib.C64, int(N), k, eps, eta, L, int(Nh), int(Nv), None, None, None, ctypes.byref(out)))
+    assert out.value == len(d["local_rect_indices"])
+    pkg._lib.check(lib.cgamd_gen_poisson2d(None, pkg._lib.F64, 8, None, None, None, ctypes.byref(out)))
+    assert out.value == len(d["poisson8_indices"])
+    assert lib.cgamd_gen_helm_fe_var(None, pkg._lib.C64, 1, 12.0, None, 0.15, 1, 1, None, None, None, ctypes.byref(out)) == pkg._lib.ERR_INVALID
