@@ -266,10 +266,11 @@ __global__ __launch_bounds__(kResThreads) void resident_window_kernel(int n, int
 template <typename T, bool LOCAL, int UNROLL, bool WINDOW>
 __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) {
     using A = typename VT<T>::acc;
-    constexpr int E = Pack<T>::N;                    // 2 or 4 (16-byte value types are not handled here)
+    constexpr int E = Pack<T>::N;                    // 4, 2, or 1 (complex128: one value per 16-byte pack)
     constexpr int W = sizeof(A) / 4;                 // granule words per partial
-    constexpr int VT_ = kResRows / E;                // threads with a pack (<= kResThreads)
-    static_assert(E >= 2 && VT_ <= kResThreads, "one pack per thread");
+    constexpr int PPT = E >= 2 ? 1 : 2;              // 16-byte packs of every vector per thread: 1024 rows / E packs on 512 threads
+    constexpr int VT_ = kResRows / E / PPT;          // threads with packs (<= kResThreads); pack j of thread t: local pack t + j VT_
+    static_assert(VT_ <= kResThreads && VT_ * PPT * E == kResRows, "the packs cover the member's rows");
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     T *sv = reinterpret_cast<T *>(dyn_smem);
     int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));
@@ -333,9 +334,14 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
         re[h] = live[h] ? a.ptr[rc + 1] - cfirst : rs[h];
         own_off[h] = (unsigned)(windowed ? rc - w0 : rc) * (unsigned)sizeof(T);
     }
-    const int pack = m * VT_ + t;                    // my 16-byte pack of every vector (t < VT_)
-    const bool packer = t < VT_ && pack < a.npack;
-    const unsigned pack_off = (unsigned)pack * 16u;
+    bool packer[PPT];                                // my 16-byte packs of every vector (t < VT_)
+    unsigned pack_off[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int pack = m * (kResRows / E) + t + j * VT_;
+        packer[j] = t < VT_ && pack < a.npack;
+        pack_off[j] = (unsigned)pack * 16u;
+    }
     u64 *g_dq = a.gran + (size_t)(slot * 2) * a.gran_stride, *g_rr = g_dq + a.gran_stride;
     __syncthreads();
     // WINDOW: the first UNROLL entries of my two rows stay in registers for the whole launch (longer rows: the rest from LDS)
@@ -385,12 +391,14 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
 
         const long long off = (long long)rhs * a.n;
         T *xr = a.x + off, *rr = a.r + off, *d0r = a.d0 + off, *d1r = a.d1 + off;
-        Pack<T> px, pr, pd;
-        if (packer) {
-            px = ld_pack(at_off(xr, pack_off));
-            pr = ld_pack(at_off(rr, pack_off));
-            pd = ld_pack(at_off((a.it0 & 1) ? d1r : d0r, pack_off));
-        }
+        Pack<T> px[PPT], pr[PPT], pd[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (packer[j]) {
+                px[j] = ld_pack(at_off(xr, pack_off[j]));
+                pr[j] = ld_pack(at_off(rr, pack_off[j]));
+                pd[j] = ld_pack(at_off((a.it0 & 1) ? d1r : d0r, pack_off[j]));
+            }
         T dlt = a.delta[rhs];                        // delta of the iteration being run (it0 == 0: delta_0 of set_rhs)
         const unsigned tag0 = seq << 20;
 
@@ -453,18 +461,22 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
             if (halo_prefetch_late) halo_prefetch();
             RES_STAMP(1)
             // ---- my pack of d_new = beta d + r, published for the NEXT iteration's gathers
-            if (packer) {
 #pragma unroll
-                for (int j = 0; j < E; ++j) pd.v[j] = vaypx(bt, pd.v[j], pr.v[j]);
-                st_pack_coh<LOCAL>(at_off(dnew_p, pack_off), pd);
-            }
+            for (int jp = 0; jp < PPT; ++jp)
+                if (packer[jp]) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) pd[jp].v[j] = vaypx(bt, pd[jp].v[j], pr[jp].v[j]);
+                    st_pack_coh<LOCAL>(at_off(dnew_p, pack_off[jp]), pd[jp]);
+                }
             // ---- q[row] = sum a_ij (beta d_old[j] + r[j]) for my two rows, matrix from LDS
             T dn_own[2], sum[2];
             sum[0] = sum[1] = vzero<T>();
             const int rounds = max(re[0] - rs[0], re[1] - rs[1]);
             if constexpr (WINDOW) {
                 char *wb = reinterpret_cast<char *>(win);
-                if (packer) *reinterpret_cast<Pack<T> *>(wb + (size_t)(R0 - w0) * sizeof(T) + (size_t)t * 16) = pd;      // my rows: already beta d + r
+#pragma unroll
+                for (int jp = 0; jp < PPT; ++jp)      // my rows: already beta d + r
+                    if (packer[jp]) *reinterpret_cast<Pack<T> *>(wb + (size_t)(R0 - w0) * sizeof(T) + (size_t)(t + jp * VT_) * 16) = pd[jp];
                 if (ht < nhalo) {                                           // the prefetched first round of the halo
                     Pack<T> oa, ob;
 #pragma unroll
@@ -577,30 +589,41 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_kernel(ResArgs<T> a) 
             RES_STAMP(4)
             if (leader && t == 0) a.alpha[rhs] = al;
             // ---- x += alpha d ; r -= alpha q ; r.r partial of my 256-pack block (axpy2_dot_body)
-            A acc = vzero<A>();
-            if (packer) {
+            A acc = vzero<A>(), acc1 = vzero<A>();      // acc1: the second pack's 256-pack block (complex128)
 #pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    const T qv = qs[t * E + j];
-                    px.v[j] = vadd(px.v[j], vmul(al, pd.v[j]));
-                    pr.v[j] = vsub(pr.v[j], vmul(al, qv));
-                    acc = vadd(acc, to_acc(vmul(pr.v[j], pr.v[j])));
+            for (int jp = 0; jp < PPT; ++jp)
+                if (packer[jp]) {
+                    A part = vzero<A>();
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        const T qv = qs[(t + jp * VT_) * E + j];
+                        px[jp].v[j] = vadd(px[jp].v[j], vmul(al, pd[jp].v[j]));
+                        pr[jp].v[j] = vsub(pr[jp].v[j], vmul(al, qv));
+                        part = vadd(part, to_acc(vmul(pr[jp].v[j], pr[jp].v[j])));
+                    }
+                    st_pack_coh<LOCAL>(at_off(rr, pack_off[jp]), pr[jp]);
+                    if (jp == 0) acc = part; else acc1 = part;
                 }
-                st_pack_coh<LOCAL>(at_off(rr, pack_off), pr);
-            }
             RES_STAMP(5)
-            vblock_sum1(acc, sh);                     // drains the r stores
+            if constexpr (PPT == 1) vblock_sum1(acc, sh);      // drains the r stores
+            else vblock_sum2(acc, acc1, sh);
             RES_STAMP(6)
             if ((t & 255) == 0 && t < VT_) {
-                const int v = m * (4 / E) + (t >> 8);
-                if (v < a.P_rr) {
-                    put_granule<LOCAL>(g_rr + (size_t)v * W, tag0 + 2 * k + 2, acc);
-                    if (k == a.K - 1) a.part_rr[(long long)rhs * a.P_rr + v] = acc;
+#pragma unroll
+                for (int jp = 0; jp < PPT; ++jp) {
+                    const int v = m * (4 / E) + (t >> 8) + jp * (VT_ / 256);      // 256-pack blocks: packs t + jp VT_ of the member's 1024 / E
+                    if (v < a.P_rr) {
+                        const A val = jp == 0 ? acc : acc1;
+                        put_granule<LOCAL>(g_rr + (size_t)v * W, tag0 + 2 * k + 2, val);
+                        if (k == a.K - 1) a.part_rr[(long long)rhs * a.P_rr + v] = val;
+                    }
                 }
             }
             // no barrier here: qs and sh.ws are rewritten only behind the barrier of the next prologue's group_sum
         }
-        if (packer) st_pack(at_off(xr, pack_off), px);
+#pragma unroll
+        for (int jp = 0; jp < PPT; ++jp)
+            if (packer[jp]) st_pack(at_off(xr, pack_off[jp]), px[jp]);
         if (stopped_at >= 0) {       // the tolerance is met after `stopped_at` iterations: delta / beta / history are already recorded
             if (leader && t == 0) {
                 if (rhs == 0) *a.iter = stopped_at;
@@ -1101,7 +1124,7 @@ static int resident_max_span(int n, const int *ptr_host, int *max_row_len) {
 // (row_blocks) and one 16-byte pack per thread in the vector launch (vgrid covers the packs once).
 bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const int *ptr_host, int max_window, ResidentPlan *out) {
     const int mode = tune().resident;
-    if (mode == 0 || !ptr_host || dtype == 3) return false;      // 16-byte values: the two-launch loop
+    if (mode == 0 || !ptr_host) return false;
     const int E = (int)(16 / dtype_size(dtype));
     if (n < 1 || n > kResMaxRows || n % E || n_cus < 8) return false;
     const int npack = n / E;
@@ -1117,8 +1140,9 @@ bool resident_plan(int dtype, int n, int vgrid, int row_blocks, int n_cus, const
     rp.wcap = 0;
     if (max_window > 0 && tune().resident_window != 0 && (size_t)max_window + 4 <= left) rp.wcap = (max_window + 3 + 4) & ~3;      // + a pack of slack
     rp.lds_bytes += (size_t)rp.wcap * dtype_size(dtype);
+    if (dtype == 3 && rp.wcap == 0) return false;      // complex128 only with the LDS window (the per-non-zero form would spill)
     rp.G = (n + kResRows - 1) / kResRows;
-    rp.unroll = (max_len > 10 && max_len <= 12 && dtype == 0) ? 12 : (max_len > 8 && max_len <= 10) ? 10 : 8;
+    rp.unroll = (max_len > 10 && max_len <= 12 && dtype == 0) ? 12 : (max_len > 8 && max_len <= 10 && dtype != 3) ? 10 : dtype == 3 ? 4 : 8;
     const int per_xcd = n_cus / 8;
     rp.local = mode == 2 ? 0 : (rp.G <= per_xcd ? 1 : 0);
     // groups wider than an XCD exchange through memory (write-through stores): measured SLOWER than two launches per iteration
@@ -1196,10 +1220,14 @@ static int resident_impl(const ResidentPlan &rp, int n, int nrhs, const void *va
     if (g_prof_dev) CG_HIP(hipMemsetAsync(g_prof_dev, 0, 64, st));
     // every polled word is zero at the start of every launch (tags count within the launch)
     CG_HIP(hipMemsetAsync(sync, 0, rp.sync_bytes, st));
-    if constexpr (sizeof(T) == 4)
-        if (rp.unroll == 12) return resident_launch_u<T, 12>(rp, a, grid, st);
-    if (rp.unroll == 10) return resident_launch_u<T, 10>(rp, a, grid, st);
-    return resident_launch_u<T, 8>(rp, a, grid, st);
+    if constexpr (sizeof(T) == 16) {        // complex128: windowed instances, 4 entries of a row in registers (the rest of the row from LDS)
+        return rp.local ? resident_launch_inst<T, true, 4, true>(a, rp.lds_bytes, grid, st) : resident_launch_inst<T, false, 4, true>(a, rp.lds_bytes, grid, st);
+    } else {
+        if constexpr (sizeof(T) == 4)
+            if (rp.unroll == 12) return resident_launch_u<T, 12>(rp, a, grid, st);
+        if (rp.unroll == 10) return resident_launch_u<T, 10>(rp, a, grid, st);
+        return resident_launch_u<T, 8>(rp, a, grid, st);
+    }
 }
 
 // the widest column range a member's rows touch (device pass over the column indices; synchronises `st`)
@@ -1231,6 +1259,7 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
     case 0: rc = resident_impl<float>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st, tol); break;
     case 1: rc = resident_impl<double>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st, tol); break;
     case 2: rc = resident_impl<float2>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st, tol); break;
+    case 3: rc = resident_impl<double2>(rp, n, nrhs, vals, ptr, cols, x, r, d0, d1, part_rr, P_rr, row_blocks, sc, it0, K, sync, grid, st, tol); break;
     default: return fail(CGAMD_ERR_INVALID, "resident loop: bad dtype");
     }
     if (rc) return rc;

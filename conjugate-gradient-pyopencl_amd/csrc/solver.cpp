@@ -199,7 +199,7 @@ static int setup_resident(cgamd_solver *s) {
     ResidentPlan rp;
     if (!aligned16(s->x) || !aligned16(s->r) || !aligned16(s->d) || !aligned16(s->d2)) return CGAMD_OK;
     int max_window = 0;
-    if (s->dtype != 3 && s->n % (int)(16 / dtype_size(s->dtype)) == 0)
+    if (s->n % (int)(16 / dtype_size(s->dtype)) == 0)
         if (int rc = resident_max_window(s->dtype, s->n, s->ptr, s->cols, s->sc.iter, s->ctx->stream, &max_window)) return rc;
     if (!resident_plan(s->dtype, s->n, s->vgrid, s->plan.n_partials, s->n_cus, ph, max_window, &rp)) return CGAMD_OK;
     if (s->res_sync && rp.sync_bytes > s->res.sync_bytes) { (void)hipFree(s->res_sync); s->res_sync = nullptr; }
