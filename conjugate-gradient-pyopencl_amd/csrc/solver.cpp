@@ -503,6 +503,7 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
                 if (!untouched) return rc;
                 s->resw.ok = false;          // the chip is shared with something that does not yield: this handle keeps the launched loops
                 if (int rc2 = launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, s->nrhs, s->part_rr, s->vgrid, st)) return rc2;
+                if (s->tol_req > 0.) { s->tol_served = false; return rc; }      // (the launched loops have no device-side stop: the caller checks from the host)
                 return cgamd_solver_iterate(s, left);
             }
             const int done = stop >= 0 ? stop - s->iters : K;      // the tolerance may end the solve before K iterations
@@ -533,6 +534,7 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
                                          s->vgrid, s->plan.n_partials, s->sc, s->iters, K, s->res_sync, s->n_cus, st, &untouched, s->tol_req, &stop)) {
                 if (!untouched) return rc;
                 s->res_ok = false;           // no group could form (CUs held by other work): this handle keeps the launched loops
+                if (s->tol_req > 0.) { s->tol_served = false; return rc; }
                 return cgamd_solver_iterate(s, left);
             }
             if (stop >= 0) {             // the tolerance ended the solve: the launched loops' r.r partials of that state are rebuilt

@@ -80,3 +80,20 @@ def test_iterate_tol_argument_and_state_errors(pkg, gpu):
     x, its, h = s.solve_tol(np.ones(1600), tol=1e-6)                                      # ... the host scheme still works
     assert 0 < its < 1000
     s.close()
+
+
+def test_tolerance_run_survives_a_resident_launch_that_cannot_start(pkg, gpu):
+    """the resident launch gives up untouched (test hook: one work-group too few): iterate_tol reports it, Solver.solve_tol goes on with
+    the host-driven scheme on the launched loops and returns what it always returned"""
+    ctx, queue, kernels = gpu
+    ip, ix, da = cg_numpy.poisson2d(40)
+    b = 1.0 + rand_vec(np.random.default_rng(9), 1600, np.float64)
+    x0, it0, h0, k0, d0 = _solve(pkg, ctx, ip, ix, da, b, 1e-8, 2000, {"resident": 0})
+    lib = pkg._lib.load()
+    pkg._lib.check(lib.cgamd_tune(b"resident_claim_ms", 40))
+    try:
+        x1, it1, h1, k1, d1 = _solve(pkg, ctx, ip, ix, da, b, 1e-8, 2000, {"resident_test_short_grid": 1})
+    finally:
+        pkg._lib.check(lib.cgamd_tune(b"resident_claim_ms", 15000))
+        pkg._lib.check(lib.cgamd_tune(b"resident_test_short_grid", 0))
+    assert k1 == 0 and it1 == it0 and np.array_equal(x1, x0)
