@@ -11,7 +11,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch  # noqa: E402
 
 pkg = importlib.import_module("conjugate-gradient-pyopencl_amd")
@@ -68,15 +67,14 @@ if "c2f32" in which:
     ip, ix, da = pkg.generators.poisson2d(ctx, 1000, dtype=np.float32)
     run("C2 2D 5-pt N=1M f32", ip, ix, da, np.float32, 1)
 if "c3" in which or "c3c64" in which:
-    import cg_numpy
-    N = 500
-    hp, hx, hd = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
-    ip, ix = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
+    N = 500          # helmFE_var(N=500, omega=12, C=1, rho=0.15), generated on the device (csrc/generators.hip)
     if "c3" in which:
-        run("C3 Helmholtz FE N=250k c128", ip, ix, torch.from_numpy(hd).to(dev), np.complex128, 1)
+        ip, ix, da = pkg.generators.helm_fe_var(ctx, N, 12.0, None, 0.15, dtype=np.complex128)
+        run("C3 Helmholtz FE N=250k c128", ip, ix, da, np.complex128, 1)
     if "c3c64" in which:
-        run("C3 Helmholtz FE N=250k c64 (reference dtype)", ip, ix, torch.from_numpy(hd.astype(np.complex64)).to(dev), np.complex64, 1)
-        run("C3 Helmholtz FE N=250k c64 nrhs=9 (as_prec shape)", ip, ix, torch.from_numpy(hd.astype(np.complex64)).to(dev), np.complex64, 9, iters=100)
+        ip, ix, da = pkg.generators.helm_fe_var(ctx, N, 12.0, None, 0.15, dtype=np.complex64)
+        run("C3 Helmholtz FE N=250k c64 (reference dtype)", ip, ix, da, np.complex64, 1)
+        run("C3 Helmholtz FE N=250k c64 nrhs=9 (as_prec shape)", ip, ix, da, np.complex64, 9, iters=100)
 if "c4" in which:
     ip, ix, da = pkg.generators.poisson2d(ctx, 1000, dtype=np.float64)
     run("C4 SpMM nrhs=32 N=1M f64", ip, ix, da, np.float64, 32, iters=50, reps=10)
@@ -107,11 +105,8 @@ if "c4" in which or "c4mfma" in which:
 if "asprec" in which:
     # the reference's own sub-domain solve (as_prec, p_h-PY_C-CL.py:1918-1953): complex64, ~16k rows (helmFE_var(128) has the
     # pattern and size of local_rect for W_s + 2 ol = 128), n_my = 9 right-hand sides, CGMaxIT = 256 fixed iterations
-    import cg_numpy
     N = 128
-    hp, hx, hd = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
-    ip, ix = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
-    da = torch.from_numpy(hd.astype(np.complex64)).to(dev)
+    ip, ix, da = pkg.generators.helm_fe_var(ctx, N, 12.0, None, 0.15, dtype=np.complex64)
     for nrhs in (9, 1):
         run(f"as_prec shape: helmFE_var(128) c64 n=16384 nrhs={nrhs}", ip, ix, da, np.complex64, nrhs, iters=2560, reps=30)
 if "mid" in which:
@@ -124,12 +119,9 @@ if "report" in which:
     # context only: the one matrix of the upstream report that can be regenerated offline --
     # helm_fem: complex, n = 16 384, nnz = 113 666 = helmFE_var(N=128); the report ran 5000 iterations in fp32 complex and
     # counts 8 nnz + 40 n flops per iteration (its Table II): 2.390 GFLOPS on an RTX 2080S, 0.351 on an i5-8250U
-    import cg_numpy
     N = 128
-    hp, hx, hd = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
-    ip, ix = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
-    da = torch.from_numpy(hd.astype(np.complex64)).to(dev)
-    n, nnz = N * N, len(hx)
+    ip, ix, da = pkg.generators.helm_fe_var(ctx, N, 12.0, None, 0.15, dtype=np.complex64)
+    n, nnz = N * N, int(ix.numel())
     s = pkg.Solver(ctx, n, nnz, da, ip, ix, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=np.complex64)
     b = torch.full((n,), 5.0, dtype=torch.complex64, device=dev)
     torch.cuda.synchronize()

@@ -12,9 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch  # noqa: E402
-import cg_numpy  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--nrhs", type=int, default=9)
@@ -30,14 +28,13 @@ ctx = pkg.Context(0)
 dev = torch.device("cuda", 0)
 dt = {"c64": np.complex64, "c128": np.complex128, "f64": np.float64, "f32": np.float32}[args.dtype]
 if args.N < 0:          # 3-D 7-point Laplacian (-N)^3
-    hp, hx, hd = cg_numpy.laplace3d(-args.N, -args.N, -args.N)
+    ip, ix, da = pkg.generators.laplace3d(ctx, -args.N, -args.N, -args.N, dtype=dt)
 elif args.dtype in ("c64", "c128"):
-    hp, hx, hd = cg_numpy.helm_fe_var(args.N, 12.0, np.ones((args.N - 1, args.N - 1)), 0.15, args.N, args.N)
+    ip, ix, da = pkg.generators.helm_fe_var(ctx, args.N, 12.0, None, 0.15, dtype=dt)
 else:
-    hp, hx, hd = cg_numpy.poisson2d(args.N)
-n = len(hp) - 1
-ip, ix = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
-da = torch.from_numpy(hd.astype(dt)).to(dev)
+    ip, ix, da = pkg.generators.poisson2d(ctx, args.N, dtype=dt)
+n = int(ip.numel()) - 1
+nnz = int(ix.numel())
 tdt = pkg.generators.torch_dtype(dt)
 b = torch.full((n * args.nrhs,), 5.0, dtype=tdt, device=dev)
 solvers = []
@@ -45,7 +42,7 @@ for cfg in args.cfgs:
     kv = [x.split("=") for x in cfg.split(",") if "=" in x]
     for k, v in kv:
         pkg._lib.check(lib.cgamd_tune(k.encode(), int(v)))
-    s = pkg.Solver(ctx, n, len(hx), da, ip, ix, args.nrhs, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=dt)
+    s = pkg.Solver(ctx, n, nnz, da, ip, ix, args.nrhs, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=dt)
     for k, v in kv:
         pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_min": 8, "resident_window": 1, "resident_wide": 1}.get(k, 0)))
     solvers.append((cfg, s, []))

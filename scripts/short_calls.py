@@ -2,7 +2,7 @@
 """Wall time of short iterate(K) calls: chip-wide resident loop against the launched loops (break-even call length)."""
 import importlib, sys, time, os
 import numpy as np
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle"))
+sys.path.insert(0, os.getcwd())
 import torch
 pkg = importlib.import_module("conjugate-gradient-pyopencl_amd")
 lib = pkg._lib.load()

@@ -14,7 +14,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def main():
@@ -34,11 +33,10 @@ def main():
     ctx = pkg.Context(0)
     dev = torch.device("cuda", 0)
     if args.helm:
-        import cg_numpy
-        hp, hx, hd = cg_numpy.helm_fe_var(args.helm, 12.0, np.ones((args.helm - 1, args.helm - 1)), 0.15, args.helm, args.helm)
+        if np.dtype(dtype).kind != "c":
+            raise SystemExit("--helm: the finite-element Helmholtz matrix is complex (--dtype c64)")
         n = args.helm ** 2
-        ip, ix = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
-        da = torch.from_numpy(hd.astype(dtype)).to(dev)
+        ip, ix, da = pkg.generators.helm_fe_var(ctx, args.helm, 12.0, None, 0.15, dtype=dtype)
     else:
         n = args.N * args.N
         ip, ix, da = pkg.generators.poisson2d(ctx, args.N, dtype=dtype)

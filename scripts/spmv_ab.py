@@ -35,12 +35,10 @@ def main():
     ctx = pkg.Context(0)
     dev = torch.device("cuda", 0)
     if args.helm:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import cg_numpy
-        hp, hx, hd = cg_numpy.helm_fe_var(args.helm, 12.0, np.ones((args.helm - 1, args.helm - 1)), 0.15, args.helm, args.helm)
+        if np.dtype(dtype).kind != "c":
+            raise SystemExit("--helm: the finite-element Helmholtz matrix is complex (--dtype c64 / c128)")
         n = args.helm ** 2
-        indptr, indices = torch.from_numpy(hp).to(dev), torch.from_numpy(hx).to(dev)
-        data = torch.from_numpy(hd.astype(dtype)).to(dev)
+        indptr, indices, data = pkg.generators.helm_fe_var(ctx, args.helm, 12.0, None, 0.15, dtype=dtype)
     elif args.stencil27:
         import scipy.sparse as sp
         m = args.stencil27
