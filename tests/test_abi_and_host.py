@@ -144,6 +144,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "cg_oracle" not in text and "cg_numpy" not in text and "oracle/" not in text, f
+    # ... nor the measurement scripts (their matrices come from the product's device generators); bench.py only in its CPU-baseline leg
+    for f in os.listdir(os.path.join(ROOT, "scripts")):
+        if f.endswith(".py"):
+            text = open(os.path.join(ROOT, "scripts", f), errors="replace").read()
+            assert "cg_oracle" not in text and "cg_numpy" not in text, f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    lo, hi = bench.index("def cpu_baseline"), bench.index("def spawn_ranks")
+    outside = bench[:lo] + bench[hi:]
+    assert "import cg_oracle" in bench[lo:hi]
+    assert "cg_oracle" not in outside.replace("oracle/cg_oracle", "") and "cg_numpy" not in outside and "import cg_" not in outside
 
 
 def test_two_threads_on_the_handle_api_without_a_gpu(pkg):
