@@ -232,6 +232,14 @@ class Solver:
                                             ctypes.byref(h)))
         self.handle = h
 
+    def reload_matrix(self, a_values, a_pointers, a_cols):
+        """new values / pattern of the same size and non-zero count from HOST arrays into a handle that owns its matrix
+        (what the stateless cg() does between calls, include/cgamd.h)"""
+        a_values = np.ascontiguousarray(a_values, dtype=self.dtype)
+        a_pointers = np.ascontiguousarray(a_pointers, dtype=np.int32)
+        a_cols = np.ascontiguousarray(a_cols, dtype=np.int32)
+        check(self._lib.cgamd_solver_reload_matrix(self.handle, ptr(a_values), ptr(a_pointers), ptr(a_cols)))
+
     def set_rhs(self, b, x0=None, on_device=False):
         if not on_device:
             b = np.ascontiguousarray(np.asarray(b).reshape(-1), dtype=self.dtype)
@@ -306,6 +314,11 @@ class Solver:
     @property
     def spmv_bytes(self):
         return self._lib.cgamd_solver_spmv_bytes(self.handle)
+
+    @property
+    def index_codes(self):
+        """distinct (column - row) offsets when the SpMV reads one-byte column codes instead of aCols, else 0"""
+        return self._lib.cgamd_solver_index_codes(self.handle)
 
     def iter_bytes(self, fused=False):
         return self._lib.cgamd_solver_iter_bytes(self.handle, int(fused))

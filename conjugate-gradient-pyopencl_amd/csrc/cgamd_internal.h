@@ -43,6 +43,10 @@ struct SpmvPlan {
     int n_partials = 0;  // fused-dot partials per RHS written by that kernel
     int nt = 1;          // matrix stream loaded non-temporally (finalize_spmv_plan: off when the matrix fits the Infinity Cache)
     int vec_nt = 3;      // axpy2_dot streaming hints (see Tuning::vec_nt), resolved by finalize_spmv_plan
+    // one-byte column codes of the single-RHS row-block kernel (build_index_codes; owned by the caller, not by the plan)
+    const unsigned char *codes = nullptr;   // [nnz + pad]: aCols[j] = row(j) + dict[codes[j]]
+    const int *dict = nullptr;              // [256] distinct (column - row) offsets of the matrix
+    const int *codes_for = nullptr;         // the aCols array the codes were made from
 };
 SpmvPlan make_spmv_plan(int n);
 // fills plan->max_span / chunk_span from the matrix structure; synchronises `st`; scratch_dev: >= 32 bytes
@@ -51,6 +55,13 @@ int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scrat
 // pointer array or an out-of-range column / index; synchronises `st`; scratch_dev: >= 4 bytes
 int validate_csr_device(int n, long long nnz, int ncols, const int *ptr_dev, const int *cols_dev, const int *index_dev, int n_index,
                         int index_bound, int *scratch_dev, hipStream_t st);
+// Column indices as one-byte codes into a dictionary of the matrix's distinct (column - row) offsets: 4 -> 1 byte per
+// non-zero of index traffic for every matrix with at most 256 distinct offsets (stencils and FE matrices on structured grids:
+// 5 to 27).  Exact: the kernel rebuilds the very same column, so results do not change by a bit.  On success *codes_out
+// (nnz + 64 bytes) and *dict_out (256 ints) are device allocations the caller frees; both null when the matrix has more
+// offsets than that.  Synchronises `st`.
+int build_index_codes(int n, long long nnz, const int *ptr_dev, const int *cols_dev, hipStream_t st, unsigned char **codes_out,
+                      int **dict_out, int *distinct_out);
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols);
 constexpr int kChunkBytes = 32 * 1024;      // kind 7: preferred LDS chunk slice (4-5 work-groups per CU)
 constexpr int kMaxChunkBytes = 48 * 1024;   //         largest accepted, with 8 lanes per row (3 work-groups per CU)
@@ -97,6 +108,9 @@ struct Tuning {
     int spmv_slice_kb = 0;  // largest 256-row LDS slice the one-lane-per-row kernel accepts, in KB (0 = kMaxSliceBytes)
     int spmv_chunk_kb = 0;  // chunked row-block kernel: preferred LDS chunk in KB (0 = kChunkBytes); smaller -> more lanes per row
     int spmv_chunked = 1;   // rows too dense for the row-block kernel: chunked row-block kernel (0 = generic kernel)
+    int index_codes = 1;    // single-RHS row-block SpMV on one-byte column codes (0 = always aCols)
+    int index_codes_min_mb = 32;    // ... for matrices above this size (N = 1M 7-point fp64, 83 MB: CG 35.4 -> 33.2 us/iteration; 2.56M rows
+                                    // 76.4 -> 68.1; 10M 274 -> 241; smaller systems run the resident / two-launch loops, which read aCols)
     int spmv_ilv = -1;      // slice staging: value stream interleaved across lanes in 16-byte chunks (1), quads per lane (0), -1 auto
     int spmv_cycle = 64;    // row-block schedule: block-cyclic over the XCDs, cycle length in row blocks (1 = contiguous eighths)
     int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)

@@ -58,6 +58,8 @@ template <typename T> struct SpmvArgs {
     int rb_count;
     int cap;   // row-block kernel: LDS slice capacity in entries (multiple of 4)
     int cycle; // row-block kernel: block-cyclic schedule over the XCDs, cycle length in row blocks (1 = one contiguous eighth per XCD)
+    const unsigned char *codes;   // coded row-block kernel: one byte per non-zero, aCols[j] = row + dict[codes[j]] (build_index_codes)
+    const int *dict;              // [256]
 };
 
 // Row-block schedule shared by the row-block kernels: work-group b runs on XCD b%8 as that XCD's (b/8)-th block.
@@ -244,9 +246,9 @@ template <> struct Chunk16<float> { using V = f32x4; };
 template <> struct Chunk16<double> { using V = f64x2; };
 template <> struct Chunk16<float2> { using V = f32x4; };
 template <> struct Chunk16<double2> { using V = f64x2; };
-template <typename T, int BLOCK, bool NT, bool FULL>
+template <typename T, int BLOCK, bool NT, bool FULL, bool CODED = false>
 CG_DEV void stage_slice_ilv(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
-                            T *sv, int *sc) {
+                            T *sv, int *sc, const unsigned char *__restrict__ codes = nullptr) {
     using V = typename Chunk16<T>::V;
     constexpr int EPC = 16 / (int)sizeof(T);   // values per chunk
     constexpr int NV = 4 / EPC;                // chunks per lane and quad region
@@ -254,12 +256,18 @@ CG_DEV void stage_slice_ilv(const T *__restrict__ vals, const int *__restrict__ 
     for (long long base = cfirst; base < p1; base += 8 * BLOCK) {
         V ch[2][NV];
         i32x4 cc[2];
+        unsigned cw[2];
         long long ev[2][NV], qc[2];
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg) {
             const long long rbase = base + (long long)rg * 4 * BLOCK;
             qc[rg] = rbase + 4 * t;
-            if (qc[rg] < p1 && (FULL || qc[rg] + 4 <= nnz)) cc[rg] = ld16<i32x4, NT>(cols + qc[rg]);
+            if constexpr (CODED) {      // four one-byte codes per lane; the code array is padded, no tail handling
+                if (qc[rg] < p1) {
+                    const unsigned *cp = reinterpret_cast<const unsigned *>(codes + qc[rg]);
+                    cw[rg] = NT ? __builtin_nontemporal_load(cp) : *cp;
+                }
+            } else if (qc[rg] < p1 && (FULL || qc[rg] + 4 <= nnz)) cc[rg] = ld16<i32x4, NT>(cols + qc[rg]);
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 ev[rg][k] = rbase + (long long)wave * 4 * kWave + (long long)(k * kWave + lane) * EPC;
@@ -270,7 +278,9 @@ CG_DEV void stage_slice_ilv(const T *__restrict__ vals, const int *__restrict__ 
         for (int rg = 0; rg < 2; ++rg) {
             if (qc[rg] < p1) {
                 const int o = (int)(qc[rg] - cfirst);
-                if (FULL || qc[rg] + 4 <= nnz) {
+                if constexpr (CODED) {
+                    *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(sc) + o) = cw[rg];
+                } else if (FULL || qc[rg] + 4 <= nnz) {
                     *reinterpret_cast<i32x4 *>(sc + o) = cc[rg];
                 } else {
                     for (int j = 0; j < 4; ++j) sc[o + j] = qc[rg] + j < nnz ? cols[qc[rg] + j] : 0;
@@ -294,7 +304,12 @@ CG_DEV void stage_slice_ilv(const T *__restrict__ vals, const int *__restrict__ 
 template <typename T> constexpr bool kIlvDefault = true;   // N=10M SpMV: f64 186 -> 165 us, c64 186 -> 166, c128 435 -> 314, f32 109 -> 105 (ab_ilv.log)
 template <typename T, int BLOCK, bool NT, int POL = -1>
 CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1, T *sv,
-                        int *sc) {
+                        int *sc, const unsigned char *__restrict__ codes = nullptr) {
+    if (POL == -3) {       // lane-interleaved value chunks + one-byte column codes
+        if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true, true>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
+        else stage_slice_ilv<T, BLOCK, NT, false, true>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
+        return;
+    }
     if (POL == -2) {       // lane-interleaved value chunks
         if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true>(vals, cols, nnz, cfirst, p1, sv, sc);
         else stage_slice_ilv<T, BLOCK, NT, false>(vals, cols, nnz, cfirst, p1, sv, sc);
@@ -335,10 +350,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     using A = typename VT<T>::acc;
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     T *sv = reinterpret_cast<T *>(dyn_smem);                       // [cap]
-    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));   // [cap]
+    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));   // [cap] (coded form: cap BYTES)
     __shared__ A red[BLOCK / kWave];
+    constexpr bool CODED = POL == -3;
+    __shared__ int sdict[CODED ? BLOCK : 1];
 
     const int t = threadIdx.x;
+    if constexpr (CODED) sdict[t] = a.dict[t];      // BLOCK == 256 entries; visible after the staging barrier
     int rb;
     if (a.rb_list) {                       // explicit subset (interior or boundary row blocks of a partition)
         if ((int)blockIdx.x >= a.rb_count) return;
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
-    stage_slice<T, BLOCK, NT, POL>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+    stage_slice<T, BLOCK, NT, POL>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc, a.codes);
     const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
     __syncthreads();
     // Row walk, branch-free inside a batch: out-of-range slots re-read the row's LAST entry (a valid LDS slot
@@ -374,8 +392,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
             const int idx = min(k + j, e - 1);
-            cj[j] = sc[idx];
+            if constexpr (CODED) cj[j] = reinterpret_cast<const unsigned char *>(sc)[idx];
+            else cj[j] = sc[idx];
             av[j] = sv[idx];
+        }
+        if constexpr (CODED) {
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) cj[j] = row + sdict[cj[j]];
         }
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) xv[j] = xr[cj[j]];
@@ -1889,6 +1912,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     a.partials = static_cast<typename VT<T>::acc *>(partials);
     a.row_blocks = plan.row_blocks;
     a.rb_list = rb_list; a.rb_count = rb_count;
+    a.codes = nullptr; a.dict = nullptr;
     const bool vec = aligned16(vals) && aligned16(cols);
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
@@ -1897,15 +1921,22 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     if (variant == 5) {
         a.cap = (plan.max_span + 3) & ~3;
         a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
-        const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
         dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : rowblock_grid(plan.row_blocks, a.cycle), nrhs);
         if (rb_list && rb_count <= 0) return CGAMD_OK;
         const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
         // value stream interleaved across the lanes in 16-byte chunks (stage_slice_ilv): "spmv_ilv" 1/0, -1 = auto
         const bool ilv = tune().spmv_ilv >= 0 ? (tune().spmv_ilv != 0) : kIlvDefault<T>;
+        // one-byte column codes instead of aCols (build_index_codes; the codes belong to THIS cols array)
+        const bool coded = ilv && nrhs == 1 && plan.codes && plan.codes_for == cols && tune().index_codes != 0;
+        a.codes = coded ? plan.codes : nullptr;
+        a.dict = coded ? plan.dict : nullptr;
+        const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
 #define CG_RB(NT, UNR)                                                                                                  \
     do {                                                                                                                \
-        if (ilv) {                                                                                                      \
+        if (coded) {                                                                                                    \
+            if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -3>), g5, block, lds, st, a);        \
+            else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -3>), g5, block, lds, st, a);            \
+        } else if (ilv) {                                                                                                      \
             if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -2>), g5, block, lds, st, a);        \
             else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -2>), g5, block, lds, st, a);            \
         } else {                                                                                                        \
@@ -2028,6 +2059,105 @@ int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scrat
     for (int lv = 0; lv < 3; ++lv) plan->chunk_span[lv] = spans[lv + 1];
     plan->max_quad = spans[4];
     (void)cols_dev;
+    return CGAMD_OK;
+}
+
+// ---- one-byte column codes (SpmvPlan::codes) ---------------------------------------------------------------------------
+constexpr int kDictSlots = 1024;            // open-addressing table of the distinct offsets (<= 256 accepted)
+constexpr int kDictEmpty = -2147483647 - 1;
+CG_DEV unsigned dict_hash(int d) { return ((unsigned)d * 2654435761u) >> 22; }   // 10 bits
+// one lane per row: every (column - row) offset goes into the table; count[0] = distinct offsets so far
+__global__ __launch_bounds__(256) void index_offsets_kernel(int n, const int *__restrict__ ptr, const int *__restrict__ cols,
+                                                            int *table, int *count) {
+    for (long long row = blockIdx.x * 256LL + threadIdx.x; row < n; row += 256LL * gridDim.x) {
+        if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 256) return;     // not codable: stop early
+        int last = kDictEmpty;
+        for (int j = ptr[row], e = ptr[row + 1]; j < e; ++j) {
+            const int d = cols[j] - (int)row;
+            if (d == last) continue;
+            last = d;
+            unsigned h = dict_hash(d);
+            int probes = 0;
+            for (; probes < kDictSlots; ++probes, h = (h + 1) & (kDictSlots - 1)) {
+                int v = __hip_atomic_load(table + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v == kDictEmpty) {
+                    v = atomicCAS(table + h, kDictEmpty, d);
+                    if (v == kDictEmpty) { atomicAdd(count, 1); break; }
+                }
+                if (v == d) break;
+            }
+            if (probes == kDictSlots) { atomicAdd(count, kDictSlots); return; }       // table full
+        }
+    }
+}
+// table slot -> code (position of the offset in the sorted dictionary); one lane per row writes its codes
+__global__ __launch_bounds__(256) void index_encode_kernel(int n, const int *__restrict__ ptr, const int *__restrict__ cols,
+                                                           const int *__restrict__ table, const unsigned char *__restrict__ slot_code,
+                                                           unsigned char *__restrict__ codes) {
+    __shared__ int stab[kDictSlots];
+    __shared__ unsigned char scode[kDictSlots];
+    for (int i = threadIdx.x; i < kDictSlots; i += 256) { stab[i] = table[i]; scode[i] = slot_code[i]; }
+    __syncthreads();
+    for (long long row = blockIdx.x * 256LL + threadIdx.x; row < n; row += 256LL * gridDim.x) {
+        for (int j = ptr[row], e = ptr[row + 1]; j < e; ++j) {
+            const int d = cols[j] - (int)row;
+            unsigned h = dict_hash(d);
+            while (stab[h] != d) h = (h + 1) & (kDictSlots - 1);      // every offset is in the table
+            codes[j] = scode[h];
+        }
+    }
+}
+
+int build_index_codes(int n, long long nnz, const int *ptr_dev, const int *cols_dev, hipStream_t st, unsigned char **codes_out,
+                      int **dict_out, int *distinct_out) {
+    *codes_out = nullptr;
+    *dict_out = nullptr;
+    *distinct_out = 0;
+    if (n <= 0 || nnz <= 0) return CGAMD_OK;
+    int *work = nullptr;        // [1024 table | 1 count | 256 dict]
+    CG_HIP(hipMalloc((void **)&work, (kDictSlots + 64 + 256) * sizeof(int) + kDictSlots));
+    std::vector<int> table(kDictSlots + 1, kDictEmpty);
+    table[kDictSlots] = 0;
+    hipError_t e = hipMemcpyAsync(work, table.data(), (kDictSlots + 1) * sizeof(int), hipMemcpyHostToDevice, st);
+    int g = (int)std::min<long long>((n + 255LL) / 256, 8192);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(index_offsets_kernel, dim3(g), dim3(256), 0, st, n, ptr_dev, cols_dev, work, work + kDictSlots);
+        e = hipMemcpyAsync(table.data(), work, (kDictSlots + 1) * sizeof(int), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(work); return fail(CGAMD_ERR_HIP, std::string("build_index_codes: ") + hipGetErrorString(e)); }
+    const int distinct = table[kDictSlots];
+    if (distinct < 1 || distinct > 256) { (void)hipFree(work); return CGAMD_OK; }
+    std::vector<int> dict;
+    for (int i = 0; i < kDictSlots; ++i)
+        if (table[i] != kDictEmpty) dict.push_back(table[i]);
+    std::sort(dict.begin(), dict.end());
+    std::vector<unsigned char> slot_code(kDictSlots, 0);
+    for (int i = 0; i < kDictSlots; ++i)
+        if (table[i] != kDictEmpty) slot_code[i] = (unsigned char)(std::lower_bound(dict.begin(), dict.end(), table[i]) - dict.begin());
+    dict.resize(256, dict[0]);
+    unsigned char *codes = nullptr;
+    int *dict_dev = nullptr;
+    unsigned char *slot_dev = reinterpret_cast<unsigned char *>(work + kDictSlots + 64 + 256);
+    e = hipMalloc((void **)&codes, (size_t)nnz + 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&dict_dev, 256 * sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(codes + nnz, 0, 64, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dict_dev, dict.data(), 256 * sizeof(int), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(slot_dev, slot_code.data(), kDictSlots, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(index_encode_kernel, dim3(g), dim3(256), 0, st, n, ptr_dev, cols_dev, work, slot_dev, codes);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(work);
+    if (e != hipSuccess) {
+        if (codes) (void)hipFree(codes);
+        if (dict_dev) (void)hipFree(dict_dev);
+        return fail(CGAMD_ERR_HIP, std::string("build_index_codes: ") + hipGetErrorString(e));
+    }
+    *codes_out = codes;
+    *dict_out = dict_dev;
+    *distinct_out = distinct;
     return CGAMD_OK;
 }
 

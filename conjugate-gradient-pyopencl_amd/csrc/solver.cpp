@@ -60,6 +60,9 @@ struct cgamd_solver {
     // wide resident loop: one chip-wide group for a single right-hand side (resident.hip)
     ResidentWidePlan resw;
     void *resw_sync = nullptr;
+    unsigned char *codes = nullptr;   // one-byte column codes of the single-RHS SpMV (build_index_codes), with their dictionary
+    int *dict = nullptr;
+    int n_offsets = 0;                // distinct (column - row) offsets behind the codes; 0 = the SpMV reads aCols
     // cgamd_solver_iterate_tol: tolerance of the device-side stop for the call in progress (0 = none), and what it reported
     double tol_req = 0.;
     bool tol_served = false, tol_stopped = false;
@@ -180,6 +183,21 @@ static int setup_resident_wide(cgamd_solver *s) {
         if (int rc = dmalloc(&s->resw_sync, wp.sync_bytes, "wide resident sync words")) return rc;
     s->resw = wp;
     s->rm_ok = false;       // the chip-wide resident groups keep the caller's RHS-major layout (and beat the row-major loop: 1M x 32 fp64)
+    return CGAMD_OK;
+}
+
+// (re)build the one-byte column codes for the matrix now in s->cols; dropped when they do not apply
+static int setup_index_codes(cgamd_solver *s) {
+    if (s->codes) { (void)hipFree(s->codes); s->codes = nullptr; }
+    if (s->dict) { (void)hipFree(s->dict); s->dict = nullptr; }
+    s->plan.codes = nullptr; s->plan.dict = nullptr; s->plan.codes_for = nullptr;
+    s->n_offsets = 0;
+    const size_t matrix_bytes = (size_t)s->nnz * (dtype_size(s->dtype) + 4);
+    if (!s->tune.index_codes || s->nrhs != 1 || s->plan.kind != 5 || s->tune.index_codes_min_mb < 0 ||
+        matrix_bytes <= ((size_t)s->tune.index_codes_min_mb << 20))
+        return CGAMD_OK;
+    if (int rc = build_index_codes(s->n, s->nnz, s->ptr, s->cols, s->ctx->stream, &s->codes, &s->dict, &s->n_offsets)) return rc;
+    if (s->codes) { s->plan.codes = s->codes; s->plan.dict = s->dict; s->plan.codes_for = s->cols; }
     return CGAMD_OK;
 }
 
@@ -326,6 +344,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, size, nnz, s->vals, s->cols);
     if (!rc && s->rm_ok) s->rm_nwg = spmm_rm_grid(dtype, nRHS, size, s->plan.max_quad, true);
     if (!rc) s->fused2 = fused2_ok(s->plan, dtype, nRHS, s->vals, s->cols);
+    if (!rc) rc = setup_index_codes(s);
     if (!rc) rc = setup_resident(s);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(ctx->stream);  // host matrix arrays may go away after return
@@ -369,6 +388,12 @@ int cgamd_solver_reload_matrix(cgamd_solver *s, const void *aValues, const int *
         if (s->rm_ok) s->rm_nwg = spmm_rm_grid(s->dtype, s->nrhs, s->n, s->plan.max_quad, true);
         s->fused2 = fused2_ok(s->plan, s->dtype, s->nrhs, s->vals, s->cols);
     }
+    {                                               // the columns were replaced: their codes go with them
+        const bool had = s->codes != nullptr;
+        if (had) destroy_graphs(s);                 // captured launches hold the old code array
+        if (int rc = setup_index_codes(s)) return rc;
+        if (!had && s->codes) destroy_graphs(s);
+    }
     if (int rc = setup_resident(s)) return rc;      // also with unchanged row pointers: the column range of a row slice may have moved
     CG_HIP(hipStreamSynchronize(st));   // the host arrays may go away after return
     return CGAMD_OK;
@@ -386,7 +411,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
         if (s->cols) (void)hipFree(s->cols);
     }
     void *bufs[] = {s->slab, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
-                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync, s->resw_sync};
+                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync, s->resw_sync, s->codes, s->dict};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;
@@ -718,6 +743,8 @@ int cgamd_solver_loop_launches(cgamd_solver *s) {
     if (fused2_now(s)) return 2;
     return fold_alpha_ok(s->plan.n_partials) ? 3 : 4;
 }
+
+int cgamd_solver_index_codes(cgamd_solver *s) { return s ? s->n_offsets : -CGAMD_ERR_INVALID; }
 
 long long cgamd_solver_spmv_bytes(cgamd_solver *s) {
     if (!s) return 0;

@@ -157,6 +157,12 @@ int cgamd_solver_layout(cgamd_solver *s);
  * single right-hand side (one launch per call as well; partial sums per work-group, so not bit-identical to the others), 2 / 3 / 4 / 5 = the
  * loops of DESIGN.md section 4, 8 = the reference's op structure (CGAMD_UNFUSED); negative: error */
 int cgamd_solver_loop_launches(cgamd_solver *s);
+/* > 0: this handle's single-RHS SpMV reads one-byte column codes instead of aCols (4 -> 1 byte of index traffic per non-zero),
+ * the value is the number of distinct (column - row) offsets of the matrix (at most 256; stencil / structured-grid FE matrices
+ * have 5 to 27).  Built at create / reload for matrices above 32 MB (tuning key "index_codes_min_mb"; smaller systems run
+ * the resident or two-launch loops; "index_codes" 0 disables).  Exact: the kernel rebuilds the same column, results do not change by a bit.
+ * 0: the kernel reads aCols as the reference's does (kernel/real/spmv.cl:21-27). */
+int cgamd_solver_index_codes(cgamd_solver *s);
 int cgamd_transpose(cgamd_ctx *ctx, int dtype, int rows, int cols, const void *in, void *out);
 /* algorithmic HBM bytes of one SpMV / one CG iteration of this solver (SURVEY §8d formulae: 14 vector passes for the
  * reference's op structure, 11 for its "fused minimum"; the default loop here moves 10) */

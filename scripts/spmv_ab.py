@@ -60,7 +60,7 @@ def main():
     ys = torch.empty(n, dtype=tdt, device=dev)
     torch.cuda.synchronize()
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-    defaults = {"spmv_variant": 5, "spmv_nt": -1, "spmv_grid": 0, "vec_grid": 0, "spmv_cycle": 64, "spmv_ilv": -1, "defer_x": 1, "spmv_chunked": 1, "spmv_chunk_kb": 0, "spmv_slice_kb": 0, "fold_alpha": 1, "alpha_two_level": 1, "spmv_unroll": 0, "vec_nt": -1, "vec_skew": 0}
+    defaults = {"spmv_variant": 5, "spmv_nt": -1, "spmv_grid": 0, "vec_grid": 0, "spmv_cycle": 64, "spmv_ilv": -1, "defer_x": 1, "spmv_chunked": 1, "spmv_chunk_kb": 0, "spmv_slice_kb": 0, "fold_alpha": 1, "alpha_two_level": 1, "spmv_unroll": 0, "vec_nt": -1, "vec_skew": 0, "index_codes": 1}
     solvers = []
     for cfg in args.cfgs:
         kv = dict(defaults)

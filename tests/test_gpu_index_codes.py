@@ -1,0 +1,177 @@
+"""One-byte column codes of the single-RHS row-block SpMV (include/cgamd.h: cgamd_solver_index_codes): the kernel reads
+aCols[j] as row + dict[code[j]].  The bar is bit-identity with the kernel that reads aCols (reference kernel/real/spmv.cl:21-27,
+kernel/complex/spmv.cl:24-33) -- the column is rebuilt exactly, so SpMV and whole CG histories must not move by a bit -- and
+parity with the oracle as everywhere else."""
+import numpy as np
+import pytest
+
+from conftest import rand_csr
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": np.float32, "f64": np.float64, "c64": np.complex64, "c128": np.complex128}
+
+
+@pytest.fixture
+def tuned(pkg):
+    lib = pkg._lib.load()
+    yield lambda **kv: [pkg._lib.check(lib.cgamd_tune(k.encode(), v)) for k, v in kv.items()]
+    lib.cgamd_tune(b"index_codes", 1)
+    lib.cgamd_tune(b"index_codes_min_mb", 32)
+    lib.cgamd_tune(b"resident", 1)
+
+
+def _solver(pkg, ctx, ip, ix, da, dtype):
+    import torch
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tip, tix, tda = t(ip.astype(np.int32)), t(ix.astype(np.int32)), t(da.astype(dtype))
+    s = pkg.Solver(ctx, len(ip) - 1, len(ix), tda, tip, tix, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=dtype)
+    s._keep = (tip, tix, tda)
+    return s
+
+
+def _run(pkg, ctx, ip, ix, da, dtype, b, iters):
+    import torch
+    dev = torch.device("cuda", 0)
+    s = _solver(pkg, ctx, ip, ix, da, dtype)
+    n = len(ip) - 1
+    x = torch.from_numpy(np.linspace(-1, 1, n).astype(dtype)).to(dev)
+    y = torch.empty_like(x)
+    s.spmv(x, y, fused_dot=True)
+    s.set_rhs(torch.from_numpy(b.astype(dtype)).to(dev), None, on_device=True)
+    s.iterate(iters)
+    out = (s.index_codes, y.cpu().numpy(), s.history().copy(), s.x().copy())
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32", "c64", "c128"])
+def test_coded_spmv_and_cg_are_bit_identical_to_the_index_kernel(pkg, tuned, dt):
+    import cg_numpy
+    import cg_oracle
+    dtype = DT[dt]
+    ctx = pkg.Context(0)
+    if dt[0] == "c":
+        N = 96
+        ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+        b = cg_numpy.rhsA(N, 12.0).flatten()
+    else:
+        ip, ix, da = cg_numpy.laplace3d(23, 19, 31)
+        b = np.linspace(1.0, 2.0, len(ip) - 1)
+    iters = 25
+    tuned(resident=0, index_codes=1, index_codes_min_mb=0)
+    k1, y1, h1, _ = _run(pkg, ctx, ip, ix, da, dtype, b, iters)
+    tuned(index_codes=0)
+    k0, y0, h0, _ = _run(pkg, ctx, ip, ix, da, dtype, b, iters)
+    assert k0 == 0 and k1 == 7        # 3-D 7-point stencil / P1 triangles on a structured grid: 7 offsets each
+    assert np.array_equal(y1, y0)
+    assert np.array_equal(h1, h0)
+    # and the oracle, as for every other path (tolerances of DESIGN.md section 2)
+    xo, ho = cg_oracle.cg(ip, ix, da.astype(dtype), b.astype(dtype), n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
+    rel = np.abs(h1[:, 0] - ho[:, 0]) / np.abs(ho[:, 0])
+    assert rel.max() < (1e-10 if dt in ("f64", "c128") else 2e-4), rel.max()
+    ctx.close()
+
+
+def test_irregular_matrices(pkg, tuned):
+    """ragged rows, empty rows, unsorted columns and duplicates within a band (<= 256 offsets: coded); scattered columns
+    (more offsets than the dictionary holds: the handle keeps aCols)"""
+    import torch
+    rng = np.random.default_rng(5)
+    ctx = pkg.Context(0)
+    n = 5000
+    rows = []
+    for i in range(n):
+        k = 0 if i % 97 == 0 else int(rng.integers(1, 12))
+        offs = rng.integers(-100, 101, k)
+        rows.append(np.clip(i + offs, 0, n - 1))
+    ip = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    ix = np.concatenate(rows).astype(np.int32)
+    da = rng.standard_normal(len(ix))
+    b = rng.standard_normal(n)
+    tuned(resident=0, index_codes=1, index_codes_min_mb=0)
+    k1, y1, h1, _ = _run(pkg, ctx, ip, ix, da, np.float64, b, 6)
+    tuned(index_codes=0)
+    k0, y0, h0, _ = _run(pkg, ctx, ip, ix, da, np.float64, b, 6)
+    assert 150 < k1 <= 256 and k0 == 0       # clipping at the ends adds a few offsets beyond the 201 of the band
+    assert np.array_equal(y1, y0) and np.array_equal(h1, h0, equal_nan=True)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((da, ix, ip), shape=(n, n))
+    assert np.allclose(y1, A @ np.linspace(-1, 1, n), rtol=1e-12, atol=1e-12)
+    # scattered columns: not codable
+    ip2, ix2, da2 = rand_csr(rng, 4000, 6, np.float64, empty_rows=True)
+    tuned(index_codes=1)
+    k2, y2, _, _ = _run(pkg, ctx, ip2, ix2, da2, np.float64, rng.standard_normal(4000), 3)
+    A2 = sp.csr_matrix((da2, ix2, ip2), shape=(4000, 4000))
+    assert k2 == 0 and np.allclose(y2, A2 @ np.linspace(-1, 1, 4000), rtol=1e-12, atol=1e-12)
+    ctx.close()
+
+
+def test_default_gate_and_reload(pkg, tuned):
+    """default: matrices below `index_codes_min_mb` (32 MB: the sizes the resident and two-launch loops serve) keep aCols;
+    multi-RHS handles always do; reload_matrix with a new pattern re-codes"""
+    import torch
+    import cg_numpy
+    ctx = pkg.Context(0)
+    ip, ix, da = cg_numpy.laplace3d(20, 20, 20)
+    s = _solver(pkg, ctx, ip, ix, da, np.float64)
+    assert s.index_codes == 0
+    s.close()
+    tuned(index_codes_min_mb=0)
+    n = len(ip) - 1
+    s2 = pkg.Solver(ctx, n, len(ix), da, ip, ix, 2, dtype=np.float64)
+    assert s2.index_codes == 0
+    s2.close()
+    # host matrix, owned by the handle: reload with another pattern of the same size / nnz
+    tuned(resident=0)
+    s3 = pkg.Solver(ctx, n, len(ix), da, ip, ix, 1, dtype=np.float64)
+    assert s3.index_codes == 7
+    ixr = ix.copy()
+    for r in range(n):               # reverse the column order inside every row: same rows, other code sequence
+        ixr[ip[r]:ip[r + 1]] = ix[ip[r]:ip[r + 1]][::-1]
+        da[ip[r]:ip[r + 1]] = da[ip[r]:ip[r + 1]][::-1]
+    b = np.linspace(1.0, 2.0, n)
+    s3.set_rhs(b, None)
+    s3.iterate(10)
+    h_a = s3.history().copy()
+    s3.reload_matrix(da, ip, ixr)
+    assert s3.index_codes == 7
+    s3.set_rhs(b, None)
+    s3.iterate(10)
+    h_b = s3.history().copy()
+    assert np.allclose(h_a, h_b, rtol=1e-12)          # same matrix, row sums in another order
+    s3.close()
+    ctx.close()
+
+
+def test_headline_size_uses_codes_and_keeps_the_residual_identity(pkg):
+    """N = 10M (BASELINE config 1): default handle is coded; r_k = b - A x_k and delta_k = r_k.r_k hold at full size"""
+    import torch
+    ctx = pkg.Context(0)
+    dev = torch.device("cuda", 0)
+    nx, ny, nz = 250, 200, 200
+    n = nx * ny * nz
+    ip, ix, da = pkg.generators.laplace3d(ctx, nx, ny, nz, dtype=np.float64)
+    s = pkg.Solver(ctx, n, int(ix.numel()), da, ip, ix, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=np.float64)
+    assert s.index_codes == 7
+    b = torch.full((n,), 5.0, dtype=torch.float64, device=dev)
+    s.set_rhs(b, None, on_device=True)
+    s.iterate(30)
+    h = s.history()
+    x = torch.from_numpy(s.x()).to(dev)
+    y = torch.empty_like(x)
+    s.spmv(x, y)
+    ctx.synchronize()
+    r = b - y
+    d = float((r * r).sum())
+    assert abs(d - h[-1, 0]) / h[-1, 0] < 1e-9
+    # A.1 = 0 in the interior, > 0 on the faces: a shifted stencil read through wrong offsets would break this
+    one = torch.ones(n, dtype=torch.float64, device=dev)
+    y = torch.empty_like(one)
+    s.spmv(one, y)
+    ctx.synchronize()
+    yy = y.view(nz, ny, nx)
+    assert float(yy[1:-1, 1:-1, 1:-1].abs().max()) == 0.0 and float(y.min()) >= 0.0 and float(y.max()) == 3.0
+    s.close()
+    ctx.close()
