@@ -120,6 +120,7 @@ def load():
         "cgamd_p2p_mailbox_free": (ci, [vp, vp]),
         "cgamd_dist_attach_p2p": (ci, [vp, vp, vp, vp]),
         "cgamd_dist_p2p_error": (ci, [vp]),
+        "cgamd_dist_index_codes": (ci, [vp]),
         "cgamd_dist_comm_ranks": (ci, [vp]),
         # legacy entry, reference clcg.h:3-5
         "cg": (vp, [ci, ci, vp, vp, vp, vp, vp, ci, ci, ci]),

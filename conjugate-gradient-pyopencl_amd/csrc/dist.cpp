@@ -122,6 +122,10 @@ struct cgamd_dist {
     bool direct = false;
     int *halo_flag = nullptr;
     int rotate = 0;
+    // one-byte column codes of the local matrix (build_index_codes; halo columns of a slab partition sit at constant offsets too)
+    unsigned char *codes = nullptr;
+    int *dict = nullptr;
+    int n_offsets = 0;
 };
 
 static int dalloc(void **p, size_t bytes, const char *what) {
@@ -359,6 +363,11 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
                                       ctx->stream);
     if (!rc) rc = compute_spmv_plan(d->ptr, d->cols, n_local, d->sc.iter, ctx->stream, &d->plan);
     if (!rc) finalize_spmv_plan(&d->plan, dtype, 1, n_local, nnz_local, d->vals, d->cols);
+    if (!rc && d->tune.index_codes && d->plan.kind == 5 && d->tune.index_codes_min_mb >= 0 &&
+        (size_t)nnz_local * (dtype_size(dtype) + 4) > ((size_t)d->tune.index_codes_min_mb << 20)) {
+        rc = build_index_codes(n_local, nnz_local, d->ptr, d->cols, ctx->stream, &d->codes, &d->dict, &d->n_offsets);
+        if (!rc && d->codes) { d->plan.codes = d->codes; d->plan.dict = d->dict; d->plan.codes_for = d->cols; }
+    }
     if (!rc && id128 && !d->p2p) {
         rc = need_rccl();
         if (!rc) {
@@ -406,6 +415,8 @@ int cgamd_dist_destroy(cgamd_dist *d) {
     if (d->interior_list) (void)hipFree(d->interior_list);
     if (d->boundary_list) (void)hipFree(d->boundary_list);
     if (d->halo_flag) (void)hipFree(d->halo_flag);
+    if (d->codes) (void)hipFree(d->codes);
+    if (d->dict) (void)hipFree(d->dict);
     void *bufs[] = {d->x, d->r, d->q, d->b, d->d_ext, d->sendbuf, d->part_dq, d->part_rr, d->red, d->sc.alpha,
                     d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter};
     for (void *p : bufs)
@@ -579,6 +590,8 @@ int cgamd_dist_comm_ranks(cgamd_dist *d) {
 }
 
 // 0 = fine; != 0: a bounded spin of the peer-to-peer protocol timed out (1 boundary exchange, 2 all-reduce)
+int cgamd_dist_index_codes(cgamd_dist *d) { return d ? d->n_offsets : -CGAMD_ERR_INVALID; }
+
 int cgamd_dist_p2p_error(cgamd_dist *d) {
     if (!d || !d->p2p || !d->my_mailbox) return 0;
     unsigned long long w = 0;

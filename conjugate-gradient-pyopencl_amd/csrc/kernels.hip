@@ -1517,15 +1517,17 @@ template <typename T> struct SpmvP2pArgs {
     int n_local, rotate, push_chunks;   // rotate: row blocks are visited from this one on, so leading boundary blocks come last
 };
 
-template <typename T, int BLOCK, bool NT, int UNROLL>
+template <typename T, int BLOCK, bool NT, int UNROLL, bool CODED = false>
 __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T> g) {
     using A = typename VT<T>::acc;
     const SpmvArgs<T> &a = g.s;
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     T *sv = reinterpret_cast<T *>(dyn_smem);
-    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));
+    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));      // CODED: cap bytes of column codes
     __shared__ A red[BLOCK / kWave];
+    __shared__ int sdict[CODED ? BLOCK : 1];
     const int t = threadIdx.x, b = blockIdx.x;
+    if constexpr (CODED) sdict[t] = a.dict[t];
     // the epoch is loaded only where it is needed: a load here would sit in front of every work-group's first wait
     if (b < g.x.n_peers * g.push_chunks)
         p2p_push_chunk<T>(g.x, a.x, b / g.push_chunks, b % g.push_chunks, g.push_chunks, *g.x.epoch + 1);
@@ -1540,7 +1542,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T>
     const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
-    stage_slice<T, BLOCK, NT, -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+    stage_slice<T, BLOCK, NT, CODED ? -3 : -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc, a.codes);
     const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
     const bool boundary = bflag != 0;
     if (boundary && t == 0) {
@@ -1561,8 +1563,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T>
 #pragma unroll
             for (int j = 0; j < UNROLL; ++j) {
                 const int idx = min(k + j, e - 1);
-                cj[j] = sc[idx];
+                if constexpr (CODED) cj[j] = reinterpret_cast<const unsigned char *>(sc)[idx];
+                else cj[j] = sc[idx];
                 av[j] = sv[idx];
+            }
+            if constexpr (CODED) {
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j) cj[j] = row + sdict[cj[j]];
             }
 #pragma unroll
             for (int j = 0; j < UNROLL; ++j) {
@@ -1583,8 +1590,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T>
 #pragma unroll
             for (int j = 0; j < UNROLL; ++j) {
                 const int idx = min(k + j, e - 1);
-                cj[j] = sc[idx];
+                if constexpr (CODED) cj[j] = reinterpret_cast<const unsigned char *>(sc)[idx];
+                else cj[j] = sc[idx];
                 av[j] = sv[idx];
+            }
+            if constexpr (CODED) {
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j) cj[j] = row + sdict[cj[j]];
             }
 #pragma unroll
             for (int j = 0; j < UNROLL; ++j) xv[j] = a.x[cj[j]];
@@ -2586,13 +2598,19 @@ static int spmv_p2p_impl(const SpmvPlan &plan, int n, long long nnz, const void 
     g.x = p2p_args(e);
     g.halo = static_cast<const T *>(e.my_halo);
     g.n_local = e.n_local; g.rotate = rotate; g.push_chunks = p2p_push_chunks(e);
-    const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
+    const bool coded = plan.codes && plan.codes_for == cols && tune().index_codes != 0;
+    a.codes = coded ? plan.codes : nullptr;
+    a.dict = coded ? plan.dict : nullptr;
+    const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
     const int grid = rowblock_grid(plan.row_blocks, a.cycle);
     if (grid < e.n_peers * g.push_chunks) return fail(CGAMD_ERR_STATE, "spmv_p2p: fewer work-groups than push chunks");
     const dim3 gd(grid), block(kBlock);
     const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
     constexpr int U = sizeof(T) > 8 ? 4 : 8;
-    if (nt) hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, true, U>), gd, block, lds, st, g);
+    if (coded) {
+        if (nt) hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, true, U, true>), gd, block, lds, st, g);
+        else hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, false, U, true>), gd, block, lds, st, g);
+    } else if (nt) hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, true, U>), gd, block, lds, st, g);
     else hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, false, U>), gd, block, lds, st, g);
     return check_launch("spmv_rowblock_p2p");
 }

@@ -293,6 +293,10 @@ class DistSolver:
     def p2p_error(self):
         return self._lib.cgamd_dist_p2p_error(self.handle)
 
+    def index_codes(self):
+        """distinct (column - row) offsets when this rank's SpMV reads one-byte column codes (include/cgamd.h), else 0"""
+        return int(self._lib.cgamd_dist_index_codes(self.handle))
+
     def comm_ranks(self):
         """ranks of the RCCL communicator, as RCCL reports them (0: no communicator)"""
         return int(self._lib.cgamd_dist_comm_ranks(self.handle))

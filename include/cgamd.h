@@ -241,6 +241,8 @@ int cgamd_p2p_mailbox_alloc(cgamd_ctx *ctx, long long halo_values, int dtype, vo
 int cgamd_p2p_mailbox_free(cgamd_ctx *ctx, void *mailbox);
 int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, const int *dst_offset);
 int cgamd_dist_p2p_error(cgamd_dist *d);
+/* as cgamd_solver_index_codes, for this rank's local matrix (the halo columns of a slab partition sit at constant offsets) */
+int cgamd_dist_index_codes(cgamd_dist *d);
 /* number of ranks of the RCCL communicator behind this handle as RCCL itself reports it (ncclCommCount);
  * 0 when the handle has no communicator (peer-to-peer backend, or one rank without peers) */
 int cgamd_dist_comm_ranks(cgamd_dist *d);

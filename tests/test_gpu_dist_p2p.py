@@ -57,7 +57,7 @@ def _system(kind):
     return ip, ix, da, b
 
 
-def _worker(rank, world, port, kind, iters, flags, out_dir):
+def _worker(rank, world, port, kind, iters, flags, out_dir, coded=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
@@ -81,7 +81,10 @@ def _worker(rank, world, port, kind, iters, flags, out_dir):
         plan.send_index = plan.send_index.to(dev)
         indptr = torch.from_numpy((ip[rb:re + 1] - lo).astype(np.int32)).to(dev)
         vals = torch.from_numpy(da[lo:hi]).to(dev)
+        if coded:           # one-byte column codes also for these small local matrices (default: above 32 MB)
+            pkg._lib.check(pkg._lib.load().cgamd_tune(b"index_codes_min_mb", 0))
         s = dmod.DistSolver(ctx, plan, indptr, vals, da.dtype, flags=flags, comm="p2p")
+        assert (s.index_codes() > 0) == coded, s.index_codes()
         bl = torch.from_numpy(b[rb:re].astype(da.dtype)).to(dev)
         s.set_rhs(bl, None)
         for _ in range(3):
@@ -99,15 +102,19 @@ def _worker(rank, world, port, kind, iters, flags, out_dir):
 
 # flags: 0 = four-launch iteration (push + wait inside the SpMV launch, halo read in place, beta all-reduce inside aypx),
 # 8 = the same from a hipGraph, 128 = staged push / unpack / all-reduce launches (+8 graph, +32 no interior/boundary overlap)
-@pytest.mark.parametrize("world,kind,flags", [(2, "lap3d", 0), (3, "lap3d", 8), (2, "helm", 8), (3, "helm", 0), (4, "lap3d", 0),
-                                              (2, "lap3d", 128), (3, "lap3d", 128 | 8), (3, "helm", 128 | 32),
-                                              (2, "lap3d_f32", 0), (3, "helm_c64", 0), (2, "dense", 0), (3, "dense", 8),
-                                              (4, "rand", 0), (3, "rand", 8), (3, "rand", 128)])
-def test_p2p_multirank_on_one_gpu(tmp_path, world, kind, flags):
+# coded: the local matrices (halo columns included) through one-byte column codes (cgamd_dist_index_codes)
+@pytest.mark.parametrize("world,kind,flags,coded", [(2, "lap3d", 0, False), (3, "lap3d", 8, False), (2, "helm", 8, False), (3, "helm", 0, False),
+                                                    (4, "lap3d", 0, False), (2, "lap3d", 128, False), (3, "lap3d", 128 | 8, False),
+                                                    (3, "helm", 128 | 32, False), (2, "lap3d_f32", 0, False), (3, "helm_c64", 0, False),
+                                                    (2, "dense", 0, False), (3, "dense", 8, False), (4, "rand", 0, False), (3, "rand", 8, False),
+                                                    (3, "rand", 128, False),
+                                                    (3, "lap3d", 0, True), (2, "helm", 8, True), (3, "lap3d", 128, True), (3, "helm_c64", 0, True),
+                                                    (2, "lap3d", 128 | 32, True)])
+def test_p2p_multirank_on_one_gpu(tmp_path, world, kind, flags, coded):
     import torch.multiprocessing as mp
     import cg_oracle
     iters = 30
-    mp.spawn(_worker, args=(world, _free_port(), kind, iters, flags, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), kind, iters, flags, str(tmp_path), coded), nprocs=world, join=True)
     ip, ix, da, b = _system(kind)
     # single-precision runs are held against the fp64 oracle (stated tolerance 1e-4 while delta_k/delta_0 > 1e-4)
     wide = np.complex128 if np.dtype(da.dtype).kind == "c" else np.float64
