@@ -426,15 +426,17 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
 // stencil / FE rows consecutive columns), the LPR partial sums meet in a shuffle tree.  The generic kernel, which these
 // matrices used before, runs the 27-point stencil at 50 % of the HBM roofline.
 // -------------------------------------------------------------------------------------------------
-template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int LPR, int UNROLL>
+template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int LPR, int UNROLL, bool CODED = false>
 __global__ __launch_bounds__(BLOCK) void spmv_rowblock_chunked_kernel(SpmvArgs<T> a) {
     using A = typename VT<T>::acc;
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     T *sv = reinterpret_cast<T *>(dyn_smem);
-    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));
+    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));      // CODED: cap bytes of column codes
     __shared__ A red[BLOCK / kWave];
+    __shared__ int sdict[CODED ? BLOCK : 1];
     constexpr int RC = BLOCK / LPR;                 // rows per chunk
     const int t = threadIdx.x, j = t / LPR, l = t % LPR;
+    if constexpr (CODED) sdict[t] = a.dict[t];      // visible after the first staging barrier
     const int rb = rowblock_of(blockIdx.x, a.row_blocks, a.cycle);
     if (rb < 0) return;
     A dot1 = vzero<A>();
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_chunked_kernel(SpmvArgs<T
         const int p0 = a.ptr[c0], p1 = a.ptr[min(c0 + RC, a.n)];
         const int cfirst = p0 & ~3;
         if (c) __syncthreads();                     // the previous chunk's walk is over before LDS is overwritten
-        stage_slice<T, BLOCK, NT, -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc);
+        stage_slice<T, BLOCK, NT, CODED ? -3 : -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc, a.codes);
         const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
         __syncthreads();
         T sum = vzero<T>();
@@ -458,8 +460,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_chunked_kernel(SpmvArgs<T
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int idx = min(k + u * LPR, last);
-                cj[u] = sc[idx];
+                if constexpr (CODED) cj[u] = reinterpret_cast<const unsigned char *>(sc)[idx];
+                else cj[u] = sc[idx];
                 av[u] = sv[idx];
+            }
+            if constexpr (CODED) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) cj[u] = row + sdict[cj[u]];
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) xv[u] = a.x[cj[u]];
@@ -1967,13 +1974,19 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         const int span = plan.chunk_span[plan.lpr == 2 ? 0 : plan.lpr == 4 ? 1 : 2];
         a.cap = (span + 3) & ~3;
         a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
-        const size_t lds = (size_t)a.cap * (sizeof(T) + 4);
+        const bool coded = plan.codes && plan.codes_for == cols && tune().index_codes != 0;
+        a.codes = coded ? plan.codes : nullptr;
+        a.dict = coded ? plan.dict : nullptr;
+        const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
         const dim3 g7(rowblock_grid(plan.row_blocks, a.cycle));
         const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
         constexpr int U = sizeof(T) > 8 ? 4 : 8;
 #define CG_CH(NT, L)                                                                                                     \
     do {                                                                                                                  \
-        if (fuse) hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, true, L, U>), g7, block, lds, st, a);   \
+        if (coded) {                                                                                                      \
+            if (fuse) hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, true, L, U, true>), g7, block, lds, st, a);   \
+            else hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, false, L, U, true>), g7, block, lds, st, a);       \
+        } else if (fuse) hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, true, L, U>), g7, block, lds, st, a);   \
         else hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, false, L, U>), g7, block, lds, st, a);       \
     } while (0)
         if (plan.lpr == 2) { if (nt) CG_CH(true, 2); else CG_CH(false, 2); }

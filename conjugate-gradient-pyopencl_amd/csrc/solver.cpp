@@ -193,7 +193,7 @@ static int setup_index_codes(cgamd_solver *s) {
     s->plan.codes = nullptr; s->plan.dict = nullptr; s->plan.codes_for = nullptr;
     s->n_offsets = 0;
     const size_t matrix_bytes = (size_t)s->nnz * (dtype_size(s->dtype) + 4);
-    if (!s->tune.index_codes || s->nrhs != 1 || s->plan.kind != 5 || s->tune.index_codes_min_mb < 0 ||
+    if (!s->tune.index_codes || s->nrhs != 1 || (s->plan.kind != 5 && s->plan.kind != 7) || s->tune.index_codes_min_mb < 0 ||
         matrix_bytes <= ((size_t)s->tune.index_codes_min_mb << 20))
         return CGAMD_OK;
     if (int rc = build_index_codes(s->n, s->nnz, s->ptr, s->cols, s->ctx->stream, &s->codes, &s->dict, &s->n_offsets)) return rc;

@@ -175,3 +175,28 @@ def test_headline_size_uses_codes_and_keeps_the_residual_identity(pkg):
     assert float(yy[1:-1, 1:-1, 1:-1].abs().max()) == 0.0 and float(y.min()) >= 0.0 and float(y.max()) == 3.0
     s.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("dt", ["f64", "c64"])
+def test_dense_rows_chunked_kernel(pkg, tuned, dt):
+    """27-point stencil: the 256-row slice no longer fits LDS, the chunked row-block kernel (2-8 lanes per row) reads the codes"""
+    import scipy.sparse as sp
+    m = 22
+    t1 = sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], [-1, 0, 1], format="csr")
+    A = sp.kron(sp.kron(t1, t1, format="csr"), t1, format="csr")
+    A = (sp.identity(m ** 3, format="csr") * 27.0 - A * 0.5).tocsr()
+    A.sort_indices()
+    dtype = DT[dt]
+    da = A.data.astype(dtype) * ((1 + 0.25j) if dt[0] == "c" else 1)
+    ip, ix = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    b = np.linspace(1.0, 2.0, m ** 3)
+    ctx = pkg.Context(0)
+    tuned(resident=0, index_codes=1, index_codes_min_mb=0)
+    k1, y1, h1, x1 = _run(pkg, ctx, ip, ix, da, dtype, b, 12)
+    tuned(index_codes=0)
+    k0, y0, h0, x0 = _run(pkg, ctx, ip, ix, da, dtype, b, 12)
+    assert k0 == 0 and k1 == 27
+    assert np.array_equal(y1, y0) and np.array_equal(h1, h0) and np.array_equal(x1, x0)
+    ref = sp.csr_matrix((da.astype(np.complex128 if dt[0] == "c" else np.float64), ix, ip)) @ np.linspace(-1, 1, m ** 3).astype(dtype)
+    assert np.allclose(y1, ref, rtol=1e-12 if dt == "f64" else 2e-5, atol=1e-12 if dt == "f64" else 1e-4)
+    ctx.close()
