@@ -304,7 +304,8 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
         "cg_iter_moved_bytes": moved_bytes,
         "cg_iter_moved_pct_of_8tbs": 100.0 * moved_bytes * it_s / 1e9 / HBM_PEAK_GBS,
         "residual_check": {"delta_0": float(delta0), "delta_last": float(deltak), "iterations": int(hist.shape[0] - 1)},
-        "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel (CSR SpMV fused with d.q partials), in-loop average over the instrumented pass (HIP events on each dispatch)",
+        "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel (CSR SpMV fused with d.q partials" + (", column indices read as one-byte codes" if n_offsets > 0 else "")
+                               + "), in-loop average over the instrumented pass (HIP events on each dispatch)",
                      "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                      "traffic": pmc_traffic()[0], "traffic_source": pmc_traffic()[1],
                      "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms,

@@ -193,6 +193,9 @@ static int setup_index_codes(cgamd_solver *s) {
     s->plan.codes = nullptr; s->plan.dict = nullptr; s->plan.codes_for = nullptr;
     s->n_offsets = 0;
     const size_t matrix_bytes = (size_t)s->nnz * (dtype_size(s->dtype) + 4);
+    // a handle whose iterations run in the chip-wide resident loop (matrix in registers) would pay the two coding passes at every
+    // create / reload (the stateless cg() reloads per call) for the few launched SpMVs around it
+    if (s->resw.ok && !(s->flags & CGAMD_NO_GRAPH) && s->tune.index_codes < 2) return CGAMD_OK;
     if (!s->tune.index_codes || s->nrhs != 1 || (s->plan.kind != 5 && s->plan.kind != 7) || s->tune.index_codes_min_mb < 0 ||
         matrix_bytes <= ((size_t)s->tune.index_codes_min_mb << 20))
         return CGAMD_OK;
@@ -344,8 +347,8 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, size, nnz, s->vals, s->cols);
     if (!rc && s->rm_ok) s->rm_nwg = spmm_rm_grid(dtype, nRHS, size, s->plan.max_quad, true);
     if (!rc) s->fused2 = fused2_ok(s->plan, dtype, nRHS, s->vals, s->cols);
-    if (!rc) rc = setup_index_codes(s);
     if (!rc) rc = setup_resident(s);
+    if (!rc) rc = setup_index_codes(s);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(ctx->stream);  // host matrix arrays may go away after return
         if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("solver_create sync: ") + hipGetErrorString(e));
@@ -388,13 +391,13 @@ int cgamd_solver_reload_matrix(cgamd_solver *s, const void *aValues, const int *
         if (s->rm_ok) s->rm_nwg = spmm_rm_grid(s->dtype, s->nrhs, s->n, s->plan.max_quad, true);
         s->fused2 = fused2_ok(s->plan, s->dtype, s->nrhs, s->vals, s->cols);
     }
+    if (int rc = setup_resident(s)) return rc;      // also with unchanged row pointers: the column range of a row slice may have moved
     {                                               // the columns were replaced: their codes go with them
         const bool had = s->codes != nullptr;
         if (had) destroy_graphs(s);                 // captured launches hold the old code array
         if (int rc = setup_index_codes(s)) return rc;
         if (!had && s->codes) destroy_graphs(s);
     }
-    if (int rc = setup_resident(s)) return rc;      // also with unchanged row pointers: the column range of a row slice may have moved
     CG_HIP(hipStreamSynchronize(st));   // the host arrays may go away after return
     return CGAMD_OK;
 }
