@@ -85,6 +85,7 @@ def load():
         "cgamd_solver_history": (ci, [vp, vp, ci]),
         "cgamd_solver_iterations_done": (ci, [vp]),
         "cgamd_solver_vector": (vp, [vp, ci]),
+        "cgamd_solver_ld": (ci, [vp]),
         "cgamd_solver_solve": (ci, [vp, vp, vp, ci, vp]),
         "cgamd_solver_spmv": (ci, [vp, vp, vp, ci]),
         "cgamd_solver_spmm_rowmajor": (ci, [vp, vp, vp, ci]),

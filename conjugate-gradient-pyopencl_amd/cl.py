@@ -309,7 +309,12 @@ class Solver:
         check(self._lib.cgamd_solver_spmm_rowmajor(self.handle, ptr(x), ptr(y), int(n_rhs)))
 
     def vector(self, which):
+        """device pointer of one of the handle's own vectors; right-hand side k starts at k * self.ld values"""
         return self._lib.cgamd_solver_vector(self.handle, {"x": 0, "r": 1, "d": 2, "q": 3}[which])
+
+    @property
+    def ld(self):
+        return self._lib.cgamd_solver_ld(self.handle)
 
     @property
     def spmv_bytes(self):

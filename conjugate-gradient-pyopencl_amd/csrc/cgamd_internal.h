@@ -108,6 +108,7 @@ struct Tuning {
     int spmv_slice_kb = 0;  // largest 256-row LDS slice the one-lane-per-row kernel accepts, in KB (0 = kMaxSliceBytes)
     int spmv_chunk_kb = 0;  // chunked row-block kernel: preferred LDS chunk in KB (0 = kChunkBytes); smaller -> more lanes per row
     int spmv_chunked = 1;   // rows too dense for the row-block kernel: chunked row-block kernel (0 = generic kernel)
+    int pad_rows = 1;       // sizes that are not whole 16-byte packs are carried with 1-3 empty rows appended (0 = as passed)
     int index_codes = 1;    // single-RHS row-block SpMV on one-byte column codes (0 = always aCols)
     int index_codes_min_mb = 32;    // ... for matrices above this size (N = 1M 7-point fp64, 83 MB: CG 35.4 -> 33.2 us/iteration; 2.56M rows
                                     // 76.4 -> 68.1; 10M 274 -> 241; smaller systems run the resident / two-launch loops, which read aCols)

@@ -22,6 +22,13 @@ struct cgamd_solver {
     Tuning tune;            // configuration this handle was created under (installed per call: TuneScope)
     cgamd_ctx *ctx = nullptr;
     int dtype = 0, n = 0, nrhs = 1, flags = 0;
+    // n is the size every kernel of the handle works on; n_user the caller's.  They differ when `size` is not a whole number of
+    // 16-byte packs (odd sizes in fp64 / complex64, not a multiple of 4 in fp32): the system is then carried with 1-3 EMPTY rows
+    // appended (row pointers repeated, b = x0 = 0 there, so r, d, q and x stay exactly 0 in them and every sum gains exact zeros),
+    // which keeps every right-hand side's vectors 16-byte aligned: the vectorised multi-RHS kernels and the resident loops apply
+    // to any size.  The caller's arrays keep their own stride (strided copies in set_rhs / get_x).
+    int n_user = 0;
+    bool own_ptr = false;   // a borrowed device matrix whose row pointers were copied to append the padding rows
     long long nnz = 0;
     void *vals = nullptr;
     int *ptr = nullptr, *cols = nullptr;
@@ -281,9 +288,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     cgamd_solver *s = new cgamd_solver();
     s->tune = tune_snapshot();
     TuneScope ts(&s->tune);
-    s->ctx = ctx; s->dtype = dtype; s->n = size; s->nnz = nnz; s->nrhs = nRHS; s->flags = flags;
-    s->plan = make_spmv_plan(size);
-    s->vgrid = vec_grid(size, dtype, nRHS);
+    s->ctx = ctx; s->dtype = dtype; s->n = size; s->n_user = size; s->nnz = nnz; s->nrhs = nRHS; s->flags = flags;
     s->defer_x = tune().defer_x != 0;
     // Row-major block + matrix-core SpMM inside the loop: by default only where the whole iteration is faster than the RHS-major
     // one (measured in one process at N = 1M, profiles/r2_experiments/spmm_ab12.log: f64 x 32 +8 %; f64 x 16, f32 x 32 equal within
@@ -294,16 +299,34 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     const bool rm_wins = dtype == CGAMD_F64 && nRHS == 32 && size > 32768;
     s->rm_ok = nRHS > 1 && (rm_knob >= 2 || (rm_knob == 1 && rm_wins)) && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS, size);
     if (s->rm_ok) s->rm_vgrid = rm_vec_grid((long long)size * nRHS, dtype);
+    {
+        const int E = (int)(16 / vs);      // values per 16-byte pack
+        if (size % E != 0 && !s->rm_ok && tune().pad_rows != 0 && size < 2147483647 - 8) s->n = (size + E - 1) / E * E;
+    }
+    const int n_int = s->n;
+    s->plan = make_spmv_plan(n_int);
+    s->vgrid = vec_grid(n_int, dtype, nRHS);
     int rc = CGAMD_OK;
+    std::vector<int> pad_ptr((size_t)(n_int - size), (int)nnz);      // row pointers of the appended empty rows
     if (flags & CGAMD_MATRIX_ON_DEVICE) {
         s->vals = const_cast<void *>(aValues);
         s->ptr = const_cast<int *>(aPointers);
         s->cols = const_cast<int *>(aCols);
+        if (n_int != size) {
+            s->ptr = nullptr;
+            rc = dmalloc((void **)&s->ptr, (size_t)(n_int + 1) * 4, "aPointers (padded copy)");
+            if (!rc) {
+                s->own_ptr = true;
+                hipError_t e = hipMemcpyAsync(s->ptr, aPointers, (size_t)(size + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(s->ptr + size + 1, pad_ptr.data(), pad_ptr.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+                if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("copy aPointers: ") + hipGetErrorString(e));
+            }
+        }
     } else {
         rc = validate_csr_host(size, nnz, aPointers, aCols);
         s->own_matrix = true;
         if (!rc) rc = dmalloc(&s->vals, (size_t)nnz * vs + 64, "aValues");
-        if (!rc) rc = dmalloc((void **)&s->ptr, (size_t)(size + 1) * 4, "aPointers");
+        if (!rc) rc = dmalloc((void **)&s->ptr, (size_t)(n_int + 1) * 4, "aPointers");
         if (!rc) rc = dmalloc((void **)&s->cols, (size_t)nnz * 4 + 64, "aCols");
         if (!rc && nnz) {
             hipError_t e = hipMemcpyAsync(s->vals, aValues, (size_t)nnz * vs, hipMemcpyHostToDevice, ctx->stream);
@@ -312,17 +335,24 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
         }
         if (!rc) {
             hipError_t e = hipMemcpyAsync(s->ptr, aPointers, (size_t)(size + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess && n_int != size)
+                e = hipMemcpyAsync(s->ptr + size + 1, pad_ptr.data(), pad_ptr.size() * 4, hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) rc = fail(CGAMD_ERR_HIP, std::string("upload aPointers: ") + hipGetErrorString(e));
-            else s->ptr_host.assign(aPointers, aPointers + size + 1);
+            else {
+                s->ptr_host.assign(aPointers, aPointers + size + 1);
+                s->ptr_host.insert(s->ptr_host.end(), pad_ptr.begin(), pad_ptr.end());
+            }
         }
     }
-    const size_t vbytes = (size_t)size * nRHS * vs;
+    const size_t vbytes = (size_t)n_int * nRHS * vs;
     {
         // the five vectors live in one slab, each at a 4 KiB-aligned offset plus a per-vector skew: the update kernels
         // stream up to four of them in lock-step, and equal strides between them alias onto the same HBM channels
         const size_t skew = (size_t)(tune().vec_skew >= 0 ? tune().vec_skew : 0);
         const size_t pitch = ((vbytes + 4095) & ~(size_t)4095) + skew;
         if (!rc) rc = dmalloc(&s->slab, pitch * 6 + 4096, "vectors");
+        if (!rc && n_int != size && hipMemsetAsync(s->slab, 0, pitch * 6 + 4096, ctx->stream) != hipSuccess)     // the padding rows of b
+            rc = fail(CGAMD_ERR_HIP, "hipMemsetAsync(vectors)");
         if (!rc) {
             char *base = static_cast<char *>(s->slab);
             s->x = base; s->r = base + pitch; s->d = base + 2 * pitch; s->q = base + 3 * pitch; s->b = base + 4 * pitch;
@@ -342,9 +372,9 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc && hipMemsetAsync(s->sc.ticket, 0, sizeof(unsigned) * (size_t)nRHS, ctx->stream) != hipSuccess) rc = fail(CGAMD_ERR_HIP, "hipMemsetAsync(alpha tickets)");
     if (!rc) rc = ensure_history(s, 1024);
     if (!rc && (flags & CGAMD_MATRIX_ON_DEVICE))      // host matrices were checked before the upload
-        rc = validate_csr_device(size, nnz, size, s->ptr, s->cols, nullptr, 0, 0, s->sc.iter, ctx->stream);
-    if (!rc) rc = compute_spmv_plan(s->ptr, s->cols, size, s->sc.iter, ctx->stream, &s->plan);
-    if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, size, nnz, s->vals, s->cols);
+        rc = validate_csr_device(size, nnz, size, aPointers, s->cols, nullptr, 0, 0, s->sc.iter, ctx->stream);     // the caller's arrays, as passed
+    if (!rc) rc = compute_spmv_plan(s->ptr, s->cols, n_int, s->sc.iter, ctx->stream, &s->plan);
+    if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, n_int, nnz, s->vals, s->cols);
     if (!rc && s->rm_ok) s->rm_nwg = spmm_rm_grid(dtype, nRHS, size, s->plan.max_quad, true);
     if (!rc) s->fused2 = fused2_ok(s->plan, dtype, nRHS, s->vals, s->cols);
     if (!rc) rc = setup_resident(s);
@@ -371,7 +401,7 @@ int cgamd_solver_reload_matrix(cgamd_solver *s, const void *aValues, const int *
     if (!s->own_matrix) return fail(CGAMD_ERR_STATE, "reload_matrix: the handle borrows a device matrix");
     TuneScope ts(&s->tune);
     CG_HIP(hipSetDevice(s->ctx->device));
-    if (int rc = validate_csr_host(s->n, s->nnz, aPointers, aCols)) return rc;
+    if (int rc = validate_csr_host(s->n_user, s->nnz, aPointers, aCols)) return rc;
     hipStream_t st = s->ctx->stream;
     const size_t vs = dtype_size(s->dtype);
     s->rhs_set = false;
@@ -379,10 +409,11 @@ int cgamd_solver_reload_matrix(cgamd_solver *s, const void *aValues, const int *
         CG_HIP(hipMemcpyAsync(s->vals, aValues, (size_t)s->nnz * vs, hipMemcpyHostToDevice, st));
         CG_HIP(hipMemcpyAsync(s->cols, aCols, (size_t)s->nnz * 4, hipMemcpyHostToDevice, st));
     }
-    const bool same_ptr = s->ptr_host.size() == (size_t)s->n + 1 && memcmp(s->ptr_host.data(), aPointers, ((size_t)s->n + 1) * 4) == 0;
+    const bool same_ptr = s->ptr_host.size() == (size_t)s->n + 1 && memcmp(s->ptr_host.data(), aPointers, ((size_t)s->n_user + 1) * 4) == 0;
     if (!same_ptr) {
-        CG_HIP(hipMemcpyAsync(s->ptr, aPointers, ((size_t)s->n + 1) * 4, hipMemcpyHostToDevice, st));
-        s->ptr_host.assign(aPointers, aPointers + s->n + 1);
+        // (the row pointers of the appended empty rows all equal nnz, which does not change: they stay as uploaded at creation)
+        CG_HIP(hipMemcpyAsync(s->ptr, aPointers, ((size_t)s->n_user + 1) * 4, hipMemcpyHostToDevice, st));
+        std::copy(aPointers, aPointers + s->n_user + 1, s->ptr_host.begin());
         destroy_graphs(s);          // kernel choice, LDS size and partial counts are baked into the captured launches
         s->plan = make_spmv_plan(s->n);
         if (int rc = compute_spmv_plan(s->ptr, s->cols, s->n, s->sc.iter, st, &s->plan)) return rc;
@@ -408,6 +439,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     destroy_graphs(s);
+    if (s->own_ptr && s->ptr) (void)hipFree(s->ptr);
     if (s->own_matrix) {
         if (s->vals) (void)hipFree(s->vals);
         if (s->ptr) (void)hipFree(s->ptr);
@@ -453,9 +485,16 @@ int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_
         s->iters = 0;
         return CGAMD_OK;
     }
-    CG_HIP(hipMemcpyAsync(s->b, b, vbytes, kind, st));
-    if (x0) CG_HIP(hipMemcpyAsync(s->x, x0, vbytes, kind, st));
-    else CG_HIP(hipMemsetAsync(s->x, 0, vbytes, st));
+    if (s->n != s->n_user) {     // caller's blocks are [nrhs][size]; the handle's carry the padding rows (b and x stay 0 there)
+        const size_t vs = dtype_size(s->dtype);
+        CG_HIP(hipMemcpy2DAsync(s->b, (size_t)s->n * vs, b, (size_t)s->n_user * vs, (size_t)s->n_user * vs, (size_t)s->nrhs, kind, st));
+        CG_HIP(hipMemsetAsync(s->x, 0, vbytes, st));
+        if (x0) CG_HIP(hipMemcpy2DAsync(s->x, (size_t)s->n * vs, x0, (size_t)s->n_user * vs, (size_t)s->n_user * vs, (size_t)s->nrhs, kind, st));
+    } else {
+        CG_HIP(hipMemcpyAsync(s->b, b, vbytes, kind, st));
+        if (x0) CG_HIP(hipMemcpyAsync(s->x, x0, vbytes, kind, st));
+        else CG_HIP(hipMemsetAsync(s->x, 0, vbytes, st));
+    }
     // r = b - A x0 ; d = r ; delta0 = r.r   (clcg.c:255-292)
     if ((rc = launch_spmv(s->dtype, s->plan, s->n, s->nnz, s->vals, s->ptr, s->cols, s->x, s->n, s->q, s->n, s->nrhs,
                           nullptr, nullptr, st))) return rc;
@@ -495,7 +534,8 @@ int cgamd_solver_set_preconditioner(cgamd_solver *s, const void *m, int on_devic
     if (!rc && !s->part_rz) rc = dmalloc(&s->part_rz, acc_size(s->dtype) * (size_t)s->vgrid * s->nrhs, "partials_rz");
     if (!rc && !s->rho2) rc = dmalloc(&s->rho2, 2 * vs * (size_t)s->nrhs, "rho");
     if (rc) return rc;
-    CG_HIP(hipMemcpyAsync(s->mdiag, m, (size_t)s->n * vs, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->ctx->stream));
+    if (s->n != s->n_user) CG_HIP(hipMemsetAsync(s->mdiag, 0, (size_t)s->n * vs, s->ctx->stream));
+    CG_HIP(hipMemcpyAsync(s->mdiag, m, (size_t)s->n_user * vs, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->ctx->stream));
     CG_HIP(hipStreamSynchronize(s->ctx->stream));
     return CGAMD_OK;
 }
@@ -681,7 +721,13 @@ int cgamd_solver_get_x(cgamd_solver *s, void *x, int on_device) {
         if (int rc = launch_transpose(s->dtype, s->n, s->nrhs, s->x, s->q, s->ctx->stream)) return rc;
         src = s->q;
     }
-    CG_HIP(hipMemcpyAsync(x, src, vbytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->ctx->stream));
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (s->n != s->n_user) {
+        const size_t vs = dtype_size(s->dtype);
+        CG_HIP(hipMemcpy2DAsync(x, (size_t)s->n_user * vs, src, (size_t)s->n * vs, (size_t)s->n_user * vs, (size_t)s->nrhs, kind, s->ctx->stream));
+    } else {
+        CG_HIP(hipMemcpyAsync(x, src, vbytes, kind, s->ctx->stream));
+    }
     if (!on_device) CG_HIP(hipStreamSynchronize(s->ctx->stream));
     return CGAMD_OK;
 }
@@ -700,6 +746,8 @@ int cgamd_solver_history(cgamd_solver *s, void *history, int max_entries) {
     if (e != hipSuccess) { fail(CGAMD_ERR_HIP, std::string("history: ") + hipGetErrorString(e)); return -CGAMD_ERR_HIP; }
     return entries;
 }
+
+int cgamd_solver_ld(cgamd_solver *s) { return s ? s->n : -CGAMD_ERR_INVALID; }
 
 void *cgamd_solver_vector(cgamd_solver *s, int which) {
     if (!s) return nullptr;
@@ -723,7 +771,8 @@ int cgamd_solver_spmv(cgamd_solver *s, const void *x, void *y, int fused_dot) {
     if (!s || !x || !y) return fail(CGAMD_ERR_INVALID, "solver_spmv: null argument");
     TuneScope ts(&s->tune);
     CG_HIP(hipSetDevice(s->ctx->device));
-    return launch_spmv(s->dtype, s->plan, s->n, s->nnz, s->vals, s->ptr, s->cols, x, s->n, y, s->n, s->nrhs,
+    // the caller's vectors have the caller's stride; the plan fits both sizes (same row blocks, the appended rows are empty)
+    return launch_spmv(s->dtype, s->plan, s->n_user, s->nnz, s->vals, s->ptr, s->cols, x, s->n_user, y, s->n_user, s->nrhs,
                        fused_dot ? x : nullptr, fused_dot ? s->part_dq : nullptr, s->ctx->stream);
 }
 
@@ -731,7 +780,7 @@ int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS
     if (!s || !x || !y) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: null argument");
     TuneScope ts(&s->tune);
     CG_HIP(hipSetDevice(s->ctx->device));
-    return launch_spmm_rm(s->dtype, s->n, s->nnz, s->vals, s->ptr, s->cols, x, y, nRHS, nullptr, s->plan.max_quad, s->ctx->stream);
+    return launch_spmm_rm(s->dtype, s->n_user, s->nnz, s->vals, s->ptr, s->cols, x, y, nRHS, nullptr, s->plan.max_quad, s->ctx->stream);
 }
 
 int cgamd_solver_layout(cgamd_solver *s) { return s ? (s->rm ? 1 : 0) : -CGAMD_ERR_INVALID; }
@@ -752,12 +801,12 @@ int cgamd_solver_index_codes(cgamd_solver *s) { return s ? s->n_offsets : -CGAMD
 long long cgamd_solver_spmv_bytes(cgamd_solver *s) {
     if (!s) return 0;
     const long long V = (long long)dtype_size(s->dtype);
-    return s->nnz * (V + 4) + ((long long)s->n + 1) * 4 + 2LL * s->n * V * s->nrhs;
+    return s->nnz * (V + 4) + ((long long)s->n_user + 1) * 4 + 2LL * s->n_user * V * s->nrhs;
 }
 long long cgamd_solver_iter_bytes(cgamd_solver *s, int fused) {
     if (!s) return 0;
     const long long V = (long long)dtype_size(s->dtype);
-    return s->nnz * (V + 4) + ((long long)s->n + 1) * 4 + (fused ? 11LL : 14LL) * s->n * V * s->nrhs;
+    return s->nnz * (V + 4) + ((long long)s->n_user + 1) * 4 + (fused ? 11LL : 14LL) * s->n_user * V * s->nrhs;
 }
 
 }  // extern "C"

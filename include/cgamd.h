@@ -134,6 +134,10 @@ int cgamd_solver_history(cgamd_solver *s, void *history, int max_entries);
 int cgamd_solver_iterations_done(cgamd_solver *s);
 /* device pointers of the solver's resident state (for zero-copy inspection): which = 0:x 1:r 2:d 3:q */
 void *cgamd_solver_vector(cgamd_solver *s, int which);
+/* leading dimension (values between consecutive right-hand sides) of the handle's own vectors: `size` rounded up to a whole number
+ * of 16-byte packs (2 values in fp64 / complex64, 4 in fp32) -- the handle carries such systems with 1-3 empty rows appended so that
+ * every right-hand side stays 16-byte aligned; b / x0 / x in the caller's arrays keep stride `size` (tuning key "pad_rows" 0: as passed) */
+int cgamd_solver_ld(cgamd_solver *s);
 /* Diagonal (Jacobi) preconditioning -- the reference's PCG(A, b, M) with a diagonal CSR M, z = M.dot(r)
  * (helmFE_var.py:546-586).  m: `size` values of the solver's type (1/diag(A) for Jacobi), host or
  * device; NULL removes it.  Takes effect at the next cgamd_solver_set_rhs; history keeps holding r.r (the stopping

@@ -38,9 +38,13 @@ def _run(pkg, ctx, ip, ix, da, dtype, b, iters):
     n = len(ip) - 1
     x = torch.from_numpy(np.linspace(-1, 1, n).astype(dtype)).to(dev)
     y = torch.empty_like(x)
+    torch.cuda.synchronize()             # the solver runs on its own stream
     s.spmv(x, y, fused_dot=True)
-    s.set_rhs(torch.from_numpy(b.astype(dtype)).to(dev), None, on_device=True)
+    bd = torch.from_numpy(b.astype(dtype)).to(dev)
+    torch.cuda.synchronize()
+    s.set_rhs(bd, None, on_device=True)
     s.iterate(iters)
+    ctx.synchronize()
     out = (s.index_codes, y.cpu().numpy(), s.history().copy(), s.x().copy())
     s.close()
     return out
@@ -156,11 +160,14 @@ def test_headline_size_uses_codes_and_keeps_the_residual_identity(pkg):
     s = pkg.Solver(ctx, n, int(ix.numel()), da, ip, ix, 1, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=np.float64)
     assert s.index_codes == 7
     b = torch.full((n,), 5.0, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()             # the solver runs on its own stream
     s.set_rhs(b, None, on_device=True)
     s.iterate(30)
     h = s.history()
+    assert h[0, 0] == 25.0 * n
     x = torch.from_numpy(s.x()).to(dev)
     y = torch.empty_like(x)
+    torch.cuda.synchronize()             # the solver runs on its own stream
     s.spmv(x, y)
     ctx.synchronize()
     r = b - y
@@ -169,6 +176,7 @@ def test_headline_size_uses_codes_and_keeps_the_residual_identity(pkg):
     # A.1 = 0 in the interior, > 0 on the faces: a shifted stencil read through wrong offsets would break this
     one = torch.ones(n, dtype=torch.float64, device=dev)
     y = torch.empty_like(one)
+    torch.cuda.synchronize()
     s.spmv(one, y)
     ctx.synchronize()
     yy = y.view(nz, ny, nx)

@@ -192,10 +192,17 @@ def test_resident_loop_does_not_apply(pkg, gpu):
     s = pkg.Solver(ctx, 40000, len(ix), da, ip, ix, 2, flags=pkg._lib.NO_GRAPH)     # plain launches requested
     assert lib.cgamd_solver_loop_launches(s.handle) == 2
     s.close()
-    ip, ix, da = cg_numpy.poisson2d(37)                     # 1369 rows: odd, no 16-byte packs per right-hand side
-    s = pkg.Solver(ctx, 1369, len(ix), da, ip, ix, 2)
-    assert lib.cgamd_solver_loop_launches(s.handle) != 0
+    ip, ix, da = cg_numpy.poisson2d(37)                     # 1369 rows: odd, no 16-byte packs per right-hand side ...
+    s = pkg.Solver(ctx, 1369, len(ix), da, ip, ix, 2)       # ... the handle carries it with one empty row appended (tests/test_gpu_odd_sizes.py)
+    assert lib.cgamd_solver_loop_launches(s.handle) == 0 and s.ld == 1370
     s.close()
+    pkg._lib.check(lib.cgamd_tune(b"pad_rows", 0))          # as passed: launched loops
+    try:
+        s = pkg.Solver(ctx, 1369, len(ix), da, ip, ix, 2)
+        assert lib.cgamd_solver_loop_launches(s.handle) != 0 and s.ld == 1369
+        s.close()
+    finally:
+        pkg._lib.check(lib.cgamd_tune(b"pad_rows", 1))
     ip, ix, da = cg_numpy.poisson2d(40)
     s = pkg.Solver(ctx, 1600, len(ix), da, ip, ix, 1, flags=pkg._lib.UNFUSED)
     assert lib.cgamd_solver_loop_launches(s.handle) == 8
