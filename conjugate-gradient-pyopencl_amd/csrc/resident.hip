@@ -92,7 +92,7 @@ template <bool LOCAL> CG_DEV void st_word(u64 *p, u64 v) {
     if (LOCAL) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-CG_DEV float ld_coh(const float *p) { return __uint_as_float(ld_word(reinterpret_cast<const unsigned *>(p))); }
+[[maybe_unused]] CG_DEV float ld_coh(const float *p) { return __uint_as_float(ld_word(reinterpret_cast<const unsigned *>(p))); }
 CG_DEV double ld_coh(const double *p) { return __longlong_as_double((long long)ld_word(reinterpret_cast<const u64 *>(p))); }
 CG_DEV float2 ld_coh(const float2 *p) {
     const u64 w = ld_word(reinterpret_cast<const u64 *>(p));
