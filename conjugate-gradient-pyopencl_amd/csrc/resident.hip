@@ -92,13 +92,13 @@ template <bool LOCAL> CG_DEV void st_word(u64 *p, u64 v) {
     if (LOCAL) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-[[maybe_unused]] CG_DEV float ld_coh(const float *p) { return __uint_as_float(ld_word(reinterpret_cast<const unsigned *>(p))); }
+CG_DEV float ld_coh(const float *p) { return __uint_as_float(ld_word(reinterpret_cast<const unsigned *>(p))); }
 CG_DEV double ld_coh(const double *p) { return __longlong_as_double((long long)ld_word(reinterpret_cast<const u64 *>(p))); }
 CG_DEV float2 ld_coh(const float2 *p) {
     const u64 w = ld_word(reinterpret_cast<const u64 *>(p));
     return make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
 }
-CG_DEV double2 ld_coh(const double2 *p) {
+[[maybe_unused]] CG_DEV double2 ld_coh(const double2 *p) {
     return make_double2(ld_coh(reinterpret_cast<const double *>(p)), ld_coh(reinterpret_cast<const double *>(p) + 1));
 }
 template <bool LOCAL, typename T> CG_DEV void st_pack_coh(T *p, const Pack<T> &v) {
