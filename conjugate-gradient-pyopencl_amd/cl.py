@@ -343,9 +343,10 @@ class Solver:
     def solve_tol(self, b, x0=None, tol=1e-5, maxit=1000, check_every=8):
         """Tolerance-stopping variant of the reference's NumPy sub-solver (p_h-PY_C-CL.py:1338-1369, UseCG==5), which breaks
         at the first iteration with sqrt(|r.r|) < tol.  The residual history stays on the device and is read back every
-        `check_every` iterations (one small read-back instead of the reference's per-iteration host reductions); when the
-        check overshot the first iteration that met the tolerance, the solve is re-run for exactly that many iterations, so
-        x is the iterate the reference returns and not one from past convergence (where d.q can reach 0 and alpha 0/0).
+        `check_every` iterations (one small read-back instead of the reference's per-iteration host reductions), more often
+        as the residual nears the tolerance (_run_to_tol); when a check still overshot the first iteration that met the
+        tolerance, the solve is re-run for exactly that many iterations, so x is the iterate the reference returns and not one
+        from past convergence (where d.q can reach 0 and alpha 0/0).
         Returns (x, iterations_run, history).  Single right-hand side."""
         if self.n_rhs != 1:
             raise ValueError("solve_tol handles one right-hand side")
@@ -356,23 +357,36 @@ class Solver:
             if self._lib.cgamd_solver_iterate_tol(self.handle, int(maxit), float(tol), ctypes.byref(run_)) == 0:
                 return self.x(), int(run_.value), self.history()
 
-        def run(limit, stop_early):
-            self.set_rhs(b, x0)
-            done = 0
-            while done < limit:
-                step = min(check_every, limit - done)
-                self.iterate(step)
-                done += step
-                if stop_early:
-                    h = self.history()
-                    hit = np.nonzero(~(np.sqrt(np.abs(h[1:, 0])) >= tol))[0]        # below tol, or NaN
-                    if hit.size:
-                        return int(hit[0]) + 1
-            return limit
-        its = run(int(maxit), True)
-        if self.iterations_done() != its:
-            run(its, False)
+        its = self._run_to_tol(b, x0, tol, int(maxit), int(check_every))
         return self.x(), its, self.history()
+
+    def _run_to_tol(self, b, x0, tol, maxit, check_every):
+        """Host-driven tolerance stop for the launched loops: iterate in chunks, read the residual history back after each,
+        and leave x at the FIRST iteration whose sqrt(|r.r|) is below tol (or NaN).  The chunk shrinks as the residual nears
+        the tolerance (the decay rate of the last chunk predicts how many iterations are left), down to single iterations,
+        so the loop normally ends exactly there; when a chunk still overshot, the solve is re-run for exactly that many
+        iterations.  Returns the number of iterations run."""
+        self.set_rhs(b, x0)
+        done, step, its = 0, max(1, check_every), maxit
+        while done < maxit:
+            s_ = min(step, maxit - done)
+            self.iterate(s_)
+            done += s_
+            norms = np.sqrt(np.abs(self.history()[:, 0]))
+            hit = np.nonzero(~(norms[1:] >= tol))[0]                # below tol, or NaN
+            if hit.size:
+                its = int(hit[0]) + 1
+                break
+            cur, start = float(norms[-1]), float(norms[-1 - s_])
+            step = max(1, check_every)
+            if 0.0 < cur < start and tol > 0:
+                togo = np.log(tol / cur) / (np.log(cur / start) / s_)     # iterations left at the last chunk's rate
+                if togo < 2 * step:
+                    step = max(1, int(togo / 2))
+        if self.iterations_done() != its:
+            self.set_rhs(b, x0)
+            self.iterate(its)
+        return its
 
     def pcg(self, b, M=None, x0=None, tol=1e-6, maxit=1000, check_every=8):
         """`PCG(A, b, M, x, tol, maxit)` of the reference (helmFE_var.py:546-586) for M = None or a diagonal M: stops when
@@ -389,22 +403,7 @@ class Solver:
                 return self.x(), int(run_.value) - 1
         self.set_preconditioner(M)
         try:
-            def run(limit, stop_early):
-                self.set_rhs(b, x0)
-                done = 0
-                while done < limit:
-                    step = min(check_every, limit - done)
-                    self.iterate(step)
-                    done += step
-                    if stop_early:
-                        h = self.history()
-                        hit = np.nonzero(~(np.sqrt(np.abs(h[1:, 0])) >= tol))[0]        # below tol, or NaN
-                        if hit.size:
-                            return int(hit[0]) + 1
-                return limit
-            its = run(int(maxit), True)
-            if self.iterations_done() != its:
-                run(its, False)
+            its = self._run_to_tol(b, x0, tol, int(maxit), int(check_every))
             return self.x(), its - 1
         finally:
             self.set_preconditioner(None)

@@ -97,3 +97,37 @@ def test_tolerance_run_survives_a_resident_launch_that_cannot_start(pkg, gpu):
         pkg._lib.check(lib.cgamd_tune(b"resident_claim_ms", 15000))
         pkg._lib.check(lib.cgamd_tune(b"resident_test_short_grid", 0))
     assert k1 == 0 and it1 == it0 and np.array_equal(x1, x0)
+
+
+@pytest.mark.parametrize("kind,tol", [("poisson", 1e-6), ("poisson", 1e-2), ("helm", 1e-3)])
+def test_host_scheme_lands_on_the_stopping_iteration(pkg, gpu, kind, tol):
+    """launched loops: the check interval shrinks as the residual nears the tolerance (Solver._run_to_tol), so the loop ends in the
+    stopping iteration itself and the exact re-run stays the exception; either way its and x are those of the per-iteration check"""
+    ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
+    if kind == "poisson":
+        ip, ix, da = cg_numpy.poisson2d(90)
+        b = 1.0 + rand_vec(np.random.default_rng(90), 8100, np.float64)
+    else:
+        N = 64
+        ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+        b = cg_numpy.rhsA(N, 12.0).flatten()
+    pkg._lib.check(lib.cgamd_tune(b"resident", 0))
+    try:
+        s = pkg.Solver(ctx, len(ip) - 1, len(ix), da, ip, ix, 1)
+        assert lib.cgamd_solver_loop_launches(s.handle) >= 2
+        calls = []
+        plain = s.set_rhs
+        s.set_rhs = lambda *a, **k: (calls.append(1), plain(*a, **k))[1]
+        x, its, h = s.solve_tol(b, tol=tol, maxit=3000, check_every=8)
+        n_calls = len(calls)
+        x1, its1, h1 = s.solve_tol(b, tol=tol, maxit=3000, check_every=1)       # the reference's own cadence: a check per iteration
+        s.close()
+    finally:
+        pkg._lib.check(lib.cgamd_tune(b"resident", 1))
+    assert its == its1 and 5 < its < 3000
+    assert np.array_equal(x, x1) and np.array_equal(h, h1)
+    assert np.sqrt(abs(h[its, 0])) < tol <= np.sqrt(abs(h[its - 1, 0]))
+    assert n_calls <= 2
+    if kind == "poisson" and tol == 1e-6:
+        assert n_calls == 1          # smooth convergence over many chunks: no re-run needed
