@@ -3,6 +3,8 @@
 //   spmv_rowblock_kernel          CSR SpMV (replaces reference kernel/{real,complex}/spmv.cl) fused with the d.q partial
 //                                 reduction (reference vdot.cl + host sum clcg.c:317-324): matrix slice through LDS, one lane
 //                                 per row; _chunked: 2/4/8 lanes per row for denser rows; _p2p: with the halo push / wait
+//                                 POL = -3: the column indices arrive as one-byte codes (aCols[j] = row + dict[code[j]],
+//                                 index_offsets_kernel / index_encode_kernel / build_index_codes): 9 instead of 12 B per fp64 non-zero
 //   spmm_rowblock_kernel          the same for nRHS > 1 (RHS-major, the ABI layout); the row-major matrix-core path is rowmajor.hip
 //   spmv_stream_kernel            generic chunked CSR stream (huge rows, unaligned pointers)
 //   dot_partials_kernel           reference kernel/{real,complex}/vdot.cl (partials stay on the device)
