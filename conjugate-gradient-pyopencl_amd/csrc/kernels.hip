@@ -1884,6 +1884,10 @@ int vec_grid(long long n, int dtype, int nrhs) {
     long long g = (n + per_block - 1) / per_block;
     const long long cap = tune().vec_grid > 0 ? tune().vec_grid : kMaxGrid;
     if (g > cap) g = cap;
+    // single right-hand side, streaming sizes: exactly two work-groups per CU.  611 (1.25M rows) or 1221 (2.5M) leave the CUs
+    // unevenly loaded, and every work-group of the beta launch adds all the r.r partials in its prologue: 1.25M rows 37.5 -> 36.7 us
+    // per iteration, 2.5M 64.9 -> 62.5, 5M 124.8 -> 123.4, 10M 237.5 -> 235.9 (profiles/r2_experiments/vec_grid_ab.log)
+    if (nrhs <= 1 && tune().vec_grid == 0 && g > 512) g = 512;
     if (g < 1) g = 1;
     return (int)g;
 }
