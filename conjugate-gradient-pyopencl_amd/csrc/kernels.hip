@@ -16,7 +16,7 @@
 //   p2p_*                         peer-to-peer mailbox protocol of the row-partitioned multi-GPU loop
 //
 // Design (MI355X): every kernel is bound by the memory system.  Work-groups are 256 threads (4 wave64).  The SpMV kernels
-// run one work-group per 256-row block, dealt block-cyclically over the 8 XCDs; the vector kernels launch <= 2048 grid-
+// run one work-group per 256-row block, dealt block-cyclically over the 8 XCDs; the vector kernels launch <= 2048 (streaming single-RHS systems: 512) grid-
 // stride work-groups (256 CUs x 8).  Loads are 16 B per lane and every load instruction of a wave covers contiguous
 // memory; matrix streams are non-temporal unless the matrix fits the Infinity Cache.  Reductions are wave64 shuffles,
 // then LDS across the 4 waves, then a fixed-order pass over the per-work-group partials: bitwise reproducible run to
