@@ -38,6 +38,7 @@ struct SpmvPlan {
     int kind = 0;        // kernel chosen by finalize_spmv_plan (0 generic, 5 row-block, 6 its SpMM form, 7 chunked row-block)
     int chunk_span[3] = {0, 0, 0};   // largest 4-aligned span of a 128 / 64 / 32-row slice
     bool wide = false;   // kind 6 only: small system, one work-group per (row block, RHS) runs the single-RHS kernel
+    int max_row = 0;     // longest row (0 = unknown): the row-block kernel's batch length follows it
     int max_quad = 0;    // most non-zeros in 4 consecutive rows starting at a multiple of 4 (row-major SpMM: K-steps per quad)
     int lpr = 1;         // kind 7: lanes per row (2, 4, 8) = chunks per 256-row block
     int n_partials = 0;  // fused-dot partials per RHS written by that kernel
