@@ -229,6 +229,36 @@ def small_system_extra(pkg, ctx, torch, dev):
             "finite_history": bool(np.all(np.isfinite(h[: iters + 65])))}
 
 
+def rate_fields(spmv_moved, spmv_csr, spmv_ms, spmv_alone_ms, iter_moved, iter_csr, it_s, traffic, traffic_source, n_offsets):
+    """The rate / roofline part of the single-GPU line (pure arithmetic: tests/test_bench_launch.py checks it without a GPU).
+
+    `moved`: what the kernels that ran really move -- index bytes per non-zero as the SpMV reads them (1 with the one-byte
+    column codes) and the loop's own vector passes (10).  Every FRACTION of the 8 TB/s peak is priced on
+    these bytes, so none can exceed what the memory system delivers.  `csr`: the reference's CSR byte model of SURVEY 8(d)
+    (12 B per fp64 non-zero, 14 vector passes of its unfused op structure) -- reported as an "effective" rate only."""
+    spmv_gbs = spmv_moved / (spmv_ms * 1e-3) / 1e9
+    alone_gbs = spmv_moved / (spmv_alone_ms * 1e-3) / 1e9
+    return {
+        "spmv_gbs": spmv_gbs, "spmv_pct_of_8tbs": 100.0 * spmv_gbs / HBM_PEAK_GBS,
+        "spmv_back_to_back_gbs": alone_gbs, "spmv_back_to_back_pct_of_8tbs": 100.0 * alone_gbs / HBM_PEAK_GBS,
+        "cg_iter_moved_bytes": iter_moved, "cg_iter_gbs": iter_moved * it_s / 1e9,
+        "cg_iter_pct_of_8tbs": 100.0 * iter_moved * it_s / 1e9 / HBM_PEAK_GBS,
+        "effective_csr": {"note": "reference CSR byte model (SURVEY 8d): 4 index bytes per non-zero, 14 vector passes; an effective "
+                                  "rate for comparison with a solver that reads aCols, not a fraction of the peak",
+                          "spmv_bytes": spmv_csr, "spmv_gbs": spmv_csr / (spmv_ms * 1e-3) / 1e9,
+                          "cg_iter_bytes": iter_csr, "cg_iter_gbs": iter_csr * it_s / 1e9},
+        "roofline": {"bound": "hbm",
+                     "kernel": "spmv_rowblock_kernel (CSR SpMV fused with d.q partials" + (", column indices read as one-byte codes" if n_offsets > 0 else "")
+                               + "), in-loop average over the instrumented pass (HIP events on each dispatch)",
+                     "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_ratio": (traffic / spmv_moved) if traffic else None,
+                     "moved_bytes_per_launch": spmv_moved, "avg_launch_ms": spmv_ms,
+                     "index_codes": {"distinct_offsets": n_offsets, "index_bytes_per_nonzero": 1 if n_offsets > 0 else 4},
+                     "effective_csr_bytes_per_launch": spmv_csr, "effective_csr_gbs": spmv_csr / (spmv_ms * 1e-3) / 1e9},
+    }
+
+
 def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
     lib = pkg._lib
     n = nx * ny * nz
@@ -277,15 +307,7 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
     spmv_alone_ms = e0.elapsed_time(e1) / args.spmv_reps
     if spmv_ms is None:
         spmv_ms = spmv_alone_ms
-    spmv_gbs = spmv_bytes / (spmv_ms * 1e-3) / 1e9
-
-    V = np.dtype(dtype).itemsize
-    passes = 14 if args.unfused else 10      # SpMV 2 + r update 3 + (beta, x update, aypx) 5; see DESIGN.md section 4
-    # one-byte column codes (include/cgamd.h: cgamd_solver_index_codes): the SpMV reads 1 instead of 4 index bytes per non-zero
-    n_offsets = solver.index_codes
-    idx_bytes = 1 if n_offsets > 0 else 4
-    moved_bytes = nnz * (V + idx_bytes) + (n + 1) * 4 + passes * n * V
-    spmv_moved = nnz * (V + idx_bytes) + (n + 1) * 4 + 2 * n * V
+    traffic, traffic_source = pmc_traffic()
     delta0, deltak = abs(hist[0, 0]), abs(hist[-1, 0])
     res = {
         "metric": "CG iterations/sec + SpMV effective HBM GB/s (% of 8 TB/s peak), N=10M CSR",
@@ -295,26 +317,11 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
         "config": {"workload": f"3D 7-pt Laplacian {nx}x{ny}x{nz} CSR, N={n}, nnz={nnz}, {args.dtype}, 1 RHS, "
                                f"b=5, x0=0, fixed-iteration CG ({'reference 6-op' if args.unfused else 'fused 4-launch'} loop)",
                    "rows": n, "nnz": nnz, "parallelism": "1 GPU"},
-        "spmv_gbs": spmv_gbs, "spmv_pct_of_8tbs": 100.0 * spmv_gbs / HBM_PEAK_GBS,
-        "spmv_back_to_back_gbs": spmv_bytes / (spmv_alone_ms * 1e-3) / 1e9,
-        "spmv_back_to_back_pct_of_8tbs": 100.0 * spmv_bytes / (spmv_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "cg_iter_algorithmic_gbs": iter_bytes * it_s / 1e9,
-        "cg_iter_pct_of_8tbs": 100.0 * iter_bytes * it_s / 1e9 / HBM_PEAK_GBS,
-        # the byte model above is the reference's op structure (14 vector passes); the loop that ran moves fewer:
-        "cg_iter_moved_bytes": moved_bytes,
-        "cg_iter_moved_pct_of_8tbs": 100.0 * moved_bytes * it_s / 1e9 / HBM_PEAK_GBS,
         "residual_check": {"delta_0": float(delta0), "delta_last": float(deltak), "iterations": int(hist.shape[0] - 1)},
-        "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel (CSR SpMV fused with d.q partials" + (", column indices read as one-byte codes" if n_offsets > 0 else "")
-                               + "), in-loop average over the instrumented pass (HIP events on each dispatch)",
-                     "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic()[0], "traffic_source": pmc_traffic()[1],
-                     "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms,
-                     # `achieved` / `frac` price the CSR bytes of SURVEY 8(d) (12 B per fp64 non-zero) as the contract asks; with the
-                     # column indices coded in one byte the kernel moves fewer, so also the rate of what it really moves:
-                     "index_codes": {"distinct_offsets": n_offsets, "index_bytes_per_nonzero": idx_bytes},
-                     "moved_bytes_per_launch": spmv_moved, "achieved_moved": spmv_moved / (spmv_ms * 1e-3) / 1e9,
-                     "frac_moved": spmv_moved / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
+    res.update(rate_fields(spmv_moved=solver.spmv_moved_bytes, spmv_csr=spmv_bytes, spmv_ms=spmv_ms, spmv_alone_ms=spmv_alone_ms,
+                           iter_moved=solver.iter_moved_bytes, iter_csr=iter_bytes, it_s=it_s, traffic=traffic,
+                           traffic_source=traffic_source, n_offsets=solver.index_codes))
     solver.close()
     return res
 

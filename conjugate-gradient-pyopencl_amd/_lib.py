@@ -96,6 +96,8 @@ def load():
         "cgamd_transpose": (ci, [vp, ci, ci, ci, vp, vp]),
         "cgamd_solver_spmv_bytes": (ll, [vp]),
         "cgamd_solver_iter_bytes": (ll, [vp, ci]),
+        "cgamd_solver_spmv_moved_bytes": (ll, [vp]),
+        "cgamd_solver_iter_moved_bytes": (ll, [vp]),
         "cgamd_cg": (ci, [ci, ci, ll, vp, vp, vp, vp, vp, ci, ci, vp, ci]),
         "cgamd_cg_last_timing": (ci, [ctypes.POINTER(ctypes.c_double)]),
         "cgamd_cg_release_cache": (ci, []),

@@ -328,6 +328,16 @@ class Solver:
     def iter_bytes(self, fused=False):
         return self._lib.cgamd_solver_iter_bytes(self.handle, int(fused))
 
+    @property
+    def spmv_moved_bytes(self):
+        """bytes the handle's SpMV really moves per launch (index bytes as the kernel reads them): what a roofline fraction is priced on"""
+        return self._lib.cgamd_solver_spmv_moved_bytes(self.handle)
+
+    @property
+    def iter_moved_bytes(self):
+        """bytes one iteration of the handle's launched loop moves (its own vector passes, its own index bytes)"""
+        return self._lib.cgamd_solver_iter_moved_bytes(self.handle)
+
     def close(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self._lib.cgamd_solver_destroy(self.handle)

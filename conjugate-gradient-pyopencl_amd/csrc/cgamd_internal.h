@@ -48,6 +48,7 @@ struct SpmvPlan {
     const unsigned char *codes = nullptr;   // [nnz + pad]: aCols[j] = row(j) + dict[codes[j]]
     const int *dict = nullptr;              // [256] distinct (column - row) offsets of the matrix
     const int *codes_for = nullptr;         // the aCols array the codes were made from
+    bool codes16 = false;                   // the codes are 16-bit columns relative to the row block's first column (build_index_codes16)
 };
 SpmvPlan make_spmv_plan(int n);
 // fills plan->max_span / chunk_span from the matrix structure; synchronises `st`; scratch_dev: >= 32 bytes

@@ -809,4 +809,21 @@ long long cgamd_solver_iter_bytes(cgamd_solver *s, int fused) {
     return s->nnz * (V + 4) + ((long long)s->n_user + 1) * 4 + (fused ? 11LL : 14LL) * s->n_user * V * s->nrhs;
 }
 
+// What the handle's own kernels MOVE (the physical byte model the roofline fraction is priced on): index bytes per non-zero as
+// the SpMV really reads them (1 with the one-byte column codes, 2 with 16-bit block-relative columns, else 4) and the vector
+// passes of the launched loop the handle runs (10 with the deferred x update, 11 without, 12 preconditioned, 14 for the
+// reference's op structure).  Handles whose iterate() runs a resident loop report the launched loop they fall back to.
+static long long index_bytes_per_nnz(const cgamd_solver *s) { return s->plan.codes ? (s->plan.codes16 ? 2 : 1) : 4; }
+long long cgamd_solver_spmv_moved_bytes(cgamd_solver *s) {
+    if (!s) return 0;
+    const long long V = (long long)dtype_size(s->dtype);
+    return s->nnz * (V + index_bytes_per_nnz(s)) + ((long long)s->n_user + 1) * 4 + 2LL * s->n_user * V * s->nrhs;
+}
+long long cgamd_solver_iter_moved_bytes(cgamd_solver *s) {
+    if (!s) return 0;
+    const long long V = (long long)dtype_size(s->dtype);
+    const long long passes = (s->flags & CGAMD_UNFUSED) ? 14 : s->mdiag ? 12 : (s->defer_x || s->rm || fused2_now(s)) ? 10 : 11;
+    return s->nnz * (V + index_bytes_per_nnz(s)) + ((long long)s->n_user + 1) * 4 + passes * s->n_user * V * s->nrhs;
+}
+
 }  // extern "C"

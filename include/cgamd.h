@@ -172,6 +172,12 @@ int cgamd_transpose(cgamd_ctx *ctx, int dtype, int rows, int cols, const void *i
  * reference's op structure, 11 for its "fused minimum"; the default loop here moves 10) */
 long long cgamd_solver_spmv_bytes(cgamd_solver *s);
 long long cgamd_solver_iter_bytes(cgamd_solver *s, int fused);
+/* the bytes this handle's own kernels move per SpMV / per iteration of its launched loop: index bytes per non-zero as the SpMV
+ * reads them (1 with one-byte column codes, 2 with 16-bit block-relative columns, 4 with aCols) and the loop's own vector passes
+ * (10 by default).  This is the figure a roofline FRACTION is priced on; the SURVEY 8(d) figures above are the
+ * reference's CSR byte model (an "effective" rate). */
+long long cgamd_solver_spmv_moved_bytes(cgamd_solver *s);
+long long cgamd_solver_iter_moved_bytes(cgamd_solver *s);
 
 /* one-call typed solve on host arrays: cg() generalised to all four dtypes, with history and status */
 int cgamd_cg(int dtype, int size, long long nnz, const void *aValues, const void *b, const int *aPointers,

@@ -130,3 +130,29 @@ def test_run_dist_keeps_collectives_matched_when_a_rank_fails(tmp_path, fail_ran
         assert int(rank) == r
         assert int(ok) == int(expect_ok) and int(agreed) == int(expect_ok)      # every rank learns the same verdict
         assert (err == "err") == (r == fail_rank)
+
+
+def test_roofline_fraction_is_priced_on_moved_bytes():
+    """VERDICT r2 weak #2 / ADVICE r2: `roofline.frac` and every `*_pct_of_8tbs` field are fractions of the bytes the kernels
+    really move; the reference's CSR byte model appears only as an "effective" rate.  Round 2's own numbers (one-byte column
+    codes: 827.5 MB moved per SpMV, 1 036.6 MB in the CSR model, 137.8 us per launch, 4 121 it/s) must read 0.75, not 0.94."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n, nnz, V = 10_000_000, 69_720_000, 8
+    moved = nnz * (V + 1) + (n + 1) * 4 + 2 * n * V
+    csr = nnz * (V + 4) + (n + 1) * 4 + 2 * n * V
+    it_moved = nnz * (V + 1) + (n + 1) * 4 + 10 * n * V
+    it_csr = nnz * (V + 4) + (n + 1) * 4 + 14 * n * V
+    f = bench.rate_fields(spmv_moved=moved, spmv_csr=csr, spmv_ms=0.1378, spmv_alone_ms=0.132, iter_moved=it_moved, iter_csr=it_csr,
+                          it_s=4121.0, traffic=889.6e6, traffic_source="test", n_offsets=7)
+    r = f["roofline"]
+    assert r["moved_bytes_per_launch"] == 827_480_004 and r["effective_csr_bytes_per_launch"] == 1_036_640_004
+    assert abs(r["frac"] - moved / 0.1378e-3 / 8e12) < 1e-12 and abs(r["frac"] - 0.7507) < 1e-3
+    assert abs(r["achieved"] - r["frac"] * 8000.0) < 1e-9
+    assert abs(r["traffic_ratio"] - 889.6e6 / moved) < 1e-12
+    # no printed fraction of moved bytes may exceed the peak (the CSR-priced iteration figure of round 2 read 102.8 %)
+    for key in ("spmv_pct_of_8tbs", "spmv_back_to_back_pct_of_8tbs", "cg_iter_pct_of_8tbs"):
+        assert 0.0 < f[key] <= 100.0, (key, f[key])
+    assert abs(f["cg_iter_pct_of_8tbs"] - 100.0 * it_moved * 4121.0 / 8e12) < 1e-9
+    assert f["effective_csr"]["cg_iter_gbs"] > 8000.0          # the effective figure may, and is labelled as such
+    assert "frac_moved" not in r and "frac" not in f["effective_csr"]
