@@ -266,7 +266,7 @@ int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs,
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);
 
 // ---- peer-to-peer backend (kernels.hip "Peer-to-peer communication over xGMI") ----------------------------
-constexpr size_t kMailboxHeader = 8192;   // slots + flags + error word; halo entries follow
+constexpr size_t kMailboxHeader = 16384;  // slots + flags + error word + single-reduction slots; halo entries follow
 struct P2pExchange {
     char *const *mailbox = nullptr;   // device array [nranks] of mapped mailbox bases
     int rank = 0, n_peers = 0, n_local = 0;
@@ -300,6 +300,33 @@ int launch_p2p_exchange(int dtype, const P2pExchange &e, void *v_ext, hipStream_
 int launch_p2p_allreduce(int dtype, int mode, const void *partials, int grid, char *const *mailbox, int rank, int nranks,
                          int which, unsigned long long *epoch, const CgScalars &sc, hipStream_t st,
                          unsigned long long *bump0 = nullptr, unsigned long long *bump1 = nullptr);
+
+// ---- single-reduction (Chronopoulos-Gear) loop of the row-partitioned solver (cg1.hip): w = A r with r.w and r.r partials
+// ([2][row_blocks]); one global exchange per iteration in the prologue of the update launch
+struct Cg1Update {
+    int n = 0;
+    void *r = nullptr, *p = nullptr, *s = nullptr, *x = nullptr;   // r: own part of the extended residual
+    const void *w = nullptr;
+    const void *red = nullptr;          // mailbox == null: accumulators {w.r, r.r} already summed over all ranks
+    const void *partials = nullptr;     // mailbox != null: [2][P] local partials of the SpMV launch
+    int P = 0;
+    char *const *mailbox = nullptr;
+    int rank = 0, nranks = 1;
+    const unsigned long long *slot_epoch = nullptr;
+    unsigned long long *halo_epoch = nullptr;
+    void *state = nullptr;              // T[2][2] {gamma, alpha} by iteration parity
+    CgScalars sc;
+};
+bool cg1_supported(const SpmvPlan &plan, const void *vals, const int *cols);
+// e == nullptr: the halo is already in r_ext (RCCL backend, single rank); else push / wait inside the launch.  Bumps *iter and
+// *slot_epoch (when non-null)
+int launch_spmv_cg1(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
+                    const void *r_ext, void *w, void *partials, const int *halo_flag, int rotate, const P2pExchange *e, int *iter,
+                    unsigned long long *slot_epoch, hipStream_t st);
+int launch_cg1_rowblock_rr(int dtype, int n, const void *r, void *partials, hipStream_t st);
+int launch_cg1_update(int dtype, const Cg1Update &c, hipStream_t st, int vec_nt = 0);
+// history[*iter] = r.r (no state of the recurrence changes); slot_epoch_rw: the slot epoch word (peer-to-peer form, advanced here)
+int launch_cg1_tail(int dtype, const Cg1Update &c, unsigned long long *slot_epoch_rw, hipStream_t st);
 
 // synthetic generators (device)
 int launch_gen_laplace3d(int dtype, int nx, int ny, int nz, long long row_begin, long long row_end, void *vals,

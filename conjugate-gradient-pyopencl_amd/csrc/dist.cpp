@@ -126,6 +126,10 @@ struct cgamd_dist {
     unsigned char *codes = nullptr;
     int *dict = nullptr;
     int n_offsets = 0;
+    // single-reduction loop (CGAMD_DIST_SINGLE_REDUCTION, cg1.hip).  Roles of the buffers there: d_ext = r (the residual is what the
+    // SpMV gathers, so it carries the halo), r = p, q = w = A r, s2 = s = A p
+    bool cg1 = false;
+    void *s2 = nullptr, *cg1_state = nullptr, *part_cg1 = nullptr;
 };
 
 static int dalloc(void **p, size_t bytes, const char *what) {
@@ -159,9 +163,9 @@ static int exchange(cgamd_dist *d, void *v_ext, hipStream_t st) {
     return CGAMD_OK;
 }
 
-static int allreduce_scalar(cgamd_dist *d, void *acc, hipStream_t st) {
+static int allreduce_scalar(cgamd_dist *d, void *acc, hipStream_t st, int count = 1) {
     if (!d->comm) return CGAMD_OK;
-    CG_NCCL(g_rccl.AllReduce(acc, acc, acc_size(d->dtype) / 8, ncclDouble, ncclSum, d->comm, st));
+    CG_NCCL(g_rccl.AllReduce(acc, acc, (size_t)count * acc_size(d->dtype) / 8, ncclDouble, ncclSum, d->comm, st));
     return CGAMD_OK;
 }
 
@@ -181,7 +185,49 @@ static int reduce_all(cgamd_dist *d, const void *partials, int count, int which,
     return launch_cg_beta(d->dtype, out, 1, 1, d->sc, st);
 }
 
+// ---- single-reduction loop (cg1.hip): [exchange of r] -> w = A r (+ r.w, r.r partials) -> ONE global sum -> alpha, beta and the
+// four vector updates in one launch.  Peer-to-peer: two launches (the exchange rides in the SpMV launch, the sum in the update
+// launch's prologue); RCCL: pack, send/recv, SpMV, local reduce, ncclAllReduce of two scalars, update (6 instead of 11 operations)
+static Cg1Update cg1_update_args(cgamd_dist *d, bool p2p) {
+    Cg1Update c;
+    c.n = d->n_local; c.r = d->d_ext; c.p = d->r; c.s = d->s2; c.x = d->x; c.w = d->q;
+    c.red = d->red; c.partials = d->part_cg1; c.P = d->plan.row_blocks;
+    c.mailbox = p2p ? d->mailbox_dev : nullptr;
+    c.rank = d->rank; c.nranks = d->nranks;
+    c.slot_epoch = p2p ? d->epochs + 3 : nullptr;
+    c.halo_epoch = p2p ? d->epochs : nullptr;
+    c.state = d->cg1_state; c.sc = d->sc;
+    return c;
+}
+static int enqueue_iteration_cg1(cgamd_dist *d, hipStream_t st) {
+    const int dt = d->dtype, n = d->n_local;
+    if (d->p2p && !d->p2p_attached) return fail(CGAMD_ERR_STATE, "p2p backend: call cgamd_dist_attach_p2p first");
+    const bool p2p = d->p2p;
+    int rc;
+    if (!p2p && (rc = exchange(d, d->d_ext, st))) return rc;
+    if ((rc = launch_spmv_cg1(dt, d->plan, n, d->nnz, d->vals, d->ptr, d->cols, d->d_ext, d->q, d->part_cg1, p2p ? d->halo_flag : nullptr,
+                              p2p ? d->rotate : 0, p2p ? &d->xch : nullptr, d->sc.iter, p2p ? d->epochs + 3 : nullptr, st))) return rc;
+    if (!p2p) {
+        if ((rc = launch_reduce_to_acc(dt, d->part_cg1, d->plan.row_blocks, 2, d->red, st))) return rc;
+        if ((rc = allreduce_scalar(d, d->red, st, 2))) return rc;
+    }
+    return launch_cg1_update(dt, cg1_update_args(d, p2p), st, d->plan.vec_nt);
+}
+// history[iterations done] = r.r of the current residual, in the partial-sum structure of the SpMV launch
+static int enqueue_tail_cg1(cgamd_dist *d, hipStream_t st) {
+    const int dt = d->dtype;
+    const bool p2p = d->p2p;
+    int rc;
+    if ((rc = launch_cg1_rowblock_rr(dt, d->n_local, d->d_ext, (char *)d->part_cg1 + acc_size(dt) * (size_t)d->plan.row_blocks, st))) return rc;
+    if (!p2p) {
+        if ((rc = launch_reduce_to_acc(dt, d->part_cg1, d->plan.row_blocks, 2, d->red, st))) return rc;
+        if ((rc = allreduce_scalar(d, d->red, st, 2))) return rc;
+    }
+    return launch_cg1_tail(dt, cg1_update_args(d, p2p), p2p ? d->epochs + 3 : nullptr, st);
+}
+
 static int enqueue_iteration(cgamd_dist *d, hipStream_t st) {
+    if (d->cg1) return enqueue_iteration_cg1(d, st);
     const int dt = d->dtype, n = d->n_local;
     const long long ldx = (long long)d->n_local + d->n_halo;
     int rc;
@@ -322,6 +368,7 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     d->ctx = ctx; d->dtype = dtype; d->rank = rank; d->nranks = nranks; d->n_local = n_local; d->n_halo = n_halo;
     d->nnz = nnz_local; d->vals = aValues; d->ptr = aPointers; d->cols = aCols; d->flags = flags;
     d->p2p = (flags & CGAMD_DIST_P2P) != 0;
+    d->cg1 = (flags & CGAMD_DIST_SINGLE_REDUCTION) != 0;
     d->plan = make_spmv_plan(n_local);
     d->vgrid = vec_grid(n_local, dtype);
     long long so = 0, ro = 0;
@@ -368,6 +415,14 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
         rc = build_index_codes(n_local, nnz_local, d->ptr, d->cols, ctx->stream, &d->codes, &d->dict, &d->n_offsets);
         if (!rc && d->codes) { d->plan.codes = d->codes; d->plan.dict = d->dict; d->plan.codes_for = d->cols; }
     }
+    if (!rc && d->cg1) {
+        if (!cg1_supported(d->plan, d->vals, d->cols))
+            rc = fail(CGAMD_ERR_INVALID, "dist_create: the single-reduction loop needs the row-block SpMV (16-byte aligned matrix arrays, rows "
+                                         "whose 256-row slices fit LDS)");
+        if (!rc) rc = dalloc(&d->s2, (size_t)n_local * vs, "s");
+        if (!rc) rc = dalloc(&d->cg1_state, 64, "single-reduction state");
+        if (!rc) rc = dalloc(&d->part_cg1, acc_size(dtype) * 2 * (size_t)d->plan.row_blocks, "partials (r.w, r.r)");
+    }
     if (!rc && id128 && !d->p2p) {
         rc = need_rccl();
         if (!rc) {
@@ -384,8 +439,8 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
         std::vector<int> interior, boundary;
         rc = classify_row_blocks(d, &interior, &boundary);
         const bool staged = (flags & CGAMD_DIST_P2P_STAGED) != 0;
-        if (!rc && d->p2p && !staged) rc = build_direct_schedule(d, boundary);
-        if (!rc && !d->direct && !(flags & CGAMD_DIST_NO_OVERLAP) && ((d->comm && !(flags & CGAMD_DIST_GRAPH)) || d->p2p))
+        if (!rc && d->p2p && (!staged || d->cg1)) rc = build_direct_schedule(d, boundary);
+        if (!rc && !d->direct && !d->cg1 && !(flags & CGAMD_DIST_NO_OVERLAP) && ((d->comm && !(flags & CGAMD_DIST_GRAPH)) || d->p2p))
             rc = build_overlap_lists(d, interior, boundary);
     }
     if (rc) {
@@ -418,7 +473,7 @@ int cgamd_dist_destroy(cgamd_dist *d) {
     if (d->codes) (void)hipFree(d->codes);
     if (d->dict) (void)hipFree(d->dict);
     void *bufs[] = {d->x, d->r, d->q, d->b, d->d_ext, d->sendbuf, d->part_dq, d->part_rr, d->red, d->sc.alpha,
-                    d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter};
+                    d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter, d->s2, d->cg1_state, d->part_cg1};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete d;
@@ -445,6 +500,10 @@ int cgamd_dist_set_rhs(cgamd_dist *d, const void *b_local, const void *x0_local)
     CG_HIP(hipMemcpyAsync(d->d_ext, d->r, vb, hipMemcpyDeviceToDevice, st));
     if ((rc = launch_dot_partials(d->dtype, d->n_local, d->r, d->r, d->n_local, 1, d->part_rr, d->vgrid, st))) return rc;
     if ((rc = reduce_all(d, d->part_rr, d->vgrid, 1, 1, st))) return rc;
+    if (d->cg1) {       // the residual lives in d_ext; p = s = 0 (the first iteration runs with beta = 0)
+        CG_HIP(hipMemsetAsync(d->r, 0, vb, st));
+        CG_HIP(hipMemsetAsync(d->s2, 0, vb, st));
+    }
     d->rhs_set = true;
     d->iters = 0;
     return CGAMD_OK;
@@ -476,6 +535,7 @@ int cgamd_dist_iterate(cgamd_dist *d, int nIterations) {
         else if (int rc = enqueue_iteration(d, st)) return rc;
     }
     d->iters += nIterations;
+    if (d->cg1 && nIterations > 0) return enqueue_tail_cg1(d, st);
     return CGAMD_OK;
 }
 
@@ -591,6 +651,15 @@ int cgamd_dist_comm_ranks(cgamd_dist *d) {
 
 // 0 = fine; != 0: a bounded spin of the peer-to-peer protocol timed out (1 boundary exchange, 2 all-reduce)
 int cgamd_dist_index_codes(cgamd_dist *d) { return d ? d->n_offsets : -CGAMD_ERR_INVALID; }
+
+// stream operations per iteration of the loop this handle runs (kernel launches, plus RCCL calls with that backend)
+int cgamd_dist_loop_launches(cgamd_dist *d) {
+    if (!d) return -CGAMD_ERR_INVALID;
+    if (d->cg1) return d->p2p ? 2 : (d->peer.empty() ? 4 : 6);
+    if (d->direct && d->p2p_attached) return 4;
+    if (d->p2p) return d->peer.empty() ? 5 : 7;
+    return d->peer.empty() ? 9 : 11;
+}
 
 int cgamd_dist_p2p_error(cgamd_dist *d) {
     if (!d || !d->p2p || !d->my_mailbox) return 0;

@@ -13,6 +13,7 @@
 
 #include "cgamd_internal.h"
 #include "device_types.h"
+#include "launch_util.h"
 
 namespace cgamd {
 namespace {
@@ -157,6 +158,100 @@ int launch_gen_helm_fe(int dtype, int variable, int N, double p0, double p1, dou
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("gen_helm_fe launch: ") + hipGetErrorString(e));
     return CGAMD_OK;
+}
+
+}  // namespace cgamd
+
+// =================================================================================================
+// Stencil generators (device side, so multi-GB systems never cross PCIe): SURVEY 8(d) "M" / "C5" and reference Poisson()
+// =================================================================================================
+namespace cgamd {
+
+__host__ __device__ inline long long lap3d_ptr(long long i, long long nx, long long ny, long long nz) {
+    // entries stored before row i = 7 i - (missing neighbours of rows < i), closed form
+    const long long pl = nx * ny, n = pl * nz;
+    const long long x0 = (i + nx - 1) / nx;                       // rows j<i with ix == 0
+    const long long x1 = i / nx;                                  // ix == nx-1
+    const long long full = i / pl, rem = i % pl;
+    const long long y0 = full * nx + (rem < nx ? rem : nx);       // iy == 0
+    const long long y1 = full * nx + (rem > pl - nx ? rem - (pl - nx) : 0);  // iy == ny-1
+    const long long z0 = i < pl ? i : pl;                         // iz == 0
+    const long long z1 = i > n - pl ? i - (n - pl) : 0;           // iz == nz-1
+    return 7 * i - (x0 + x1 + y0 + y1 + z0 + z1);
+}
+long long laplace3d_ptr(long long i, int nx, int ny, int nz) { return lap3d_ptr(i, nx, ny, nz); }
+
+template <typename T> CG_DEV T real_val(double v);
+template <> CG_DEV float real_val<float>(double v) { return (float)v; }
+template <> CG_DEV double real_val<double>(double v) { return v; }
+template <> CG_DEV float2 real_val<float2>(double v) { return make_float2((float)v, 0.f); }
+template <> CG_DEV double2 real_val<double2>(double v) { return make_double2(v, 0.); }
+
+template <typename T>
+__global__ void gen_laplace3d_kernel(int nx, int ny, int nz, long long row_begin, long long row_end, T *vals, int *ptr,
+                                     int *cols) {
+    const long long nloc = row_end - row_begin;
+    const long long base = lap3d_ptr(row_begin, nx, ny, nz);
+    for (long long li = (long long)blockIdx.x * blockDim.x + threadIdx.x; li <= nloc;
+         li += (long long)gridDim.x * blockDim.x) {
+        const long long i = row_begin + li;
+        long long p = lap3d_ptr(i, nx, ny, nz) - base;
+        ptr[li] = (int)p;
+        if (li == nloc) break;
+        const long long pl = (long long)nx * ny;
+        const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / pl);
+        if (iz > 0) { cols[p] = (int)(i - pl); vals[p++] = real_val<T>(-1.0); }
+        if (iy > 0) { cols[p] = (int)(i - nx); vals[p++] = real_val<T>(-1.0); }
+        if (ix > 0) { cols[p] = (int)(i - 1); vals[p++] = real_val<T>(-1.0); }
+        cols[p] = (int)i; vals[p++] = real_val<T>(6.0);
+        if (ix < nx - 1) { cols[p] = (int)(i + 1); vals[p++] = real_val<T>(-1.0); }
+        if (iy < ny - 1) { cols[p] = (int)(i + nx); vals[p++] = real_val<T>(-1.0); }
+        if (iz < nz - 1) { cols[p] = (int)(i + pl); vals[p++] = real_val<T>(-1.0); }
+    }
+}
+
+__host__ __device__ inline long long poi2d_ptr(long long i, long long N) {
+    const long long n = N * N;
+    const long long x0 = (i + N - 1) / N, x1 = i / N;
+    const long long y0 = i < N ? i : N, y1 = i > n - N ? i - (n - N) : 0;
+    return 5 * i - (x0 + x1 + y0 + y1);
+}
+long long poisson2d_ptr(long long i, int N) { return poi2d_ptr(i, N); }
+
+template <typename T> __global__ void gen_poisson2d_kernel(int N, T *vals, int *ptr, int *cols) {
+    const long long n = (long long)N * N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (long long)gridDim.x * blockDim.x) {
+        long long p = poi2d_ptr(i, N);
+        ptr[i] = (int)p;
+        if (i == n) break;
+        const int jx = (int)(i % N), iy = (int)(i / N);
+        if (iy > 0) { cols[p] = (int)(i - N); vals[p++] = real_val<T>(-1.0); }
+        if (jx > 0) { cols[p] = (int)(i - 1); vals[p++] = real_val<T>(-1.0); }
+        cols[p] = (int)i; vals[p++] = real_val<T>(4.0);
+        if (jx < N - 1) { cols[p] = (int)(i + 1); vals[p++] = real_val<T>(-1.0); }
+        if (iy < N - 1) { cols[p] = (int)(i + N); vals[p++] = real_val<T>(-1.0); }
+    }
+}
+
+template <typename T>
+static int gen3d_impl(int nx, int ny, int nz, long long rb, long long re, void *vals, int *ptr, int *cols, hipStream_t st) {
+    const long long nloc = re - rb + 1;
+    int g = (int)((nloc + 255) / 256 < 8192 ? (nloc + 255) / 256 : 8192);
+    hipLaunchKernelGGL((gen_laplace3d_kernel<T>), dim3(g), dim3(256), 0, st, nx, ny, nz, rb, re, (T *)vals, ptr, cols);
+    return check_launch("gen_laplace3d");
+}
+int launch_gen_laplace3d(int dtype, int nx, int ny, int nz, long long row_begin, long long row_end, void *vals, int *ptr,
+                         int *cols, hipStream_t st) {
+    CG_DISPATCH(dtype, gen3d_impl, nx, ny, nz, row_begin, row_end, vals, ptr, cols, st);
+}
+template <typename T> static int gen2d_impl(int N, void *vals, int *ptr, int *cols, hipStream_t st) {
+    const long long n = (long long)N * N + 1;
+    int g = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL((gen_poisson2d_kernel<T>), dim3(g), dim3(256), 0, st, N, (T *)vals, ptr, cols);
+    return check_launch("gen_poisson2d");
+}
+int launch_gen_poisson2d(int dtype, int N, void *vals, int *ptr, int *cols, hipStream_t st) {
+    CG_DISPATCH(dtype, gen2d_impl, N, vals, ptr, cols, st);
 }
 
 }  // namespace cgamd

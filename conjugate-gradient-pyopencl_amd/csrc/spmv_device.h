@@ -1,0 +1,194 @@
+// Device-side pieces shared by the SpMV kernel files (spmv.hip, p2p.hip, cg1.hip): kernel arguments, the row-block -> XCD
+// schedule, and the staging of a row block's matrix slice in LDS.
+#pragma once
+#include "cgamd_internal.h"
+#include "device_types.h"
+#include "device_mem.h"
+
+namespace cgamd {
+
+// =================================================================================================
+// SpMV / SpMM, CSR-stream: a work-group owns BLOCK consecutive rows at a time.  Their non-zeros are one
+// contiguous slice of aValues/aCols, streamed with 16 B coalesced non-temporal loads (4 nnz per lane
+// per load group, slice start rounded down to a multiple of 4 so every load is aligned); each lane
+// multiplies its non-zeros with the gathered x entries and parks the products in LDS; after one
+// barrier, lane t sums the products of row t (left to right, CSR order) and writes y[t] coalesced.
+// For nRHS > 1 the matrix quads stay in registers while the gather/LDS/sum phase repeats per RHS,
+// so the matrix is read from HBM once per SpMM.
+// =================================================================================================
+template <typename T> struct SpmvArgs {
+    int n;
+    int nrhs;
+    long long nnz;
+    const T *vals;
+    const int *ptr;
+    const int *cols;
+    const T *x;
+    long long ldx;
+    T *y;
+    long long ldy;
+    const T *dvec;                  // fused dot: sum dvec[row] * y[row]
+    typename VT<T>::acc *partials;  // [nrhs][grid]
+    int row_blocks;
+    const int *rb_list;             // row-block kernel: optional explicit list of row blocks (multi-GPU interior / boundary split)
+    int rb_count;
+    int cap;   // row-block kernel: LDS slice capacity in entries (multiple of 4)
+    int cycle; // row-block kernel: block-cyclic schedule over the XCDs, cycle length in row blocks (1 = one contiguous eighth per XCD)
+    const unsigned char *codes;   // coded row-block kernel: one byte per non-zero, aCols[j] = row + dict[codes[j]] (build_index_codes)
+    const int *dict;              // [256]
+};
+
+// Row-block schedule shared by the row-block kernels: work-group b runs on XCD b%8 as that XCD's (b/8)-th block.
+// cycle > 1: block-cyclic -- cycles of `cycle` row blocks, XCD j takes the j-th run of ceil(cycle/8) blocks of each;
+// cycle <= 1: XCD j owns the j-th contiguous eighth.  Returns -1 for the padding work-groups of the grid.
+__host__ __device__ __forceinline__ int rowblock_of(int b, int row_blocks, int cycle) {
+    const int xcd = b & 7, i = b >> 3;
+    if (cycle > 1) {
+        const int chunk = (cycle + 7) >> 3;
+        const int k = i / chunk, lo = xcd * chunk + (i - k * chunk);
+        const int rb = k * cycle + lo;
+        return (lo < cycle && rb < row_blocks) ? rb : -1;
+    }
+    const int xb = (int)((long long)xcd * row_blocks / 8), xe = (int)((long long)(xcd + 1) * row_blocks / 8);
+    return i < xe - xb ? xb + i : -1;
+}
+inline int rowblock_grid(int row_blocks, int cycle) {
+    if (cycle > 1) return 8 * ((cycle + 7) / 8) * ((row_blocks + cycle - 1) / cycle);
+    int per_xcd = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int m = (int)((long long)(x + 1) * row_blocks / 8) - (int)((long long)x * row_blocks / 8);
+        per_xcd = m > per_xcd ? m : per_xcd;
+    }
+    return per_xcd * 8;
+}
+
+// 4 consecutive matrix entries (values + columns) starting at the 4-aligned entry q: 16-byte loads.  FULL = the
+// caller knows q + 4 <= nnz; otherwise the guarded scalar path covers the last, partial quad of the matrix.
+template <typename T, bool NT, bool FULL> CG_DEV void load_quad(const T *__restrict__ vals, const int *__restrict__ cols,
+                                                                long long nnz, long long q, T (&v)[4], int (&c)[4]) {
+    if (FULL || q + 4 <= nnz) {
+        ld4<NT>(vals + q, v);
+        const i32x4 cc = ld16<i32x4, NT>(cols + q);
+        c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = q + k < nnz;
+            v[k] = ok ? vals[q + k] : vzero<T>();
+            c[k] = ok ? cols[q + k] : 0;
+        }
+    }
+}
+
+// Park the slice [cfirst, p1) of aValues/aCols raw in LDS.  Every lane issues the loads of TWO quads before it
+// waits for either (a plain loop made hipcc wait for quad 1 before issuing quad 2: one more dependent HBM
+// round trip per work-group, and the work-group's lifetime is a chain of such round trips).
+template <typename T, int BLOCK, bool NT, bool FULL>
+CG_DEV void stage_slice_impl(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
+                             T *sv, int *sc) {
+    const int t = threadIdx.x;
+    for (long long base = cfirst; base < p1; base += 8 * BLOCK) {
+        const long long q0 = base + 4 * t, q1 = q0 + 4 * BLOCK;
+        const bool h0 = q0 < p1, h1 = q1 < p1;
+        T v0[4], v1[4];
+        int c0[4], c1[4];
+        if (h0) load_quad<T, NT, FULL>(vals, cols, nnz, q0, v0, c0);
+        if (h1) load_quad<T, NT, FULL>(vals, cols, nnz, q1, v1, c1);
+        if (h0) {
+            const int o = (int)(q0 - cfirst);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sv[o + k] = v0[k]; sc[o + k] = c0[k]; }
+        }
+        if (h1) {
+            const int o = (int)(q1 - cfirst);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sv[o + k] = v1[k]; sc[o + k] = c1[k]; }
+        }
+    }
+}
+// Same job with the VALUE stream interleaved across the lanes in 16-byte chunks: chunk k of a lane is chunk k*64 + lane of
+// its wave's 256-entry span, so every load instruction of a wave covers one contiguous 1 KB (the plain version above gives
+// a lane 4 consecutive entries = 16/32/64 contiguous bytes, and each of its 1/2/4 load instructions touches every cache
+// line of the span partially).  With non-temporal loads the partially used lines of complex128 were fetched again by the
+// later instructions: 435 -> 313 us for the N=10M SpMV.  Columns (4 B) keep the quad mapping: one 16-byte load per lane.
+template <typename T> struct Chunk16;
+template <> struct Chunk16<float> { using V = f32x4; };
+template <> struct Chunk16<double> { using V = f64x2; };
+template <> struct Chunk16<float2> { using V = f32x4; };
+template <> struct Chunk16<double2> { using V = f64x2; };
+template <typename T, int BLOCK, bool NT, bool FULL, bool CODED = false>
+CG_DEV void stage_slice_ilv(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
+                            T *sv, int *sc, const unsigned char *__restrict__ codes = nullptr) {
+    using V = typename Chunk16<T>::V;
+    constexpr int EPC = 16 / (int)sizeof(T);   // values per chunk
+    constexpr int NV = 4 / EPC;                // chunks per lane and quad region
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    for (long long base = cfirst; base < p1; base += 8 * BLOCK) {
+        V ch[2][NV];
+        i32x4 cc[2];
+        unsigned cw[2];
+        long long ev[2][NV], qc[2];
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            const long long rbase = base + (long long)rg * 4 * BLOCK;
+            qc[rg] = rbase + 4 * t;
+            if constexpr (CODED) {      // four one-byte codes per lane; the code array is padded, no tail handling
+                if (qc[rg] < p1) {
+                    const unsigned *cp = reinterpret_cast<const unsigned *>(codes + qc[rg]);
+                    cw[rg] = NT ? __builtin_nontemporal_load(cp) : *cp;
+                }
+            } else if (qc[rg] < p1 && (FULL || qc[rg] + 4 <= nnz)) cc[rg] = ld16<i32x4, NT>(cols + qc[rg]);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                ev[rg][k] = rbase + (long long)wave * 4 * kWave + (long long)(k * kWave + lane) * EPC;
+                if (ev[rg][k] < p1 && (FULL || ev[rg][k] + EPC <= nnz)) ch[rg][k] = ld16<V, NT>(vals + ev[rg][k]);
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            if (qc[rg] < p1) {
+                const int o = (int)(qc[rg] - cfirst);
+                if constexpr (CODED) {
+                    *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(sc) + o) = cw[rg];
+                } else if (FULL || qc[rg] + 4 <= nnz) {
+                    *reinterpret_cast<i32x4 *>(sc + o) = cc[rg];
+                } else {
+                    for (int j = 0; j < 4; ++j) sc[o + j] = qc[rg] + j < nnz ? cols[qc[rg] + j] : 0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (ev[rg][k] < p1) {
+                    const int o = (int)(ev[rg][k] - cfirst);
+                    if (FULL || ev[rg][k] + EPC <= nnz) {
+                        *reinterpret_cast<V *>(sv + o) = ch[rg][k];
+                    } else {
+                        for (int j = 0; j < EPC; ++j) sv[o + j] = ev[rg][k] + j < nnz ? vals[ev[rg][k] + j] : vzero<T>();
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T> constexpr bool kIlvDefault = true;   // N=10M SpMV: f64 186 -> 165 us, c64 186 -> 166, c128 435 -> 314, f32 109 -> 105 (ab_ilv.log)
+template <typename T, int BLOCK, bool NT, int POL = -1>
+CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1, T *sv,
+                        int *sc, const unsigned char *__restrict__ codes = nullptr) {
+    if (POL == -3) {       // lane-interleaved value chunks + one-byte column codes
+        if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true, true>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
+        else stage_slice_ilv<T, BLOCK, NT, false, true>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
+        return;
+    }
+    if (POL == -2) {       // lane-interleaved value chunks
+        if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true>(vals, cols, nnz, cfirst, p1, sv, sc);
+        else stage_slice_ilv<T, BLOCK, NT, false>(vals, cols, nnz, cfirst, p1, sv, sc);
+        return;
+    }
+    // only the work-group that owns the very end of the matrix can meet a partial quad: block-uniform branch,
+    // so the common path carries no per-lane tail handling (whose control flow made hipcc serialise the loads)
+    if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_impl<T, BLOCK, NT, true>(vals, cols, nnz, cfirst, p1, sv, sc);
+    else stage_slice_impl<T, BLOCK, NT, false>(vals, cols, nnz, cfirst, p1, sv, sc);
+}
+
+}  // namespace cgamd

@@ -178,6 +178,42 @@ def cg_loop(ops, comm, plan, b_local, x0_local, n_iterations):
     return x, torch.cat(hist)
 
 
+def cg_loop_single_reduction(ops, comm, plan, b_local, x0_local, n_iterations):
+    """The single-reduction form of the same recurrence (Chronopoulos & Gear; csrc/cg1.hip is the device loop): w = A r, ONE
+    all-reduce of {r.r, w.r} per iteration instead of two, the exchanged vector is r.  Same iterates in exact arithmetic; the
+    rounding differs, so callers hold it to a stated tolerance, not to the bits of `cg_loop`.  history[k] = r_k . r_k."""
+    import torch
+    n = plan.n_local
+    x = x0_local.clone()
+    r_ext = torch.zeros(n + plan.n_halo, dtype=b_local.dtype, device=b_local.device)
+    r_ext[:n] = x
+    comm.exchange(r_ext)
+    r_ext[:n] = b_local - ops.spmv(r_ext)                            # clcg.c:255-260
+    p = torch.zeros_like(b_local)
+    s = torch.zeros_like(b_local)
+    hist, gamma_old, alpha_old = [], None, None
+    for k in range(n_iterations + 1):
+        comm.exchange(r_ext)                                        # boundary exchange of r
+        w = ops.spmv(r_ext)
+        red = comm.allreduce(torch.stack([ops.dot(r_ext[:n], r_ext[:n]), ops.dot(r_ext[:n], w)]).clone())   # the ONE reduction
+        gamma, dl = red[0], red[1]
+        hist.append(gamma.reshape(1).clone())
+        if k == n_iterations:
+            break
+        if k == 0:
+            beta = torch.zeros_like(gamma)
+            alpha = gamma / dl
+        else:
+            beta = gamma / gamma_old
+            alpha = gamma / (dl - beta * gamma / alpha_old)
+        p = r_ext[:n] + beta * p
+        s = w + beta * s
+        x = x + alpha * p
+        r_ext[:n] = r_ext[:n] - alpha * s
+        gamma_old, alpha_old = gamma, alpha
+    return x, torch.cat(hist)
+
+
 # ---------------------------------------------------------------------------------------------------
 # the C loop
 # ---------------------------------------------------------------------------------------------------

@@ -107,6 +107,11 @@ int cgamd_sub(cgamd_ctx *ctx, int dtype, int size, const void *a, const void *b,
                                      * iteration) instead of the default four-launch iteration (push and wait inside the SpMV
                                      * launch, halo read in place from the mailbox, beta all-reduce inside the aypx launch) */
 
+#define CGAMD_DIST_SINGLE_REDUCTION 256   /* cgamd_dist_create: the single-reduction form of the recurrence (Chronopoulos-Gear: w = A r,
+                                     * ONE global exchange of {r.r, w.r} per iteration instead of two, two launches per iteration with
+                                     * CGAMD_DIST_P2P): the same iterates in exact arithmetic, different rounding -- opt-in, held to a
+                                     * stated tolerance against the reference's iterates, not bit for bit (csrc/cg1.hip) */
+
 int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, const void *aValues,
                         const int *aPointers, const int *aCols, int nRHS, int flags, cgamd_solver **out);
 int cgamd_solver_destroy(cgamd_solver *s);
@@ -243,7 +248,7 @@ int cgamd_dist_get_x(cgamd_dist *d, void *x_local);                             
 int cgamd_dist_history(cgamd_dist *d, void *history, int max_entries);
 int cgamd_dist_synchronize(cgamd_dist *d);
 /* Peer-to-peer backend (CGAMD_DIST_P2P): instead of RCCL, every rank owns an uncached IPC-shared mailbox
- * (8 KiB header + n_halo values) that its peers write over xGMI; all-reduces are sums in rank order of values
+ * (16 KiB header + n_halo values) that its peers write over xGMI; all-reduces are sums in rank order of values
  * deposited in per-rank slots (bitwise identical on all ranks).  Sequence: mailbox_alloc on every rank -> gather
  * the 64-byte handles of all ranks (torch.distributed) -> dist_create(..., id128 = NULL, flags | CGAMD_DIST_P2P)
  * -> attach_p2p(handles[nranks*64], dst_offset[n_peers] = where my entries land in each peer's halo area). */
@@ -253,6 +258,8 @@ int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, 
 int cgamd_dist_p2p_error(cgamd_dist *d);
 /* as cgamd_solver_index_codes, for this rank's local matrix (the halo columns of a slab partition sit at constant offsets) */
 int cgamd_dist_index_codes(cgamd_dist *d);
+/* stream operations per iteration of the loop this handle runs (kernel launches, plus RCCL calls with that backend) */
+int cgamd_dist_loop_launches(cgamd_dist *d);
 /* number of ranks of the RCCL communicator behind this handle as RCCL itself reports it (ncclCommCount);
  * 0 when the handle has no communicator (peer-to-peer backend, or one rank without peers) */
 int cgamd_dist_comm_ranks(cgamd_dist *d);
