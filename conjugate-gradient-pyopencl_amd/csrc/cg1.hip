@@ -168,7 +168,21 @@ template <typename T> struct Cg1UpdateArgs {
 // launch's work-group 0 and the tail kernel, so both produce the same bits for the same partials
 template <typename A, int BLOCK> CG_DEV void cg1_local_sums(const A *partials, int P, bool both, A &s_wr, A &s_rr, A *red) {
     A a1 = vzero<A>(), a2 = vzero<A>();
-    for (int i = threadIdx.x; i < P; i += BLOCK) {
+    int i = threadIdx.x;
+    for (; i + 7 * BLOCK < P; i += 8 * BLOCK) {      // 8 (x2) loads in flight; the additions keep the thread-strided order
+        A v1[8], v2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v2[k] = partials[P + i + k * BLOCK];
+            if (both) v1[k] = partials[i + k * BLOCK];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (both) a1 = vadd(a1, v1[k]);
+            a2 = vadd(a2, v2[k]);
+        }
+    }
+    for (; i < P; i += BLOCK) {
         if (both) a1 = vadd(a1, partials[i]);
         a2 = vadd(a2, partials[P + i]);
     }

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--skip-rccl", action="store_true")
     ap.add_argument("--only", default="", help="run just this loop (e.g. 'p2p+graph'); skips the plain solver too")
+    ap.add_argument("--skip-staged", action="store_true", help="skip the staged peer-to-peer loops (seven launches)")
     args = ap.parse_args()
     import torch
     pkg = importlib.import_module("conjugate-gradient-pyopencl_amd")
@@ -69,13 +70,18 @@ def main():
     plan = dmod.HaloPlan(0, 1, 0, n, n, h, cols_local, torch.arange(h), [0], [h], [h],
                          torch.arange(h, dtype=torch.int32, device=dev))
     ST = L.DIST_P2P_STAGED
-    modes = [("p2p4", "p2p", 0), ("p2p4+graph", "p2p", L.DIST_GRAPH),
+    SR = L.DIST_SINGLE_REDUCTION
+    modes = [("p2p2 single-reduction", "p2p", SR), ("p2p2 single-red.+graph", "p2p", SR | L.DIST_GRAPH),
+             ("p2p4", "p2p", 0), ("p2p4+graph", "p2p", L.DIST_GRAPH),
              ("p2p staged", "p2p", ST | L.DIST_NO_OVERLAP), ("p2p staged+graph", "p2p", ST | L.DIST_GRAPH | L.DIST_NO_OVERLAP),
              ("p2p staged overlap", "p2p", ST)]
     if not args.skip_rccl:
-        modes += [("rccl+graph", "rccl", L.DIST_GRAPH), ("rccl", "rccl", 0)]
+        modes += [("rccl single-red.+graph", "rccl", SR | L.DIST_GRAPH), ("rccl single-reduction", "rccl", SR),
+                  ("rccl+graph", "rccl", L.DIST_GRAPH), ("rccl", "rccl", 0)]
     for name, comm, fl in modes:
         if args.only and args.only != name:
+            continue
+        if args.skip_staged and "staged" in name:
             continue
         uid = np.zeros(128, dtype=np.uint8)
         if comm == "rccl":

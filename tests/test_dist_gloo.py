@@ -43,7 +43,7 @@ def _system(kind):
     return ip, ix, da, b
 
 
-def _worker(rank, world, port, kind, iters, out_dir):
+def _worker(rank, world, port, kind, iters, out_dir, single_reduction=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -88,7 +88,8 @@ def _worker(rank, world, port, kind, iters, out_dir):
 
         comm = dmod.TorchComm(plan)
         bl = torch.from_numpy(b[rb:re].astype(da.dtype))
-        x, hist = dmod.cg_loop(OracleOps(), comm, plan, bl, torch.zeros_like(bl), iters)
+        loop = dmod.cg_loop_single_reduction if single_reduction else dmod.cg_loop
+        x, hist = loop(OracleOps(), comm, plan, bl, torch.zeros_like(bl), iters)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), x=x.numpy(), hist=hist.numpy(), rb=rb, re=re,
                  n_halo=plan.n_halo, peers=np.array(plan.peers))
     finally:
@@ -116,6 +117,25 @@ def test_distributed_cg_matches_serial_oracle(tmp_path, world, kind):
     if kind == "lap3d":       # z-slab partition of a 7-point stencil: one plane per neighbour
         assert all(int(p["n_halo"]) in (30, 60) for p in parts)
         assert [list(p["peers"]) for p in parts] == ([[1], [0]] if world == 2 else [[1], [0, 2], [1]])
+
+
+@pytest.mark.parametrize("world,kind", [(2, "lap3d"), (3, "helm"), (2, "random")])
+def test_single_reduction_loop_matches_serial_oracle(tmp_path, world, kind):
+    """the single-reduction form of the distributed recurrence (dist.cg_loop_single_reduction, the host twin of csrc/cg1.hip):
+    one all-reduce of {r.r, w.r} per iteration, the halo exchange carries r.  Same iterates as the reference recurrence to the
+    stated fp64 tolerance (not bit for bit: the rounding differs)."""
+    import torch.multiprocessing as mp
+    import cg_oracle
+    iters = 12
+    mp.spawn(_worker, args=(world, _free_port(), kind, iters, str(tmp_path), True), nprocs=world, join=True)
+    ip, ix, da, b = _system(kind)
+    xo, ho = cg_oracle.cg(ip, ix, da, b.astype(da.dtype), n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
+    parts = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    x = np.concatenate([p["x"] for p in parts])
+    for p in parts[1:]:
+        assert np.allclose(p["hist"], parts[0]["hist"], rtol=1e-12)
+    assert np.max(np.abs(parts[0]["hist"] - ho[:, 0]) / np.abs(ho[:, 0])) < 1e-10
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-9
 
 
 def test_nnz_balanced_row_ranges(pkg):

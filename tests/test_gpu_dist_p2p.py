@@ -109,7 +109,10 @@ def _worker(rank, world, port, kind, iters, flags, out_dir, coded=False):
                                                     (2, "dense", 0, False), (3, "dense", 8, False), (4, "rand", 0, False), (3, "rand", 8, False),
                                                     (3, "rand", 128, False),
                                                     (3, "lap3d", 0, True), (2, "helm", 8, True), (3, "lap3d", 128, True), (3, "helm_c64", 0, True),
-                                                    (2, "lap3d", 128 | 32, True)])
+                                                    (2, "lap3d", 128 | 32, True),
+                                                    # 256 = single-reduction loop (csrc/cg1.hip): two launches, one scalar exchange per iteration
+                                                    (2, "lap3d", 256, False), (3, "helm", 256 | 8, False), (4, "lap3d", 256, True),
+                                                    (3, "helm_c64", 256, False), (2, "lap3d_f32", 256 | 8, False), (4, "rand", 256, False)])
 def test_p2p_multirank_on_one_gpu(tmp_path, world, kind, flags, coded):
     import torch.multiprocessing as mp
     import cg_oracle
