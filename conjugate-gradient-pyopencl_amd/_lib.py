@@ -17,7 +17,7 @@ DTYPE_CODE = {np.dtype(np.float32): F32, np.dtype(np.float64): F64,
               np.dtype(np.complex64): C64, np.dtype(np.complex128): C128}
 CODE_DTYPE = {v: k for k, v in DTYPE_CODE.items()}
 
-MATRIX_ON_DEVICE, NO_GRAPH, UNFUSED, DIST_GRAPH, DIST_NO_OVERLAP, DIST_P2P, DIST_P2P_STAGED, DIST_SINGLE_REDUCTION = 1, 2, 4, 8, 32, 64, 128, 256
+MATRIX_ON_DEVICE, NO_GRAPH, UNFUSED, DIST_GRAPH, DIST_NO_OVERLAP, DIST_P2P, DIST_P2P_STAGED, DIST_SINGLE_REDUCTION, DIST_RESIDENT = 1, 2, 4, 8, 32, 64, 128, 256, 512
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_IO, ERR_COMM, ERR_STATE = range(8)      # cgamd_status (include/cgamd.h)
 
 

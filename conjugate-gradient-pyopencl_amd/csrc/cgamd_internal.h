@@ -101,7 +101,7 @@ struct Tuning {
                             // 4096 rows: up to ~1M rows): one chip-wide resident group, matrix in registers; 0 = launched loops
     int resident_wide_min = 16; // ... for iterate() calls of at least this many iterations (a launch costs ~70-150 us of set-up: break-even
                                // against the launched loops at 4 / 12 / 24 iterations for 1M / 250k / 90k rows, scripts/short_calls.py)
-    int resident_claim_ms = 15000; // resident loops: how long work-groups wait for their group to fill (CUs held by other kernels) before the
+    int resident_claim_ms = 200;   // resident loops: how long a call waits for the GPU's resident-launch lock, and work-groups for their group to fill (CUs held by other kernels), before the
                                // launch gives up untouched and the handle goes back to the launched loops
     int resident_test_short_grid = 0; // test hook: launch one work-group too few, so that no group can fill
     int resident_wide_rpt = 0; // rows per thread of the chip-wide loop: 0 = the smallest that fits (4, then 8), or 4 / 8
@@ -247,6 +247,19 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
                     void *d0, void *d1, void *part_rr, int P_rr, int row_blocks, const CgScalars &sc, int it0, int K, void *sync,
                     int n_cus, hipStream_t st, bool *untouched = nullptr, double tol = 0., int *stopped_at = nullptr);
 
+// serialises resident launches per GPU (resident.hip); held() == false: not obtained within wait_ms -- fall back, touch nothing
+struct ResidentLock {
+    ResidentLock(int device, int wait_ms);
+    ~ResidentLock();
+    ResidentLock(const ResidentLock &) = delete;
+    ResidentLock &operator=(const ResidentLock &) = delete;
+    bool held() const { return held_; }
+private:
+    void *mutex_ = nullptr;
+    int fd_ = -1;
+    bool held_ = false;
+};
+
 // wide resident loop (resident.hip): chip-wide groups (one right-hand side each at a time), matrix rows in registers
 struct ResidentWidePlan {
     bool ok = false;
@@ -261,6 +274,19 @@ int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, con
 int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs, const void *vals, const int *ptr, const int *cols, void *x,
                          void *r, void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int n_cus, hipStream_t st,
                          bool *untouched = nullptr, double tol = 0., int *stopped_at = nullptr);
+
+// slab loop (slab.hip): every iteration of a call in one launch, vectors in registers, matrix streamed; systems of up to ~3M rows
+struct SlabPlan {
+    bool ok = false;
+    int rows_m = 0, G = 0, nsteps = 0, cap = 0, ccap = 0, unroll = 8;
+    size_t lds_bytes = 0, sync_bytes = 0;
+};
+bool slab_plan(int dtype, int n, int n_cus, const SpmvPlan &plan, bool coded, SlabPlan *out);
+// state in and out: x, r, d (already beta d + r), delta / beta / alpha / history / iter of the three / four-launch loops; d1: a second
+// buffer of n values; codes / dict: the one-byte column codes of the matrix (required)
+int run_cg_slab(int dtype, const SlabPlan &sp, int n, long long nnz, const void *vals, const int *ptr, const unsigned char *codes,
+                const int *dict, void *x, void *r, void *d0, void *d1, const CgScalars &sc, int it0, int K, void *sync, hipStream_t st,
+                bool *untouched = nullptr);
 
 // [rows][cols] -> [cols][rows]: RHS-major (the reference ABI) <-> row-major
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);

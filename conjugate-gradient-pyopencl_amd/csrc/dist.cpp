@@ -130,6 +130,10 @@ struct cgamd_dist {
     // SpMV gathers, so it carries the halo), r = p, q = w = A r, s2 = s = A p
     bool cg1 = false;
     void *s2 = nullptr, *cg1_state = nullptr, *part_cg1 = nullptr;
+    // slab loop (CGAMD_DIST_RESIDENT, slab.hip): every iteration of an iterate() call in one launch, vectors in registers
+    SlabPlan slab;
+    void *slab_sync = nullptr, *d2 = nullptr;
+    int n_cus = 0;
 };
 
 static int dalloc(void **p, size_t bytes, const char *what) {
@@ -423,6 +427,15 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
         if (!rc) rc = dalloc(&d->cg1_state, 64, "single-reduction state");
         if (!rc) rc = dalloc(&d->part_cg1, acc_size(dtype) * 2 * (size_t)d->plan.row_blocks, "partials (r.w, r.r)");
     }
+    if (!rc && (flags & CGAMD_DIST_RESIDENT) && !d->cg1) {
+        if (hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) d->n_cus = 0;
+        SlabPlan sp;
+        if (slab_plan(dtype, n_local, d->n_cus, d->plan, d->codes != nullptr, &sp) && d->peer.empty()) {
+            rc = dalloc(&d->slab_sync, sp.sync_bytes, "slab sync words");
+            if (!rc) rc = dalloc(&d->d2, (size_t)n_local * vs, "d (second buffer)");
+            if (!rc) d->slab = sp;
+        }
+    }
     if (!rc && id128 && !d->p2p) {
         rc = need_rccl();
         if (!rc) {
@@ -473,7 +486,7 @@ int cgamd_dist_destroy(cgamd_dist *d) {
     if (d->codes) (void)hipFree(d->codes);
     if (d->dict) (void)hipFree(d->dict);
     void *bufs[] = {d->x, d->r, d->q, d->b, d->d_ext, d->sendbuf, d->part_dq, d->part_rr, d->red, d->sc.alpha,
-                    d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter, d->s2, d->cg1_state, d->part_cg1};
+                    d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter, d->s2, d->cg1_state, d->part_cg1, d->slab_sync, d->d2};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete d;
@@ -518,6 +531,23 @@ int cgamd_dist_iterate(cgamd_dist *d, int nIterations) {
     if (int rc = ensure_history(d, d->iters + nIterations + 1)) return rc;
     hipStream_t st = d->ctx->stream;
     int left = nIterations;
+    if (d->slab.ok && nIterations >= std::max(1, d->tune.resident_wide_min)) {
+        // the whole call in one launch per 2^15 iterations (slab.hip); same state in and out as the launched loop below
+        while (left > 0) {
+            const int K = std::min(left, 1 << 15);
+            bool untouched = false;
+            if (int rc = run_cg_slab(d->dtype, d->slab, d->n_local, d->nnz, d->vals, d->ptr, d->codes, d->dict, d->x, d->r, d->d_ext,
+                                     d->d2, d->sc, d->iters, K, d->slab_sync, st, &untouched)) {
+                if (!untouched) return rc;
+                d->slab.ok = false;          // the chip is shared with something that does not yield: launched loop from here on
+                break;
+            }
+            d->iters += K;
+            left -= K;
+        }
+        if (left == 0) return CGAMD_OK;
+        nIterations = left;
+    }
     // Optional hipGraph replay of one iteration including the RCCL operations (RCCL >= 2.9 captures).
     if ((d->flags & CGAMD_DIST_GRAPH) && !d->graph_failed && !d->gexec) {
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
@@ -655,6 +685,7 @@ int cgamd_dist_index_codes(cgamd_dist *d) { return d ? d->n_offsets : -CGAMD_ERR
 // stream operations per iteration of the loop this handle runs (kernel launches, plus RCCL calls with that backend)
 int cgamd_dist_loop_launches(cgamd_dist *d) {
     if (!d) return -CGAMD_ERR_INVALID;
+    if (d->slab.ok) return 0;
     if (d->cg1) return d->p2p ? 2 : (d->peer.empty() ? 4 : 6);
     if (d->direct && d->p2p_attached) return 4;
     if (d->p2p) return d->peer.empty() ? 5 : 7;

@@ -112,6 +112,12 @@ int cgamd_sub(cgamd_ctx *ctx, int dtype, int size, const void *a, const void *b,
                                      * CGAMD_DIST_P2P): the same iterates in exact arithmetic, different rounding -- opt-in, held to a
                                      * stated tolerance against the reference's iterates, not bit for bit (csrc/cg1.hip) */
 
+#define CGAMD_DIST_RESIDENT 512      /* cgamd_dist_create: iterate() calls of at least `resident_wide_min` iterations run in ONE launch (csrc/slab.hip:
+                                     * vectors in registers, matrix streamed, the two reductions as in-launch all-gathers) where the rank's
+                                     * slab fits (up to ~3M rows of at most 8 entries on average, not complex128); the reference's
+                                     * recurrence, results held to the oracle like the chip-wide resident loop's.  cgamd_dist_loop_launches()
+                                     * reports 0 when it applies; otherwise the flag changes nothing */
+
 int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, const void *aValues,
                         const int *aPointers, const int *aCols, int nRHS, int flags, cgamd_solver **out);
 int cgamd_solver_destroy(cgamd_solver *s);

@@ -63,6 +63,14 @@ def main():
         print(f"{args.grid} rows={n}  plain solver ({name:14s})        : {lo:7.2f} us/iter (median {med:7.2f})", flush=True)
         s.close()
 
+    # the slab loop (one launch per call, vectors in registers) on the rank's matrix without the self-halo: what the rank's own work costs
+    if not args.only or args.only == "slab":
+        plan0 = dmod.build_halo_plan(indices.long(), [(0, n)], 0)
+        d = dmod.DistSolver(ctx, plan0, indptr, data, np.float64, flags=L.DIST_RESIDENT)
+        lo, med = timed(d)
+        print(f"{args.grid} rows={n}  slab loop (no halo), launches/iteration {lib.cgamd_dist_loop_launches(d.handle)}: {lo:7.2f} us/iter (median {med:7.2f})", flush=True)
+        d.close()
+
     # self-halo routing: columns < h referenced by rows >= h go through halo slots
     rows = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]).long())
     route = (indices < h) & (rows >= h)

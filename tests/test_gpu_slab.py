@@ -1,0 +1,107 @@
+"""Slab loop (csrc/slab.hip, CGAMD_DIST_RESIDENT): every iteration of an iterate() call in ONE launch with the vectors in
+registers and the matrix streamed -- the loop body of the reference (clcg.c:297-419) for systems of ~1M to ~3M rows (one rank's
+slab of the row-partitioned headline system).  Same recurrence and per-row order as the launched loops; partial sums are per
+member, so results are held to the oracle at the standard tolerance (fp64 delta_k rtol 1e-10, x 1e-9), are bitwise
+reproducible run to run, and a handle may alternate between this loop and the launched one."""
+import importlib
+
+import numpy as np
+import pytest
+
+import cg_numpy
+import cg_oracle
+from conftest import PKG_NAME
+
+pytestmark = pytest.mark.gpu
+RESIDENT = 512
+
+
+def _handle(pkg, ctx, ip, ix, da, dtype, flags):
+    import torch
+    dmod = importlib.import_module(PKG_NAME + ".dist")
+    dev = torch.device("cuda", 0)
+    n = len(ip) - 1
+    plan = dmod.build_halo_plan(torch.from_numpy(ix.astype(np.int64)).to(dev), [(0, n)], 0)
+    vals = torch.from_numpy(da.astype(dtype)).to(dev)
+    indptr = torch.from_numpy(ip.astype(np.int32)).to(dev)
+    s = dmod.DistSolver(ctx, plan, indptr, vals, dtype, flags=flags)
+    s._test_keep = (vals, indptr, plan)
+    return s
+
+
+def _tuned(pkg, **kv):
+    lib = pkg._lib.load()
+    for k, v in kv.items():
+        pkg._lib.check(lib.cgamd_tune(k.encode(), int(v)))
+
+
+@pytest.mark.parametrize("dtype,coded", [(np.float64, True), (np.float32, True), (np.complex64, True)])
+def test_slab_loop_matches_oracle(pkg, gpu, dtype, coded):
+    import torch
+    ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
+    dev = torch.device("cuda", 0)
+    if np.dtype(dtype).kind == "c":
+        N = 1000                # helmFE_var(1000): 1M rows, 7 entries per row, complex symmetric
+        ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+        b = np.tile(cg_numpy.rhsA(100, 12.0).flatten(), 100)
+    else:
+        ip, ix, da = cg_numpy.laplace3d(120, 100, 90)     # 1.08M rows: z-neighbours 12 000 rows away, other members' columns
+        b = np.linspace(1.0, 2.0, len(ip) - 1)
+    n = len(ip) - 1
+    tdt = pkg.generators.torch_dtype(dtype)
+    try:
+        if not coded:
+            _tuned(pkg, index_codes=0)
+        s = _handle(pkg, ctx, ip, ix, da, dtype, RESIDENT)
+    finally:
+        _tuned(pkg, index_codes=1)
+    assert (s.index_codes() > 0) == coded
+    assert lib.cgamd_dist_loop_launches(s.handle) == 0
+    bl = torch.from_numpy(b.astype(dtype)).to(dev)
+    outs = []
+    for split in ((20, 16), (36,)):
+        s.set_rhs(bl, None)
+        for k in split:
+            s.iterate(k)
+        outs.append((s.x(torch.empty(n, dtype=tdt, device=dev)).cpu().numpy(), s.history().copy()))
+    assert lib.cgamd_dist_loop_launches(s.handle) == 0          # no launch fell back
+    # short calls (below resident_wide_min) take the launched loop on the same handle and state
+    s.set_rhs(bl, None)
+    s.iterate(20)
+    s.iterate(5)
+    s.iterate(11)
+    mixed = (s.x(torch.empty(n, dtype=tdt, device=dev)).cpu().numpy(), s.history().copy())
+    s.close()
+    wide = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    xo, ho = cg_oracle.cg(ip, ix, da.astype(wide), b.astype(wide), n_iterations=36, mode=cg_oracle.MODE_FAST)
+    single = np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64))
+    keep = np.abs(ho[:, 0]) / np.abs(ho[0, 0]) > (1e-4 if single else 1e-8)
+    for x, h in outs + [mixed]:
+        assert np.max(np.abs(h[keep] - ho[keep, 0]) / np.abs(ho[keep, 0])) < (1e-4 if single else 1e-10)
+        assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < (1e-3 if single else 1e-9)
+    # call lengths do not change the bits (the state handed from one launch to the next is the whole state)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_slab_loop_is_reproducible_and_flag_is_inert_where_it_does_not_apply(pkg, gpu):
+    import torch
+    ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
+    dev = torch.device("cuda", 0)
+    ip, ix, da = cg_numpy.laplace3d(120, 100, 90)
+    n = len(ip) - 1
+    bl = torch.from_numpy(np.linspace(1.0, 2.0, n)).to(dev)
+    runs = []
+    for _ in range(2):
+        s = _handle(pkg, ctx, ip, ix, da, np.float64, RESIDENT)
+        s.set_rhs(bl, None)
+        s.iterate(40)
+        runs.append((s.x(torch.empty(n, dtype=torch.float64, device=dev)).cpu().numpy(), s.history().copy()))
+        s.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    # a small system (one member would do): the flag changes nothing, the launched loop runs
+    ip, ix, da = cg_numpy.laplace3d(9, 8, 7)
+    s = _handle(pkg, ctx, ip, ix, da, np.float64, RESIDENT)
+    assert lib.cgamd_dist_loop_launches(s.handle) > 0
+    s.close()
