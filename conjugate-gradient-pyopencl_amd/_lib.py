@@ -123,6 +123,7 @@ def load():
         "cgamd_p2p_mailbox_free": (ci, [vp, vp]),
         "cgamd_dist_attach_p2p": (ci, [vp, vp, vp, vp]),
         "cgamd_dist_p2p_error": (ci, [vp]),
+        "cgamd_dist_enable_resident": (ci, [vp, ll, vp, vp]),
         "cgamd_dist_index_codes": (ci, [vp]),
         "cgamd_dist_loop_launches": (ci, [vp]),
         "cgamd_dist_comm_ranks": (ci, [vp]),

@@ -103,6 +103,8 @@ struct Tuning {
                                // against the launched loops at 4 / 12 / 24 iterations for 1M / 250k / 90k rows, scripts/short_calls.py)
     int resident_claim_ms = 200;   // resident loops: how long a call waits for the GPU's resident-launch lock, and work-groups for their group to fill (CUs held by other kernels), before the
                                // launch gives up untouched and the handle goes back to the launched loops
+    int resident_lock = 1;         // 0: no per-GPU serialisation of resident launches (ranks of ONE job that share a GPU in a rehearsal must run
+                                   // their slab launches at the same time; never needed with one rank per GPU)
     int resident_test_short_grid = 0; // test hook: launch one work-group too few, so that no group can fill
     int resident_wide_rpt = 0; // rows per thread of the chip-wide loop: 0 = the smallest that fits (4, then 8), or 4 / 8
     int resident_window = 1; // ... staging the column range of a member's rows in LDS once per iteration (0 = per-non-zero gathers)
@@ -282,11 +284,20 @@ struct SlabPlan {
     size_t lds_bytes = 0, sync_bytes = 0;
 };
 bool slab_plan(int dtype, int n, int n_cus, const SpmvPlan &plan, bool coded, SlabPlan *out);
-// state in and out: x, r, d (already beta d + r), delta / beta / alpha / history / iter of the three / four-launch loops; d1: a second
-// buffer of n values; codes / dict: the one-byte column codes of the matrix (required)
+// row-partitioned run of the slab loop: the peer-to-peer mailboxes of the handle (device arrays as in P2pExchange) and, per peer and
+// buffer parity, where this rank's boundary entries land in the PEER's published-d buffer
+struct SlabComm {
+    int n_halo = 0, nranks = 1, rank = 0, n_peers = 0;
+    char *const *mailbox = nullptr;
+    const int *peer_rank = nullptr, *send_off = nullptr, *send_count = nullptr, *recv_count = nullptr, *send_index = nullptr;
+    void *const *push_dst = nullptr;                // device [2][n_peers]
+    unsigned long long *halo_epoch = nullptr, *red_seq = nullptr;
+};
+// state in and out: x, r, din = d (already beta d + r), delta / beta / alpha / history / iter of the three / four-launch loops; ds0 / ds1:
+// n + n_halo values each, where the iterations publish d; codes / dict: the one-byte column codes of the matrix (required)
 int run_cg_slab(int dtype, const SlabPlan &sp, int n, long long nnz, const void *vals, const int *ptr, const unsigned char *codes,
-                const int *dict, void *x, void *r, void *d0, void *d1, const CgScalars &sc, int it0, int K, void *sync, hipStream_t st,
-                bool *untouched = nullptr);
+                const int *dict, void *x, void *r, void *din, void *ds0, void *ds1, const SlabComm *cm, const CgScalars &sc, int it0, int K,
+                void *sync, hipStream_t st, bool *untouched = nullptr);
 
 // [rows][cols] -> [cols][rows]: RHS-major (the reference ABI) <-> row-major
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);

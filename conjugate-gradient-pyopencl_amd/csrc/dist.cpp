@@ -131,8 +131,13 @@ struct cgamd_dist {
     bool cg1 = false;
     void *s2 = nullptr, *cg1_state = nullptr, *part_cg1 = nullptr;
     // slab loop (CGAMD_DIST_RESIDENT, slab.hip): every iteration of an iterate() call in one launch, vectors in registers
-    SlabPlan slab;
-    void *slab_sync = nullptr, *d2 = nullptr;
+    SlabPlan slab, slab_plan_;         // slab: in use (ok); slab_plan_: what create found, waiting for its buffers (peer-to-peer handles)
+    void *slab_sync = nullptr, *ds_own[2] = {nullptr, nullptr};     // ds_own: plain buffers of a handle without peers
+    void *ds[2] = {nullptr, nullptr};  // where the slab loop publishes d: ds_own, or inside the rank's mailbox allocation
+    void **push_dst_dev = nullptr;     // device [2][n_peers]
+    std::vector<char *> mailbox_host;  // mapped mailbox bases (host copy of mailbox_dev)
+    std::vector<int> xch_dst_off;      // where my entries land in each peer's halo numbering
+    SlabComm slab_comm;
     int n_cus = 0;
 };
 
@@ -430,10 +435,14 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     if (!rc && (flags & CGAMD_DIST_RESIDENT) && !d->cg1) {
         if (hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) d->n_cus = 0;
         SlabPlan sp;
-        if (slab_plan(dtype, n_local, d->n_cus, d->plan, d->codes != nullptr, &sp) && d->peer.empty()) {
+        if (slab_plan(dtype, n_local, d->n_cus, d->plan, d->codes != nullptr, &sp)) {
             rc = dalloc(&d->slab_sync, sp.sync_bytes, "slab sync words");
-            if (!rc) rc = dalloc(&d->d2, (size_t)n_local * vs, "d (second buffer)");
-            if (!rc) d->slab = sp;
+            if (!rc && d->peer.empty() && nranks == 1) {     // nothing to exchange: plain buffers, usable at once
+                for (int b = 0; b < 2 && !rc; ++b) rc = dalloc(&d->ds_own[b], (size_t)n_local * vs, "published d");
+                if (!rc) { d->ds[0] = d->ds_own[0]; d->ds[1] = d->ds_own[1]; d->slab = sp; }
+            } else if (!rc && d->p2p) {
+                d->slab_plan_ = sp;              // cgamd_dist_enable_resident finds the buffers inside the mailbox allocation
+            }
         }
     }
     if (!rc && id128 && !d->p2p) {
@@ -486,7 +495,8 @@ int cgamd_dist_destroy(cgamd_dist *d) {
     if (d->codes) (void)hipFree(d->codes);
     if (d->dict) (void)hipFree(d->dict);
     void *bufs[] = {d->x, d->r, d->q, d->b, d->d_ext, d->sendbuf, d->part_dq, d->part_rr, d->red, d->sc.alpha,
-                    d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter, d->s2, d->cg1_state, d->part_cg1, d->slab_sync, d->d2};
+                    d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter, d->s2, d->cg1_state, d->part_cg1, d->slab_sync, d->ds_own[0], d->ds_own[1],
+                    d->push_dst_dev};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete d;
@@ -537,8 +547,10 @@ int cgamd_dist_iterate(cgamd_dist *d, int nIterations) {
             const int K = std::min(left, 1 << 15);
             bool untouched = false;
             if (int rc = run_cg_slab(d->dtype, d->slab, d->n_local, d->nnz, d->vals, d->ptr, d->codes, d->dict, d->x, d->r, d->d_ext,
-                                     d->d2, d->sc, d->iters, K, d->slab_sync, st, &untouched)) {
-                if (!untouched) return rc;
+                                     d->ds[0], d->ds[1], d->slab_comm.mailbox ? &d->slab_comm : nullptr, d->sc, d->iters, K, d->slab_sync, st,
+                                     &untouched)) {
+                // with peers the launched loops speak another protocol than the peers' slab launches: no silent change of loop
+                if (!untouched || d->nranks > 1 || !d->peer.empty()) return rc;
                 d->slab.ok = false;          // the chip is shared with something that does not yield: launched loop from here on
                 break;
             }
@@ -642,6 +654,7 @@ int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, 
     int rc;
     if ((rc = dalloc((void **)&d->mailbox_dev, sizeof(char *) * (size_t)d->nranks, "mailbox table"))) return rc;
     CG_HIP(hipMemcpy(d->mailbox_dev, base.data(), sizeof(char *) * (size_t)d->nranks, hipMemcpyHostToDevice));
+    d->mailbox_host = base;
     const size_t epoch_bytes = 64 + sizeof(unsigned) * (size_t)(1 + np);   // 3 epochs, then the work-group counters
     if ((rc = dalloc((void **)&d->epochs, epoch_bytes, "epochs"))) return rc;
     CG_HIP(hipMemset(d->epochs, 0, epoch_bytes));
@@ -656,6 +669,7 @@ int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, 
     }
     if ((rc = dalloc((void **)&d->plan_dev, sizeof(int) * plan.size(), "p2p plan"))) return rc;
     CG_HIP(hipMemcpy(d->plan_dev, plan.data(), sizeof(int) * plan.size(), hipMemcpyHostToDevice));
+    d->xch_dst_off.assign(dst_offset, dst_offset + np);
     P2pExchange &x = d->xch;
     x.mailbox = d->mailbox_dev; x.rank = d->rank; x.n_peers = np; x.n_local = d->n_local;
     x.peer_rank = d->plan_dev; x.send_off = d->plan_dev + np; x.send_count = d->plan_dev + 2 * np;
@@ -667,6 +681,51 @@ int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, 
     for (int p = 0; p < np; ++p) x.max_count = std::max(x.max_count, std::max(d->send_count[(size_t)p], d->recv_count[(size_t)p]));
     if (d->direct && spmv_p2p_grid(d->plan) < np * p2p_push_chunks(x)) d->direct = false;   // too few work-groups to carry the push
     d->p2p_attached = true;
+    return CGAMD_OK;
+}
+
+// Slab loop (CGAMD_DIST_RESIDENT) on a peer-to-peer handle with peers: d is published in two buffers of n_local + n_halo values that
+// live INSIDE every rank's mailbox allocation, behind the halo area, so that the peers can write their boundary entries into the
+// tail directly: mailbox = [16 KiB header | n_halo values | ds0 | ds1], each part rounded up to 256 bytes.  mailbox_values: the
+// `halo_values` the mailbox was allocated with; rank_n_local / rank_n_halo [nranks]: every rank's sizes (a peer's buffers start
+// behind ITS halo area).  Returns CGAMD_OK whether or not the loop applies; cgamd_dist_loop_launches() == 0 tells.
+int cgamd_dist_enable_resident(cgamd_dist *d, long long mailbox_values, const int *rank_n_local, const int *rank_n_halo) {
+    if (!d || !rank_n_local || !rank_n_halo) return fail(CGAMD_ERR_INVALID, "dist_enable_resident: null argument");
+    TuneScope ts(&d->tune);
+    if (!d->p2p || !d->p2p_attached) return fail(CGAMD_ERR_STATE, "dist_enable_resident: attach the peer-to-peer mailboxes first");
+    if (!d->slab_plan_.ok) return CGAMD_OK;       // nothing to enable (no plan, or the plain buffers of a lone rank are in use)
+    CG_HIP(hipSetDevice(d->ctx->device));
+    const size_t vs = dtype_size(d->dtype);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    auto ds_off = [&](int r, int which) {       // byte offset of rank r's ds0 / ds1 inside its mailbox
+        const size_t halo = up((size_t)rank_n_halo[r] * vs), body = up(((size_t)rank_n_local[r] + rank_n_halo[r]) * vs);
+        return kMailboxHeader + halo + (size_t)which * body;
+    };
+    if (rank_n_local[d->rank] != d->n_local || rank_n_halo[d->rank] != d->n_halo)
+        return fail(CGAMD_ERR_INVALID, "dist_enable_resident: sizes of this rank do not match the handle");
+    if (ds_off(d->rank, 1) + up(((size_t)d->n_local + d->n_halo) * vs) > kMailboxHeader + (size_t)mailbox_values * vs)
+        return fail(CGAMD_ERR_INVALID, "dist_enable_resident: the mailbox allocation is too small for the two published-d buffers");
+    const int np = (int)d->peer.size();
+    std::vector<void *> dst((size_t)2 * np);
+    for (int which = 0; which < 2; ++which)
+        for (int p = 0; p < np; ++p) {
+            const int q = d->peer[(size_t)p];
+            // my entries land at dst_offset[p] of the peer's halo numbering: tail of its buffer
+            dst[(size_t)which * np + p] = d->mailbox_host[(size_t)q] + ds_off(q, which) + ((size_t)rank_n_local[q] + d->xch_dst_off[(size_t)p]) * vs;
+        }
+    int rc;
+    if (!d->push_dst_dev && (rc = dalloc((void **)&d->push_dst_dev, sizeof(void *) * dst.size(), "slab push table"))) return rc;
+    CG_HIP(hipMemcpy(d->push_dst_dev, dst.data(), sizeof(void *) * dst.size(), hipMemcpyHostToDevice));
+    d->ds[0] = d->my_mailbox + ds_off(d->rank, 0);
+    d->ds[1] = d->my_mailbox + ds_off(d->rank, 1);
+    SlabComm &c = d->slab_comm;
+    c.n_halo = d->n_halo; c.nranks = d->nranks; c.rank = d->rank; c.n_peers = np;
+    c.mailbox = d->mailbox_dev;
+    c.peer_rank = d->xch.peer_rank; c.send_off = d->xch.send_off; c.send_count = d->xch.send_count; c.recv_count = d->xch.recv_count;
+    c.send_index = d->send_index;
+    c.push_dst = d->push_dst_dev;
+    c.halo_epoch = d->epochs; c.red_seq = d->epochs + 3;
+    d->slab = d->slab_plan_;
     return CGAMD_OK;
 }
 

@@ -865,6 +865,7 @@ __global__ __launch_bounds__(kResThreads) void resident_wide_scan_kernel(int n, 
 static std::timed_mutex g_resident_mutex[64];
 ResidentLock::ResidentLock(int device, int wait_ms) {
     using clock = std::chrono::steady_clock;
+    if (tune().resident_lock == 0) { held_ = true; return; }
     const auto deadline = clock::now() + std::chrono::milliseconds(wait_ms > 0 ? wait_ms : 1);
     std::timed_mutex &mx = g_resident_mutex[(unsigned)device & 63u];
     if (!mx.try_lock_until(deadline)) return;

@@ -32,6 +32,7 @@
 #include "cgamd_internal.h"
 #include "device_mem.h"
 #include "launch_util.h"
+#include "p2p_device.h"
 #include "resident_device.h"
 #include "spmv_device.h"
 
@@ -52,7 +53,18 @@ template <typename T> struct SlabArgs {
     const int *ptr;
     const unsigned char *codes;     // one byte per non-zero: aCols[j] = row + dict[codes[j]] (index_codes.hip); padded by 64 bytes
     const int *dict;
-    T *x, *r, *d0, *d1;             // d0: the caller's d (already beta d + r: state of the three / four-launch loops), d1: the second buffer
+    T *x, *r;
+    T *din;                         // the caller's d (already beta d + r: state of the three / four-launch loops); rewritten at the end
+    T *ds0, *ds1;                   // [n + n_halo] each: where iteration k's d is published (k & 1); with peers: uncached, IPC-shared, the peers
+                                    // write their boundary entries into the tail [n, n + n_halo)
+    // row-partitioned run (nranks > 1 or a rank that is its own peer): peer-to-peer mailboxes (p2p_device.h)
+    int n_halo, nranks, rank, n_peers;
+    char *const *mailbox;           // [nranks] mapped mailbox bases
+    const int *peer_rank, *send_off, *send_count, *recv_count;     // [n_peers]
+    const int *send_index;          // concatenated local rows to send, ascending per peer
+    T *const *push_dst;             // [2][n_peers]: where my entries for peer p land in ITS ds0 / ds1 tail
+    unsigned *pushcnt, *contrib;    // [n_peers] members that have pushed (running) / that push at all
+    u64 *halo_epoch, *red_seq;      // exchange epoch of the handle (advanced by K at the end), launch sequence of the scalar slots
     T *alpha, *beta, *delta, *history;
     int *iter;
     unsigned *hdr;
@@ -171,6 +183,48 @@ CG_DEV T slab_row(const T *vs, const unsigned char *scode, const int *sdict, int
     return sum;
 }
 
+// The sum of `local` over all ranks in rank order (bitwise identical everywhere), for a whole wave: lane s publishes this rank's
+// value in rank s's mailbox and waits for rank s's value in its own (p2p_device.h: scalar slots of the single-reduction region,
+// parity = tag & 1, the epoch word carries the launch sequence and the tag).  Every polling work-group of a rank publishes the
+// same bits, so it does not matter whose store a peer sees.
+template <typename T, typename A> CG_DEV A slab_rank_sum(const SlabArgs<T> &a, u64 seq, unsigned tag, A local, int *fail) {
+    if (a.nranks <= 1 && a.n_peers == 0) return local;
+    // granule form (resident_device.h): each 8-byte word carries 32 payload bits under a 32-bit tag, so a consumer has data and
+    // validity in ONE round trip and the producer needs no store ordering (payload + epoch word cost three dependent trips)
+    const int lane = threadIdx.x & (kWave - 1);
+    const u64 tg = (u64)((unsigned)(seq << 21) | tag) << 32;
+    const long long slot_off = kMbCg1 + ((long long)(tag & 1u) * 64) * 64;
+    const double2 v = to_acc2(local);
+    double vx = 0., vy = 0.;
+    if (lane < a.nranks) {
+        u64 *slot = reinterpret_cast<u64 *>(a.mailbox[lane] + slot_off + (long long)a.rank * 64);
+        const u64 bx = (u64)__double_as_longlong(v.x), by = (u64)__double_as_longlong(v.y);
+        st_sys(slot, tg | (bx & 0xffffffffull));
+        st_sys(slot + 1, tg | (bx >> 32));
+        st_sys(slot + 2, tg | (by & 0xffffffffull));
+        st_sys(slot + 3, tg | (by >> 32));
+        const u64 *in = reinterpret_cast<const u64 *>(a.mailbox[a.rank] + slot_off + (long long)lane * 64);
+        const long long t0 = wall_clock64();
+        for (unsigned spins = 0;; ++spins) {
+            const u64 w0 = ld_sys(in), w1 = ld_sys(in + 1), w2 = ld_sys(in + 2), w3 = ld_sys(in + 3);
+            if ((w0 >> 32) == (tg >> 32) && (w1 >> 32) == (tg >> 32) && (w2 >> 32) == (tg >> 32) && (w3 >> 32) == (tg >> 32)) {
+                vx = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+                vy = __longlong_as_double((long long)((w2 & 0xffffffffull) | (w3 << 32)));
+                break;
+            }
+            if ((spins & 63) == 63 && (wall_clock64() - t0 > kResSpinTicks || ld_word(a.hdr + kHdrError) != 0)) {
+                st_sys(reinterpret_cast<u64 *>(a.mailbox[a.rank] + kMbError), 2ULL);
+                atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrSweep);
+                *fail = 1;
+                break;
+            }
+        }
+    }
+    double2 tot = make_double2(0., 0.);
+    for (int r = 0; r < a.nranks; ++r) { tot.x += __shfl(vx, r, kWave); tot.y += __shfl(vy, r, kWave); }
+    return from_acc2<A>(tot);
+}
+
 template <typename T, int RPT, int UNROLL>
 __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     using A = typename VT<T>::acc;
@@ -183,6 +237,10 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     __shared__ int sdict[256];
     __shared__ unsigned depmask[8];
     __shared__ int sbound[2 * RPT + 2];     // per step: first entry (4-aligned) and end of its slice
+    __shared__ int sendlo[64], sendhi[64];  // my part of every peer's send list
+    __shared__ unsigned scontrib[64];
+    __shared__ u64 sepoch[2];               // [0] exchange epoch at the start of the launch, [1] launch sequence of the scalar slots
+    __shared__ int has_halo;
     const int t = threadIdx.x;
 
     if (t == 0) {
@@ -191,6 +249,11 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     }
     if (t < 8) depmask[t] = 0u;
     if (t < 256) sdict[t] = a.dict[t];
+    if (t == 0) {
+        has_halo = 0;
+        sepoch[0] = a.halo_epoch ? *a.halo_epoch : 0;
+        sepoch[1] = a.red_seq ? *a.red_seq + 1 : 1;
+    }
     __syncthreads();
     const int m = __builtin_amdgcn_readfirstlane(sh.ctl[1]);
     if (m >= a.G) return;
@@ -227,14 +290,31 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
             info = ((unsigned)(ps - c0) << 5) | (unsigned)(pe - ps);
             for (int j = ps; j < pe; ++j) {
                 const int c = row + sdict[scode[j - c0]];
-                if ((unsigned)(c - R0) >= (unsigned)a.rows_m) {
-                    const int owner = c / a.rows_m;
-                    atomicOr(&depmask[owner >> 5], 1u << (owner & 31));
+                if ((unsigned)(c - R0) >= (unsigned)(R1 - R0)) {       // (the last member's R0 + rows_m may lie beyond n: halo columns start at n)
+                    if (c >= a.n) {
+                        has_halo = 1;                        // a column another RANK owns: it arrives in the tail of ds0 / ds1
+                    } else {
+                        const int owner = c / a.rows_m;
+                        atomicOr(&depmask[owner >> 5], 1u << (owner & 31));
+                    }
                 }
             }
         }
         rowinfo[h] = info;
     }
+    if (t < a.n_peers) {                     // the entries of peer t's send list that are rows of mine (the list is ascending)
+        const int *idx = a.send_index + a.send_off[t];
+        const int cnt = a.send_count[t];
+        int lo = 0, hi = cnt;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (idx[mid] < R0) lo = mid + 1; else hi = mid; }
+        const int first = lo;
+        hi = cnt;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (idx[mid] < R1) lo = mid + 1; else hi = mid; }
+        sendlo[t] = first;
+        sendhi[t] = lo;
+        if (lo > first) atomicAdd(a.contrib + t, 1u);
+    }
+    drain_stores();                          // my count is performed before thread 0 announces this member at the start line
     __syncthreads();
     // ---- start line: nobody touches a vector before every member runs (a work-group queued behind other kernels).  One word
     // holds the count of members that are ready (low 16 bits) and an ABORT bit that can only be set while the count is short:
@@ -257,8 +337,10 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
         }
         if (!sh.fail && leader) atomicAdd(a.hdr + kHdrNextRhs, 1u);       // past the start line: vectors are in use from here on
     }
+    if (t < a.n_peers) scontrib[t] = ld_word(a.contrib + t);       // every member is past its set-up: the counts are final
     __syncthreads();
     if (sh.fail) return;
+    const u64 E0 = sepoch[0], seq = sepoch[1];
 
     // x, r, q of my rows in registers; d of my rows in LDS (dl) -- the row walks read it there anyway
     T px[RPT], pr[RPT], pq[RPT];
@@ -269,7 +351,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
         px[h] = lv ? a.x[row] : vzero<T>();
         pr[h] = lv ? a.r[row] : vzero<T>();
         pq[h] = vzero<T>();
-        if (h < a.nsteps) dl[h * kSlabStep + t] = lv ? a.d0[row] : vzero<T>();
+        if (h < a.nsteps) dl[h * kSlabStep + t] = lv ? a.din[row] : vzero<T>();
     }
     u64 *g_dq = a.gran, *g_rr = a.gran + (size_t)a.G * W;
     T dlt = a.delta[0];
@@ -279,7 +361,8 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     // load (~2.3 us measured) needs for the chip's streaming rate; one (the first version) ran the product at 3 TB/s.
     SliceRegs<T> slA, slB;          // slA: slices of odd global steps, slB: of even ones (nsteps is even: the parity of a step is that of h)
     const __amdgpu_buffer_rsrc_t rv = slab_rsrc(a.vals, (unsigned)((a.nnz * (long long)sizeof(T) + 15) & ~15LL));
-    const __amdgpu_buffer_rsrc_t rd0 = slab_rsrc(a.d0, (unsigned)a.n * (unsigned)sizeof(T)), rd1 = slab_rsrc(a.d1, (unsigned)a.n * (unsigned)sizeof(T));
+    const unsigned dbytes = (unsigned)(a.n + a.n_halo) * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rd0 = slab_rsrc(a.ds0, dbytes), rd1 = slab_rsrc(a.ds1, dbytes);
     slab_stage_load<T>(rv, sbound[0], sbound[1], slB);
     slab_stage_store<T>(slB, sval);
     slab_stage_load<T>(rv, sbound[2], sbound[3], slA);                                     // step 1
@@ -290,12 +373,13 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     for (int k = 0; k < a.K; ++k) {
         const int it = a.it0 + k;
         SLAB_STAMP(0)
-        T *dpub = (k & 1) ? a.d1 : a.d0;             // where iteration k's d lives in memory (k = 0: the caller's, complete before the launch)
+        T *dpub = (k & 1) ? a.ds1 : a.ds0;           // where iteration k's d is published
+        T bt = vzero<T>();
         if (k > 0) {
-            T bt, dnT;
+            T dnT;
             if (!xcd_scalars<A, T>(a.G, sh, a.hdr, bt, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, 2u * k, v); },
                                    [&](A tot, T &b, T &dn) {
-                                       dn = from_acc<T>(tot);
+                                       dn = from_acc<T>(slab_rank_sum<T, A>(a, seq, 2u * k, tot, &sh.fail));
                                        b = from_acc<T>(acc_div(to_acc(dn), to_acc(dlt)));
                                    }, xlead, xpublish, xs_rr, 2u * k)) return;
             dlt = dnT;
@@ -304,36 +388,59 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
                 a.delta[0] = dnT;
                 if (it < a.history_cap) a.history[it] = dnT;
             }
-            SLAB_STAMP(1)
-            // ---- d = beta d + r: to memory for the members that gather it, and into my LDS copy
-#pragma unroll
-            for (int h = 0; h < RPT; ++h) {
-                const int li = h * kSlabStep + t;
-                if (h < a.nsteps && R0 + li < R1) {
-                    const T dn = vaypx(bt, dl[li], pr[h]);
-                    dl[li] = dn;
-                    st_coh(dpub + (R0 + li), dn);
-                }
-            }
-            drain_stores();                          // (also lands the value slice in flight: it is stored to LDS next anyway)
-            __syncthreads();
-            if (t == 0) st_word<false>(a.dflag + m, (u64)k);
-            SLAB_STAMP(2)
-            if (t < 256) {                           // the members whose d I gather have published iteration k
-                const bool dep = t < a.G && ((depmask[t >> 5] >> (t & 31)) & 1u) != 0;
-                const long long t0 = wall_clock64();
-                for (unsigned spins = 0;; ++spins) {
-                    const bool ok = !dep || ld_word(a.dflag + t) >= (u64)k;
-                    if (__all(ok)) break;
-                    if ((spins & 63) == 63 && (wall_clock64() - t0 > kResSpinTicks || ld_word(a.hdr + kHdrError) != 0)) {
-                        if ((t & (kWave - 1)) == 0) { atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrSweep); sh.fail = 1; }
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            if (sh.fail) return;
         }
+        SLAB_STAMP(1)
+        // ---- d = beta d + r (k = 0: the caller's d as it is): to memory for the members that gather it, and into my LDS copy
+#pragma unroll
+        for (int h = 0; h < RPT; ++h) {
+            const int li = h * kSlabStep + t;
+            if (h < a.nsteps && R0 + li < R1) {
+                const T dn = k > 0 ? vaypx(bt, dl[li], pr[h]) : dl[li];
+                dl[li] = dn;
+                st_coh(dpub + (R0 + li), dn);
+            }
+        }
+        if (a.n_peers > 0) {                         // my rows on the peers' send lists: straight into their buffer of this parity
+            __syncthreads();
+            for (int p = 0; p < a.n_peers; ++p) {
+                T *dst = a.push_dst[(k & 1) * a.n_peers + p];
+                const int *idx = a.send_index + a.send_off[p];
+                for (int i = sendlo[p] + t; i < sendhi[p]; i += kResThreads) st_sys_val(dst + i, dl[idx[i] - R0]);
+            }
+        }
+        drain_stores();                              // (also lands the value slices in flight: they are stored to LDS next anyway)
+        __syncthreads();
+        if (t == 0) st_word<false>(a.dflag + m, (u64)k + 1);
+        if (t < a.n_peers && sendhi[t] > sendlo[t]) {   // the last member to have pushed its part raises my flag in the peer's mailbox
+            const unsigned old = atomicAdd(a.pushcnt + t, 1u);
+            if ((old + 1u) % scontrib[t] == 0u)
+                st_sys(reinterpret_cast<u64 *>(a.mailbox[a.peer_rank[t]] + kMbHaloFlags) + a.rank, E0 + (u64)k + 1);
+        }
+        SLAB_STAMP(2)
+        if (t < 256) {                               // the members whose d I gather have published iteration k
+            const bool dep = t < a.G && ((depmask[t >> 5] >> (t & 31)) & 1u) != 0;
+            const long long t0 = wall_clock64();
+            for (unsigned spins = 0;; ++spins) {
+                const bool ok = !dep || ld_word(a.dflag + t) >= (u64)k + 1;
+                if (__all(ok)) break;
+                if ((spins & 63) == 63 && (wall_clock64() - t0 > kResSpinTicks || ld_word(a.hdr + kHdrError) != 0)) {
+                    if ((t & (kWave - 1)) == 0) { atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrSweep); sh.fail = 1; }
+                    break;
+                }
+            }
+        } else if (t < 256 + kWave && has_halo) {    // ... and the peers whose entries my rows reference
+            const int p = t - 256;
+            if (p < a.n_peers && a.recv_count[p] > 0) {
+                const char *mb = a.mailbox[a.rank];
+                if (!spin_until(reinterpret_cast<const u64 *>(mb + kMbHaloFlags) + a.peer_rank[p], E0 + (u64)k + 1, mb)) {
+                    st_sys(reinterpret_cast<u64 *>(const_cast<char *>(mb) + kMbError), 1ULL);
+                    atomicCAS(a.hdr + kHdrError, 0u, (unsigned)kErrSweep);
+                    sh.fail = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (sh.fail) return;
         SLAB_STAMP(3)
         // ---- q = A d, 512 rows per step.  Entering step h: value slice h is in LDS buffer h & 1, slice h + 1 in flight (registers), the
         // far entries of step h are in flight in `far[h & 1]`.  Program order per step keeps every load one step ahead of its use
@@ -347,7 +454,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
         FarRegs<T, UNROLL> fA, fB;       // far entries of even / odd steps
         {
             const unsigned i0 = rowinfo[0];
-            slab_far_issue<T, UNROLL>(scode, sdict, (int)(i0 >> 5), (int)(i0 >> 5) + (int)(i0 & 31u), R0 + t, R0, a.rows_m, rd, true, fA);
+            slab_far_issue<T, UNROLL>(scode, sdict, (int)(i0 >> 5), (int)(i0 >> 5) + (int)(i0 & 31u), R0 + t, R0, R1 - R0, rd, true, fA);
         }
         auto one_step = [&](int h, int bcur, SliceRegs<T> &sl, FarRegs<T, UNROLL> &fcur, FarRegs<T, UNROLL> &fnext) {
             unsigned info = 0, info2 = 0;
@@ -358,12 +465,12 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
             }
             const int s = (int)(info >> 5), e = s + (int)(info & 31u);
             const int s2 = (int)(info2 >> 5), e2 = s2 + (int)(info2 & 31u);
-            slab_far_issue<T, UNROLL>(scode, sdict, s2, e2, R0 + (h + 1) * kSlabStep + t, R0, a.rows_m, rd, h + 1 < a.nsteps, fnext);
+            slab_far_issue<T, UNROLL>(scode, sdict, s2, e2, R0 + (h + 1) * kSlabStep + t, R0, R1 - R0, rd, h + 1 < a.nsteps, fnext);
             slab_stage_store<T>(sl, sval + (size_t)(bcur ^ 1) * a.vcap);
             const int j3 = (h + 3) % a.nsteps;           // (past the last iteration: a redundant load, never stored)
             slab_stage_load<T>(rv, sbound[2 * j3], sbound[2 * j3 + 1], sl);
             const T qv = slab_row<T, UNROLL>(sval + (size_t)bcur * a.vcap + (e > s ? (c0 + s) - sbound[2 * h] : 0), scode, sdict, s, e,
-                                             R0 + h * kSlabStep + t, R0, a.rows_m, dl, fcur);
+                                             R0 + h * kSlabStep + t, R0, R1 - R0, dl, fcur);
 #pragma unroll
             for (int i = 0; i < RPT; ++i) pq[i] = vsel(h == i, qv, pq[i]);
             __syncthreads();                         // slice h is done with; slice h + 1 is complete in the other buffer
@@ -385,7 +492,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
         T al, al_unused;
         if (!xcd_scalars<A, T>(a.G, sh, a.hdr, al, al_unused, [&](int i, A &v) { return get_granule(g_dq + (size_t)i * W, 2u * k + 1, v); },
                                [&](A dq, T &o, T &u2) {
-                                   const T dqT = from_acc<T>(dq);
+                                   const T dqT = from_acc<T>(slab_rank_sum<T, A>(a, seq, 2u * k + 1, dq, &sh.fail));
                                    o = from_acc<T>(acc_div(to_acc(dlt), to_acc(dqT)));
                                    u2 = o;
                                }, xlead, xpublish, xs_dq, 2u * k + 1)) return;
@@ -409,7 +516,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
         T bt, dnT;
         if (!xcd_scalars<A, T>(a.G, sh, a.hdr, bt, dnT, [&](int i, A &v) { return get_granule(g_rr + (size_t)i * W, 2u * a.K, v); },
                                [&](A tot, T &b, T &dn) {
-                                   dn = from_acc<T>(tot);
+                                   dn = from_acc<T>(slab_rank_sum<T, A>(a, seq, 2u * a.K, tot, &sh.fail));
                                    b = from_acc<T>(acc_div(to_acc(dn), to_acc(dlt)));
                                }, xlead, xpublish, xs_rr, 2u * a.K)) return;
 #pragma unroll
@@ -418,7 +525,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
             if (h < a.nsteps && row < R1) {
                 a.x[row] = px[h];
                 a.r[row] = pr[h];
-                a.d0[row] = vaypx(bt, dl[h * kSlabStep + t], pr[h]);
+                a.din[row] = vaypx(bt, dl[h * kSlabStep + t], pr[h]);
             }
         }
         if (leader && t == 0) {
@@ -427,6 +534,8 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
             a.delta[0] = dnT;
             if (it < a.history_cap) a.history[it] = dnT;
             *a.iter = it;
+            if (a.halo_epoch) *a.halo_epoch = E0 + (u64)a.K;     // K exchanges happened
+            if (a.red_seq) *a.red_seq = seq;
             atomicAdd(a.hdr + kHdrSolved, 1u);
         }
     }
@@ -469,14 +578,15 @@ bool slab_plan(int dtype, int n, int n_cus, const SpmvPlan &plan, bool coded, Sl
     out->nsteps = (int)(rows_m / kSlabStep);
     out->unroll = plan.max_row <= 5 ? 5 : plan.max_row <= 7 ? 7 : 8;
     constexpr int W4 = 4;       // granule words per partial (complex: 4, real: 2): sized for the larger
-    out->sync_bytes = (size_t)kHdrWords * 4 + (size_t)2 * G * W4 * 8 + 16 * 16 * 8 + 8 * 4 + 16 + (size_t)G * 8 + 256;
+    out->sync_bytes = (size_t)kHdrWords * 4 + (size_t)2 * G * W4 * 8 + 16 * 16 * 8 + 8 * 4 + 16 + (size_t)G * 8 + 2 * 64 * 4 + 256;
     return true;
 }
 
 static long long *g_slab_prof = nullptr;     // diagnostics only (CGAMD_RESIDENT_PROF=<member>; single device, single thread)
 template <typename T>
 static int slab_impl(const SlabPlan &sp, int n, long long nnz, const void *vals, const int *ptr, const unsigned char *codes, const int *dict,
-                     void *x, void *r, void *d0, void *d1, const CgScalars &sc, int it0, int K, void *sync, hipStream_t st) {
+                     void *x, void *r, void *din, void *ds0, void *ds1, const SlabComm *cm, const CgScalars &sc, int it0, int K, void *sync,
+                     hipStream_t st) {
     using A = typename VT<T>::acc;
     SlabArgs<T> a;
     a.n = n; a.G = sp.G; a.rows_m = sp.rows_m; a.nsteps = sp.nsteps; a.it0 = it0; a.K = K; a.history_cap = sc.history_cap;
@@ -484,8 +594,18 @@ static int slab_impl(const SlabPlan &sp, int n, long long nnz, const void *vals,
     a.nnz = nnz;
     a.claim_ticks = (long long)std::max(1, tune().resident_claim_ms) * 100000;
     a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.codes = codes; a.dict = dict;
-    a.x = static_cast<T *>(x); a.r = static_cast<T *>(r); a.d0 = static_cast<T *>(d0); a.d1 = static_cast<T *>(d1);
+    a.x = static_cast<T *>(x); a.r = static_cast<T *>(r); a.din = static_cast<T *>(din); a.ds0 = static_cast<T *>(ds0); a.ds1 = static_cast<T *>(ds1);
     a.alpha = (T *)sc.alpha; a.beta = (T *)sc.beta; a.delta = (T *)sc.delta; a.history = (T *)sc.history; a.iter = sc.iter;
+    a.n_halo = 0; a.nranks = 1; a.rank = 0; a.n_peers = 0;
+    a.mailbox = nullptr; a.peer_rank = a.send_off = a.send_count = a.recv_count = a.send_index = nullptr;
+    a.push_dst = nullptr; a.halo_epoch = nullptr; a.red_seq = nullptr;
+    if (cm) {
+        a.n_halo = cm->n_halo; a.nranks = cm->nranks; a.rank = cm->rank; a.n_peers = cm->n_peers;
+        a.mailbox = cm->mailbox; a.peer_rank = cm->peer_rank; a.send_off = cm->send_off; a.send_count = cm->send_count;
+        a.recv_count = cm->recv_count; a.send_index = cm->send_index;
+        a.push_dst = reinterpret_cast<T *const *>(cm->push_dst);
+        a.halo_epoch = reinterpret_cast<u64 *>(cm->halo_epoch); a.red_seq = reinterpret_cast<u64 *>(cm->red_seq);
+    }
     char *base = static_cast<char *>(sync);
     a.hdr = reinterpret_cast<unsigned *>(base);
     a.gran = reinterpret_cast<u64 *>(base + kHdrWords * 4);
@@ -493,6 +613,8 @@ static int slab_impl(const SlabPlan &sp, int n, long long nnz, const void *vals,
     a.xcnt = reinterpret_cast<unsigned *>(a.xres + 16 * 16);
     a.marks = a.xcnt + 8;
     a.dflag = reinterpret_cast<u64 *>(a.marks + 4);
+    a.pushcnt = reinterpret_cast<unsigned *>(a.dflag + sp.G);
+    a.contrib = a.pushcnt + 64;
     CG_HIP(hipMemsetAsync(sync, 0, sp.sync_bytes, st));
     if (getenv("CGAMD_RESIDENT_PROF") && !g_slab_prof) CG_HIP(hipMalloc(&g_slab_prof, 64));
     a.prof = g_slab_prof;
@@ -510,10 +632,11 @@ static int slab_impl(const SlabPlan &sp, int n, long long nnz, const void *vals,
 }
 
 // K iterations (it0 + 1 ... it0 + K) in one launch; state in and out is the three / four-launch loops' (x, r, d already
-// beta d + r, delta / beta / alpha / history / iter); their r.r partials are NOT maintained.  Synchronises `st`.
+// beta d + r in `din`, delta / beta / alpha / history / iter); their r.r partials are NOT maintained.  ds0 / ds1: n + n_halo values each
+// (with peers: inside the rank's IPC-shared mailbox allocation).  Synchronises `st`.
 int run_cg_slab(int dtype, const SlabPlan &sp, int n, long long nnz, const void *vals, const int *ptr, const unsigned char *codes,
-                const int *dict, void *x, void *r, void *d0, void *d1, const CgScalars &sc, int it0, int K, void *sync, hipStream_t st,
-                bool *untouched) {
+                const int *dict, void *x, void *r, void *din, void *ds0, void *ds1, const SlabComm *cm, const CgScalars &sc, int it0, int K,
+                void *sync, hipStream_t st, bool *untouched) {
     if (!codes || !dict) return fail(CGAMD_ERR_STATE, "slab loop: needs the one-byte column codes");
     if (K < 1 || K >= (1 << 20)) return fail(CGAMD_ERR_INVALID, "slab loop: iteration count per launch out of range");
     if (untouched) *untouched = false;
@@ -526,9 +649,9 @@ int run_cg_slab(int dtype, const SlabPlan &sp, int n, long long nnz, const void 
     }
     int rc;
     switch (dtype) {
-    case 0: rc = slab_impl<float>(sp, n, nnz, vals, ptr, codes, dict, x, r, d0, d1, sc, it0, K, sync, st); break;
-    case 1: rc = slab_impl<double>(sp, n, nnz, vals, ptr, codes, dict, x, r, d0, d1, sc, it0, K, sync, st); break;
-    case 2: rc = slab_impl<float2>(sp, n, nnz, vals, ptr, codes, dict, x, r, d0, d1, sc, it0, K, sync, st); break;
+    case 0: rc = slab_impl<float>(sp, n, nnz, vals, ptr, codes, dict, x, r, din, ds0, ds1, cm, sc, it0, K, sync, st); break;
+    case 1: rc = slab_impl<double>(sp, n, nnz, vals, ptr, codes, dict, x, r, din, ds0, ds1, cm, sc, it0, K, sync, st); break;
+    case 2: rc = slab_impl<float2>(sp, n, nnz, vals, ptr, codes, dict, x, r, din, ds0, ds1, cm, sc, it0, K, sync, st); break;
     default: return fail(CGAMD_ERR_INVALID, "slab loop: bad dtype");
     }
     if (rc) return rc;

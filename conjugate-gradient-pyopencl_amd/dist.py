@@ -274,6 +274,7 @@ class DistSolver:
             create_err = e
         self.handle = h if create_err is None else None
         self.iterations = 0
+        self._resident = bool(flags & _lib.DIST_RESIDENT)
         if comm == "p2p":
             self._attach_p2p(group, create_err)
 
@@ -294,7 +295,10 @@ class DistSolver:
             if err:
                 raise err
             mb = ctypes.c_void_p()
-            check(self._lib.cgamd_p2p_mailbox_alloc(self.ctx.handle, plan.n_halo, _lib.DTYPE_CODE[self.dtype], ctypes.byref(mb), ptr(handle)))
+            # CGAMD_DIST_RESIDENT: the slab loop's two published-d buffers (n_local + n_halo values each) live behind the halo area of
+            # the same IPC allocation, so that the peers can write into their tails (include/cgamd.h: cgamd_dist_enable_resident)
+            mb_values = plan.n_halo + (2 * (plan.n_local + plan.n_halo) + 256 if self._resident and (plan.peers or plan.world > 1) else 0)
+            check(self._lib.cgamd_p2p_mailbox_alloc(self.ctx.handle, mb_values, _lib.DTYPE_CODE[self.dtype], ctypes.byref(mb), ptr(handle)))
             self.mailbox = mb
         except Exception as e:      # noqa: BLE001 -- reported collectively below
             err = e
@@ -302,7 +306,7 @@ class DistSolver:
         for peer, cnt in zip(plan.peers, plan.recv_counts):      # where each peer's entries land in MY halo area
             recv_off[int(peer)] = off
             off += int(cnt)
-        mine = (None if err else handle.tobytes(), recv_off)
+        mine = (None if err else handle.tobytes(), recv_off, int(plan.n_local), int(plan.n_halo))
         if plan.world > 1:
             everyone = [None] * plan.world
             dist.all_gather_object(everyone, mine, group=group)
@@ -316,6 +320,10 @@ class DistSolver:
             handles = np.frombuffer(b"".join(e[0] for e in everyone), dtype=np.uint8).copy()
             dst = np.asarray([everyone[int(p)][1][plan.rank] for p in plan.peers], dtype=np.int32)
             check(self._lib.cgamd_dist_attach_p2p(self.handle, self.mailbox, ptr(handles), ptr(dst) if len(dst) else None))
+            if self._resident and (plan.peers or plan.world > 1):
+                nl = np.asarray([e[2] for e in everyone], dtype=np.int32)
+                nh = np.asarray([e[3] for e in everyone], dtype=np.int32)
+                check(self._lib.cgamd_dist_enable_resident(self.handle, int(mb_values), ptr(nl), ptr(nh)))
         except Exception as e:      # noqa: BLE001
             err = e
         if plan.world > 1:          # doubles as the barrier "every mailbox is mapped before anyone pushes"

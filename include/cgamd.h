@@ -262,6 +262,12 @@ int cgamd_p2p_mailbox_alloc(cgamd_ctx *ctx, long long halo_values, int dtype, vo
 int cgamd_p2p_mailbox_free(cgamd_ctx *ctx, void *mailbox);
 int cgamd_dist_attach_p2p(cgamd_dist *d, void *my_mailbox, const void *handles, const int *dst_offset);
 int cgamd_dist_p2p_error(cgamd_dist *d);
+/* CGAMD_DIST_RESIDENT on a peer-to-peer handle that has peers: the slab loop publishes d in two buffers of n_local + n_halo values
+ * inside every rank's mailbox allocation, behind the halo area (mailbox = 16 KiB header | n_halo values | ds0 | ds1, each part
+ * rounded up to 256 bytes), so the peers write their boundary entries into the tail directly.  Allocate the mailbox with
+ * halo_values >= n_halo + 2 (n_local + n_halo) + 96 (cgamd_p2p_mailbox_alloc), attach, then call this with that halo_values and every
+ * rank's n_local / n_halo (all-gathered by the host).  OK whether or not the loop applies; cgamd_dist_loop_launches() == 0 tells. */
+int cgamd_dist_enable_resident(cgamd_dist *d, long long mailbox_values, const int *rank_n_local, const int *rank_n_halo);
 /* as cgamd_solver_index_codes, for this rank's local matrix (the halo columns of a slab partition sit at constant offsets) */
 int cgamd_dist_index_codes(cgamd_dist *d);
 /* stream operations per iteration of the loop this handle runs (kernel launches, plus RCCL calls with that backend) */

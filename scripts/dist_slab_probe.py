@@ -79,7 +79,8 @@ def main():
                          torch.arange(h, dtype=torch.int32, device=dev))
     ST = L.DIST_P2P_STAGED
     SR = L.DIST_SINGLE_REDUCTION
-    modes = [("p2p2 single-reduction", "p2p", SR), ("p2p2 single-red.+graph", "p2p", SR | L.DIST_GRAPH),
+    modes = [("p2p slab", "p2p", L.DIST_RESIDENT),
+             ("p2p2 single-reduction", "p2p", SR), ("p2p2 single-red.+graph", "p2p", SR | L.DIST_GRAPH),
              ("p2p4", "p2p", 0), ("p2p4+graph", "p2p", L.DIST_GRAPH),
              ("p2p staged", "p2p", ST | L.DIST_NO_OVERLAP), ("p2p staged+graph", "p2p", ST | L.DIST_GRAPH | L.DIST_NO_OVERLAP),
              ("p2p staged overlap", "p2p", ST)]
@@ -96,7 +97,7 @@ def main():
             L.check(lib.cgamd_comm_unique_id(L.ptr(uid)))       # one communicator per solver
         d = dmod.DistSolver(ctx, plan, indptr, data, np.float64, unique_id=uid if comm == "rccl" else None, flags=fl, comm=comm)
         lo, med = timed(d)
-        print(f"{args.grid} rows={n}  dist loop {name:22s}: {lo:7.2f} us/iter (median {med:7.2f})", flush=True)
+        print(f"{args.grid} rows={n}  dist loop {name:22s}: {lo:7.2f} us/iter (median {med:7.2f})  [{lib.cgamd_dist_loop_launches(d.handle)} launches/iteration]", flush=True)
         d.close()
 
 

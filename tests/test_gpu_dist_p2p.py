@@ -83,12 +83,16 @@ def _worker(rank, world, port, kind, iters, flags, out_dir, coded=False):
         vals = torch.from_numpy(da[lo:hi]).to(dev)
         if coded:           # one-byte column codes also for these small local matrices (default: above 32 MB)
             pkg._lib.check(pkg._lib.load().cgamd_tune(b"index_codes_min_mb", 0))
+        if flags & 512:     # slab loop: the ranks' resident launches must run at the same time on the shared GPU
+            pkg._lib.check(pkg._lib.load().cgamd_tune(b"resident_lock", 0))
         s = dmod.DistSolver(ctx, plan, indptr, vals, da.dtype, flags=flags, comm="p2p")
         assert (s.index_codes() > 0) == coded, s.index_codes()
+        if flags & 512:
+            assert pkg._lib.load().cgamd_dist_loop_launches(s.handle) == 0
         bl = torch.from_numpy(b[rb:re].astype(da.dtype)).to(dev)
         s.set_rhs(bl, None)
-        for _ in range(3):
-            s.iterate(iters // 3)
+        for part in ((16, 4, 10) if flags & 512 else (iters // 3,) * 3):      # slab loop: calls of >= 16 iterations; the 4 run launched
+            s.iterate(part)
         x = s.x(torch.empty(plan.n_local, dtype=bl.dtype, device=dev)).cpu().numpy()
         hist = s.history()
         err = s.p2p_error()
@@ -112,7 +116,10 @@ def _worker(rank, world, port, kind, iters, flags, out_dir, coded=False):
                                                     (2, "lap3d", 128 | 32, True),
                                                     # 256 = single-reduction loop (csrc/cg1.hip): two launches, one scalar exchange per iteration
                                                     (2, "lap3d", 256, False), (3, "helm", 256 | 8, False), (4, "lap3d", 256, True),
-                                                    (3, "helm_c64", 256, False), (2, "lap3d_f32", 256 | 8, False), (4, "rand", 256, False)])
+                                                    (3, "helm_c64", 256, False), (2, "lap3d_f32", 256 | 8, False), (4, "rand", 256, False),
+                                                    # 512 = slab loop (csrc/slab.hip): whole calls in one launch per rank; needs the column codes
+                                                    (2, "lap3d", 512, True), (4, "lap3d", 512, True), (3, "helm_c64", 512, True), (3, "lap3d", 512, True),
+                                                    (2, "lap3d_f32", 512, True)])
 def test_p2p_multirank_on_one_gpu(tmp_path, world, kind, flags, coded):
     import torch.multiprocessing as mp
     import cg_oracle
