@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", type=str, default="250x200x200", help="global grid nx x ny x nz")
-    ap.add_argument("--dist-skip", type=str, default="", help="N>1: comma list of loop candidates to skip (p2p+graph,p2p,rccl+graph,rccl)")
+    ap.add_argument("--dist-skip", type=str, default="", help="N>1: comma list of loop candidates to skip (slab,p2p2-sr,p2p4,p2p4+graph,p2p,p2p+graph,rccl-sr,rccl-sr+graph,rccl+graph,rccl)")
     ap.add_argument("--dtype", type=str, default="f64", choices=["f32", "f64", "c64", "c128"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-system", action="store_true", help="skip the small-system extra (reference call shape, resident loop)")
@@ -166,6 +166,9 @@ def main():
     pkg = importlib.import_module(PKG)
     lib = pkg._lib
     tune = os.environ.get("CG_TUNE", "")
+    if shared and "resident_lock" not in tune:
+        # ranks of this job share a GPU: their slab launches must run at the same time (no per-GPU serialisation of resident launches)
+        tune = ",".join(filter(None, [tune, "resident_lock=0"]))
     if shared and "vec_grid" not in tune:
         # ranks sharing one GPU must leave each other's spinning work-groups room to run
         per_dev = (world + max(ndev, 1) - 1) // max(ndev, 1)

@@ -66,6 +66,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "resident_wide_min") g_tune.resident_wide_min = value;
     else if (k == "resident_claim_ms") g_tune.resident_claim_ms = value;
     else if (k == "resident_lock") g_tune.resident_lock = value;
+    else if (k == "slab_cus") g_tune.slab_cus = value;
     else if (k == "resident_test_short_grid") g_tune.resident_test_short_grid = value;
     else if (k == "vec_nt") g_tune.vec_nt = value;
     else if (k == "vec_skew") g_tune.vec_skew = value & ~15;

@@ -103,6 +103,8 @@ struct Tuning {
                                // against the launched loops at 4 / 12 / 24 iterations for 1M / 250k / 90k rows, scripts/short_calls.py)
     int resident_claim_ms = 200;   // resident loops: how long a call waits for the GPU's resident-launch lock, and work-groups for their group to fill (CUs held by other kernels), before the
                                // launch gives up untouched and the handle goes back to the launched loops
+    int slab_cus = 0;              // slab loop: CUs (= members at most) a handle may use; 0 = all of the device's (ranks that share a GPU in a
+                                   // rehearsal must fit side by side)
     int resident_lock = 1;         // 0: no per-GPU serialisation of resident launches (ranks of ONE job that share a GPU in a rehearsal must run
                                    // their slab launches at the same time; never needed with one rank per GPU)
     int resident_test_short_grid = 0; // test hook: launch one work-group too few, so that no group can fill

@@ -434,6 +434,7 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
     }
     if (!rc && (flags & CGAMD_DIST_RESIDENT) && !d->cg1) {
         if (hipDeviceGetAttribute(&d->n_cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) d->n_cus = 0;
+        if (d->tune.slab_cus > 0) d->n_cus = std::min(d->n_cus, d->tune.slab_cus);
         SlabPlan sp;
         if (slab_plan(dtype, n_local, d->n_cus, d->plan, d->codes != nullptr, &sp)) {
             rc = dalloc(&d->slab_sync, sp.sync_bytes, "slab sync words");

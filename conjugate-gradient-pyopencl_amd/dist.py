@@ -341,6 +341,10 @@ class DistSolver:
         """distinct (column - row) offsets when this rank's SpMV reads one-byte column codes (include/cgamd.h), else 0"""
         return int(self._lib.cgamd_dist_index_codes(self.handle))
 
+    def loop_launches(self):
+        """stream operations per iteration of the loop this handle runs; 0 = the slab loop (whole calls in one launch)"""
+        return int(self._lib.cgamd_dist_loop_launches(self.handle))
+
     def comm_ranks(self):
         """ranks of the RCCL communicator, as RCCL reports them (0: no communicator)"""
         return int(self._lib.cgamd_dist_comm_ranks(self.handle))
@@ -462,7 +466,7 @@ def _run_dist(solver, b, warmup, steps, dist, torch, dev):
     return float(red[0].item()), float(red[1].item()) == 0.0, err
 
 
-def _history_check(solver, ref_hist, entries=9):
+def _history_check(solver, ref_hist, entries=17):
     """(ok, text): no peer-to-peer time-out, finite history, first `entries` residuals equal to the single-GPU ones to 1e-9"""
     try:
         perr = solver.p2p_error()
@@ -483,13 +487,17 @@ def _history_check(solver, ref_hist, entries=9):
     return True, ""
 
 
-DIST_MODES = ("p2p4", "p2p4+graph", "p2p", "p2p+graph", "rccl+graph", "rccl")
+DIST_MODES = ("slab", "p2p2-sr", "p2p4", "p2p4+graph", "p2p", "p2p+graph", "rccl-sr", "rccl-sr+graph", "rccl+graph", "rccl")
 
 
 def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, rank, world):
     """bench.py --gpus N (N > 1): the SAME N=10M system, rows partitioned into N contiguous z-slabs.
 
     Candidate loops (all of them are built, validated and trialled; RCCL is always timed next to the peer-to-peer loops):
+      slab        peer-to-peer, the WHOLE call in one launch per rank (csrc/slab.hip): vectors in registers, matrix streamed, halo
+                  pushes, halo flags and the two rank-ordered scalar sums inside the launch
+      p2p2-sr     peer-to-peer, single-reduction recurrence (csrc/cg1.hip): two launches, one scalar exchange per iteration
+      rccl-sr(+graph)  the single-reduction recurrence over RCCL: one all-reduce of two scalars per iteration
       p2p4        peer-to-peer mailboxes over xGMI, FOUR launches per iteration: the halo push and the wait ride inside
                   the SpMV launch (halo read in place), the r.r all-reduce inside the aypx launch; plain launches
       p2p4+graph  the same, replayed from a hipGraph
@@ -497,7 +505,7 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
       p2p+graph   the same from a hipGraph
       rccl+graph  RCCL send/recv + all-reduce captured in a hipGraph
       rccl        RCCL, plain launches, exchange overlapped with the interior row blocks
-    Validation before a loop may be timed: 8 iterations whose residual history must match, to 1e-9, the history of the SAME
+    Validation before a loop may be timed: 16 iterations whose residual history must match, to 1e-9, the history of the SAME
     global system solved by the single-GPU solver, which every rank computes for itself (the whole system fits one GPU; no
     communication library is involved in the check).  The valid loops run a short trial; the fastest runs the timed
     region, AFTER which it is validated again (no protocol time-out on any rank, finite history, first residuals equal
@@ -527,8 +535,18 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
 
     def make(mode):
         flags = _lib.DIST_GRAPH if mode.endswith("+graph") else 0
+        if "-sr" in mode:
+            flags |= _lib.DIST_SINGLE_REDUCTION
+        if mode == "slab":
+            s = DistSolver(ctx, plan, indptr, data, dtype, flags=_lib.DIST_RESIDENT, comm="p2p")
+            if s.loop_launches() != 0:      # (the flag is inert where the loop does not apply: that would time p2p4 twice)
+                s.close()
+                raise RuntimeError("the slab loop does not apply to this rank's slab")
+            return s
         if mode.startswith("p2p"):
-            if not mode.startswith("p2p4"):
+            if mode.startswith("p2p2"):
+                pass
+            elif not mode.startswith("p2p4"):
                 flags |= _lib.DIST_P2P_STAGED | _lib.DIST_NO_OVERLAP
             return DistSolver(ctx, plan, indptr, data, dtype, flags=flags, comm="p2p")
         uid = broadcast_unique_id(rank, device=dev)      # collective; raises on every rank when rank 0 could not make one
@@ -551,7 +569,7 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
         b_f = torch.full((n,), 5.0, dtype=tdt, device=dev)
         torch.cuda.synchronize()                    # torch filled it on ITS stream; the solver reads it on the context's
         ref.set_rhs(b_f, None, on_device=True)
-        ref.iterate(8)
+        ref.iterate(16)
         ref_hist = ref.history()[:, 0].copy()       # synchronises the solver's stream
         ref.close()
         del ip_f, ix_f, da_f, b_f, ref
@@ -573,8 +591,8 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
         good, why = False, ""
         try:
             solver.set_rhs(b, None)
-            solver.iterate(8)
-            good, why = _history_check(solver, ref_hist)
+            solver.iterate(16)              # (one call of >= 16 iterations: what the slab loop takes whole)
+            good, why = _history_check(solver, ref_hist, entries=17)
         except Exception as e:  # noqa: BLE001
             why = f"{type(e).__name__}: {e}"
         if not all_ok(good):
@@ -589,13 +607,14 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
         if mode.startswith("rccl") and rccl_ranks is None:
             rccl_ranks = solver.comm_ranks()
 
-    mode, dt, hist = None, None, None
+    mode, dt, hist, index_codes_seen = None, None, None, 0
     for cand in sorted(trials, key=lambda m: -trials[m]):
         solver = solvers[cand]
         t, ok, err = _run_dist(solver, b, args.warmup, args.steps, dist, torch, dev)
         good, why = (False, err or "another rank failed") if not ok else _history_check(solver, ref_hist)
         if all_ok(good):
             mode, dt, hist = cand, t, solver.history()
+            index_codes_seen = solver.index_codes()
             break
         rejected[cand] = "timed run failed its check" + (f": {why}" if why else " on another rank")
         notes.append(f"{cand}: {rejected[cand]}; falling through to the next candidate")
@@ -612,7 +631,7 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
         comm = TorchComm(plan)
         _, h8 = cg_loop(ops, comm, plan, b, torch.zeros_like(b), 8)
         if ref_hist is not None:
-            dev8 = float(np.max(np.abs(h8.cpu().numpy() - ref_hist) / np.abs(ref_hist)))
+            dev8 = float(np.max(np.abs(h8.cpu().numpy() - ref_hist[:9]) / np.abs(ref_hist[:9])))
             validated = dev8 < 1e-9
             notes.append(f"python loop: max rel deviation from the single-GPU residual history over 8 iterations = {dev8:.3e}"
                          + ("" if validated else "  -- RESULT NOT VALIDATED"))
@@ -628,11 +647,17 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
         hist = h.cpu().numpy()
     nnz_total = pkg.generators.laplace3d_nnz(nx, ny, nz)
     V = np.dtype(dtype).itemsize
-    iter_bytes = nnz_total * (V + 4) + (n + 1) * 4 + 14 * n * V
+    # what the ranks' kernels move per iteration (all ranks): one index byte per non-zero where the column codes apply; vector passes
+    # of the loop that ran -- the slab loop keeps x, r, q in registers: it writes d once and gathers the off-member entries
+    coded = index_codes_seen > 0
+    passes = {"slab": 2, "p2p2-sr": 11, "rccl-sr": 11, "rccl-sr+graph": 11, "p2p4": 10, "p2p4+graph": 10}.get(mode, 11)
+    iter_bytes = nnz_total * (V + (1 if coded else 4)) + (n + 1) * 4 + passes * n * V
+    iter_bytes_csr = nnz_total * (V + 4) + (n + 1) * 4 + 14 * n * V
     it_s = args.steps / dt
-    comm_desc = ("peer-to-peer mailboxes over xGMI (direct halo writes + rank-ordered scalar sums)"
-                 + (", 4 launches/iteration" if mode.startswith("p2p4") else "") if mode.startswith("p2p")
-                 else "RCCL send/recv + 2 scalar all-reduces per iteration")
+    comm_desc = ("peer-to-peer mailboxes over xGMI (direct halo writes + rank-ordered scalar sums), one launch per call (slab loop)" if mode == "slab"
+                 else "peer-to-peer mailboxes over xGMI (direct halo writes + rank-ordered scalar sums)"
+                 + (", 4 launches/iteration" if mode.startswith("p2p4") else ", single-reduction recurrence, 2 launches/iteration" if mode.startswith("p2p2") else "")
+                 if mode.startswith("p2p") else "RCCL send/recv + " + ("1 all-reduce of two scalars" if "-sr" in mode else "2 scalar all-reduces") + " per iteration")
     return {
         "metric": "CG iterations/sec + SpMV effective HBM GB/s (% of 8 TB/s peak), N=10M CSR",
         "value": it_s, "unit": "CG iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -642,8 +667,10 @@ def bench_strong_scaling(args, pkg, ctx, torch, dist, dev, nx, ny, nz, dtype, ra
                                f"x0=0, fixed-iteration CG, rows partitioned in {world} contiguous z-slabs, "
                                f"halo {plan.n_halo} entries/rank, {comm_desc}",
                    "rows": n, "nnz": nnz_total, "parallelism": f"row-partition x{world} ({mode})"},
-        "cg_iter_algorithmic_gbs": iter_bytes * it_s / 1e9,
+        "cg_iter_moved_bytes": iter_bytes, "cg_iter_gbs": iter_bytes * it_s / 1e9,
         "cg_iter_pct_of_aggregate_hbm_peak": 100.0 * iter_bytes * it_s / 1e9 / (8000.0 * world),
+        "effective_csr": {"note": "reference CSR byte model (SURVEY 8d), an effective rate, not a fraction of the peak",
+                          "cg_iter_bytes": iter_bytes_csr, "cg_iter_gbs": iter_bytes_csr * it_s / 1e9},
         "residual_check": {"delta_0": float(abs(hist[0])), "delta_last": float(abs(hist[-1])),
                            "iterations": int(len(hist) - 1)},
         "roofline": {"bound": "hbm", "kernel": "whole CG iteration (all ranks)", "achieved": iter_bytes * it_s / 1e9,
