@@ -405,7 +405,17 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
             for (int p = 0; p < a.n_peers; ++p) {
                 T *dst = a.push_dst[(k & 1) * a.n_peers + p];
                 const int *idx = a.send_index + a.send_off[p];
-                for (int i = sendlo[p] + t; i < sendhi[p]; i += kResThreads) st_sys_val(dst + i, dl[idx[i] - R0]);
+                const int lo = sendlo[p], hi = sendhi[p];
+                if (hi <= lo) continue;              // uniform
+                int rows[RPT];                       // at most rows_m entries are mine: all index loads in flight together (one by
+                                                     // one, a member that pushes a whole plane was 5 us behind the others)
+#pragma unroll
+                for (int u = 0; u < RPT; ++u) rows[u] = idx[min(lo + t + u * kResThreads, hi - 1)];
+#pragma unroll
+                for (int u = 0; u < RPT; ++u) {
+                    const int i = lo + t + u * kResThreads;
+                    if (i < hi) st_sys_val(dst + i, dl[rows[u] - R0]);
+                }
             }
         }
         drain_stores();                              // (also lands the value slices in flight: they are stored to LDS next anyway)

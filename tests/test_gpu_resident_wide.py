@@ -108,7 +108,7 @@ def test_resident_launch_that_cannot_form_its_group_falls_back_untouched(pkg, gp
             return out
         finally:
             for k in knobs:
-                pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_claim_ms": 15000}.get(k, 0)))
+                pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_claim_ms": 200}.get(k, 0)))
 
     x0, h0, _, k0 = run({"resident": 0})
     x1, h1, before, after = run({"resident_test_short_grid": 1, "resident_claim_ms": 40})
