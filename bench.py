@@ -215,7 +215,7 @@ def small_system_extra(pkg, ctx, torch, dev):
     N, nrhs, iters = 128, 9, 2560
     ip, ix, da = pkg.generators.helm_fe_var(ctx, N, 12.0, None, 0.15, dtype=np.complex64)
     s = pkg.Solver(ctx, N * N, int(ix.numel()), da, ip, ix, nrhs, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=np.complex64)
-    b = torch.full((N * N * nrhs,), 5.0, dtype=torch.complex64, device=dev)
+    b = pkg.generators.rhsA(ctx, N, 12.0, dtype=np.complex64).repeat(nrhs)      # the drivers' right-hand side (helmFE_var.py:379-389)
     torch.cuda.synchronize()
     s.set_rhs(b, None, on_device=True)
     s.iterate(64)

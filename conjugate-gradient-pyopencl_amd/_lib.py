@@ -107,6 +107,7 @@ def load():
         "cgamd_gen_helm_fe_var": (ci, [vp, ci, ci, ctypes.c_double, vp, ctypes.c_double, ci, ci, vp, vp, vp, ctypes.POINTER(ll)]),
         "cgamd_gen_local_rect": (ci, [vp, ci, ci, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ci, ci, vp, vp, vp,
                                  ctypes.POINTER(ll)]),
+        "cgamd_gen_rhs": (ci, [vp, ci, ci, ci, ctypes.c_double, vp]),
         "cgamd_mm_read": (ci, [ctypes.c_char_p, ctypes.POINTER(ci), ctypes.POINTER(ll), ctypes.POINTER(ci),
                                ctypes.POINTER(ctypes.POINTER(ctypes.c_double)),
                                ctypes.POINTER(ctypes.POINTER(ci)), ctypes.POINTER(ctypes.POINTER(ci))]),

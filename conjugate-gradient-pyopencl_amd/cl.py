@@ -364,8 +364,11 @@ class Solver:
             # resident loop: the stop happens on the device, in the iteration the reference stops in (no read-backs, no re-run)
             self.set_rhs(b, x0)
             run_ = ctypes.c_int(0)
-            if self._lib.cgamd_solver_iterate_tol(self.handle, int(maxit), float(tol), ctypes.byref(run_)) == 0:
+            st = self._lib.cgamd_solver_iterate_tol(self.handle, int(maxit), float(tol), ctypes.byref(run_))
+            if st == 0:
                 return self.x(), int(run_.value), self.history()
+            if st != _lib.ERR_STATE:        # only "the resident loop is not available for this call" falls back; a GPU failure is reported
+                check(st)
 
         its = self._run_to_tol(b, x0, tol, int(maxit), int(check_every))
         return self.x(), its, self.history()
@@ -409,8 +412,11 @@ class Solver:
             self.set_preconditioner(None)
             self.set_rhs(b, x0)             # resident loop: the stop happens on the device (Solver.solve_tol)
             run_ = ctypes.c_int(0)
-            if self._lib.cgamd_solver_iterate_tol(self.handle, int(maxit), float(tol), ctypes.byref(run_)) == 0:
+            st = self._lib.cgamd_solver_iterate_tol(self.handle, int(maxit), float(tol), ctypes.byref(run_))
+            if st == 0:
                 return self.x(), int(run_.value) - 1
+            if st != _lib.ERR_STATE:
+                check(st)
         self.set_preconditioner(M)
         try:
             its = self._run_to_tol(b, x0, tol, int(maxit), int(check_every))

@@ -1,5 +1,8 @@
 // C ABI: context, memory helpers, the five stand-alone kernels, generators, legacy cg()/connect().
 // The ABI mirrors the reference's Python operator surface (cl.py:16-42) and C entry (clcg.h:3-5).
+#include <atomic>
+#include <pthread.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -27,10 +30,13 @@ const char *cgamd_last_error(void) { return g_err.c_str(); }
 int cgamd_version(void) { return 100; }
 size_t cgamd_dtype_size(int dtype) { return dtype_size(dtype); }
 
+static std::atomic<unsigned long long> g_tune_generation{1};     // bumped by every cgamd_tune: cached cg() handles carry the one they were made under
+
 int cgamd_tune(const char *key, int value) {
     if (!key) return fail(CGAMD_ERR_INVALID, "tune: null key");
     const std::string k(key);
     bool known = true;
+    g_tune_generation.fetch_add(1, std::memory_order_relaxed);     // cached cg() handles were created under the old configuration
     tune_set([&](Tuning &g_tune) {
     if (k == "spmv_variant") g_tune.spmv_variant = value;
     else if (k == "spmv_nt") g_tune.spmv_nt = value;
@@ -317,6 +323,14 @@ int cgamd_gen_local_rect(cgamd_ctx *c, int dtype, int N, double k, double eps, d
     return gen_fe_common(c, dtype, 0, N, k, eps, eta, L, nullptr, Nhoriz, Nvert, aValues, aPointers, aCols, nnz_out, "gen_local_rect");
 }
 
+int cgamd_gen_rhs(cgamd_ctx *c, int dtype, int kind, int N, double k, void *b) {
+    if (!c || !b) return fail(CGAMD_ERR_INVALID, "gen_rhs: null argument");
+    if (dtype < 0 || dtype > 3 || kind < 0 || kind > 2 || N < 2) return fail(CGAMD_ERR_INVALID, "gen_rhs: bad dtype / kind / N");
+    if (kind == 0 && dtype != CGAMD_C64 && dtype != CGAMD_C128) return fail(CGAMD_ERR_INVALID, "gen_rhs: rhs(N, k) is complex valued");
+    CG_HIP(hipSetDevice(c->device));
+    return launch_gen_rhs(dtype, kind, N, k, b, c->stream);
+}
+
 // ---- one-call typed solve on host arrays ----------------------------------------------------------
 // Stateless towards the caller (matrix, b, x are host arrays alive for the call only; everything is uploaded every time,
 // as in the reference clcg.c:202-211), but the DEVICE STATE -- context, stream, allocations, SpMV plan, captured graphs --
@@ -329,21 +343,47 @@ struct CgCache {
     cgamd_solver *s = nullptr;
     int dtype = -1, size = 0, nrhs = 0, device = -1;
     long long nnz = -1;
+    unsigned long long tune_gen = 0;      // generation of the tuning configuration the handle was created under
+    unsigned long long last_use = 0;
     void release() {
         if (s) cgamd_solver_destroy(s);
         if (ctx) cgamd_ctx_destroy(ctx);
         s = nullptr; ctx = nullptr; dtype = -1;
     }
-    ~CgCache() { release(); }
+    void forget() { s = nullptr; ctx = nullptr; dtype = -1; }      // after fork(): the child must not touch the parent's HIP handles
 };
-thread_local CgCache t_cg_cache;
+// A small LRU per calling thread: the reference's as_prec cycles over sub-domains of a few different sizes (p_h-PY_C-CL.py:1918-1953),
+// one entry would miss every time.  An entry is reused only under the tuning configuration it was created with.
+constexpr int kCgCacheEntries = 4;
+struct CgCacheSet {
+    CgCache e[kCgCacheEntries];
+    unsigned long long clock = 0;
+    ~CgCacheSet() { for (auto &c : e) c.release(); }
+};
+thread_local CgCacheSet t_cg_cache;
+std::atomic<unsigned long long> g_fork_generation{0};
+thread_local unsigned long long t_fork_seen = 0;
+void cg_atfork_child() { g_fork_generation.fetch_add(1, std::memory_order_relaxed); }
+void cg_cache_check_fork() {
+    static std::once_flag once;
+    std::call_once(once, [] { pthread_atfork(nullptr, nullptr, cg_atfork_child); });
+    const unsigned long long g = g_fork_generation.load(std::memory_order_relaxed);
+    if (g != t_fork_seen) {                // this process is a fork()ed child: the cached device state belongs to the parent
+        for (auto &c : t_cg_cache.e) c.forget();
+        t_fork_seen = g;
+    }
+}
 thread_local double t_cg_timing[6] = {0, 0, 0, 0, 0, 0};
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 }  // namespace
 
-int cgamd_cg_release_cache(void) { t_cg_cache.release(); return CGAMD_OK; }
+int cgamd_cg_release_cache(void) {
+    cg_cache_check_fork();
+    for (auto &c : t_cg_cache.e) c.release();
+    return CGAMD_OK;
+}
 int cgamd_cg_last_timing(double *ms6) {
     if (!ms6) return fail(CGAMD_ERR_INVALID, "cg_last_timing: null argument");
     for (int i = 0; i < 6; ++i) ms6[i] = t_cg_timing[i];
@@ -356,10 +396,22 @@ int cgamd_cg(int dtype, int size, long long nnz, const void *aValues, const void
     if (size == 0) return CGAMD_OK;
     if (!aPointers || !b || !x || (nnz > 0 && (!aValues || !aCols))) return fail(CGAMD_ERR_INVALID, "cg: null pointer");
     static const bool no_cache = [] { const char *e = getenv("CGAMD_CG_NO_CACHE"); return e && e[0] == '1'; }();
-    CgCache local, &c = no_cache ? local : t_cg_cache;
+    cg_cache_check_fork();
+    const unsigned long long tgen = g_tune_generation.load(std::memory_order_relaxed);
+    CgCache local;
+    CgCache *pick = &local;
+    if (!no_cache) {        // the entry of this shape (under today's tuning), else the least recently used one
+        CgCacheSet &set = t_cg_cache;
+        pick = &set.e[0];
+        for (auto &e : set.e)
+            if (e.s && e.dtype == dtype && e.size == size && e.nnz == nnz && e.nrhs == nRHS && e.device == device && e.tune_gen == tgen) { pick = &e; break; }
+            else if (e.last_use < pick->last_use) pick = &e;
+        pick->last_use = ++set.clock;
+    }
+    CgCache &c = *pick;
     double t[6];
     t[0] = now_ms();
-    const bool hit = c.s && c.dtype == dtype && c.size == size && c.nnz == nnz && c.nrhs == nRHS && c.device == device;
+    const bool hit = c.s && c.dtype == dtype && c.size == size && c.nnz == nnz && c.nrhs == nRHS && c.device == device && c.tune_gen == tgen;
     int rc = CGAMD_OK;
     double t_upload = 0.0;
     if (hit) {
@@ -371,7 +423,7 @@ int cgamd_cg(int dtype, int size, long long nnz, const void *aValues, const void
         rc = cgamd_ctx_create(device, &c.ctx);
         // creation uploads the matrix as part of building the handle: not separable, all of it is counted as device state
         if (rc == CGAMD_OK) rc = cgamd_solver_create(c.ctx, dtype, size, nnz, aValues, aPointers, aCols, nRHS, 0, &c.s);
-        if (rc == CGAMD_OK) { c.dtype = dtype; c.size = size; c.nnz = nnz; c.nrhs = nRHS; c.device = device; }
+        if (rc == CGAMD_OK) { c.dtype = dtype; c.size = size; c.nnz = nnz; c.nrhs = nRHS; c.device = device; c.tune_gen = tgen; }
     }
     t[1] = now_ms();
     if (rc == CGAMD_OK) rc = cgamd_solver_set_rhs(c.s, b, x, 0);      // x is in/out: initial guess (clcg.c:210)
@@ -387,7 +439,7 @@ int cgamd_cg(int dtype, int size, long long nnz, const void *aValues, const void
     t[4] = now_ms();
     t_cg_timing[0] = t[1] - t[0] - t_upload; t_cg_timing[1] = t_upload; t_cg_timing[2] = t[2] - t[1];
     t_cg_timing[3] = t[3] - t[2]; t_cg_timing[4] = t[4] - t[3]; t_cg_timing[5] = hit ? 1.0 : 0.0;
-    if (rc != CGAMD_OK) {       // never keep a handle in an unknown state
+    if (rc != CGAMD_OK || no_cache) {       // never keep a handle in an unknown state (CGAMD_CG_NO_CACHE: never keep one at all)
         std::string keep = g_err;
         c.release();
         g_err = keep;

@@ -377,6 +377,8 @@ long long helm_fe_nnz(int Nh, int Nv);
 int launch_gen_helm_fe(int dtype, int variable, int N, double p0, double p1, double p2, double L, const double *C_dev, int Nh, int Nv, void *vals,
                        int *ptr, int *cols, hipStream_t st);
 long long poisson2d_ptr(long long i, int N);
+// kind 0 rhs, 1 rhsL, 2 rhsA of helmFE_var.py:333-389 on an N x N node grid; b: N * N values of `dtype` (device)
+int launch_gen_rhs(int dtype, int kind, int N, double k, void *b, hipStream_t st);
 
 }  // namespace cgamd
 

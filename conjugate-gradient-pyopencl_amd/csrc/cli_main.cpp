@@ -1,8 +1,10 @@
 // oclcgex -- command-line front end with the reference's argv (reference main.c:13-61):
-//     oclcgex <matrix.mtx> <nRHS> <isComplex> <nIterations> [--double] [--device N] [--quiet]
+//     oclcgex <matrix.mtx> <nRHS> <isComplex> <nIterations> [--double] [--device N] [--quiet] [--history <file>]
 // Matrix-Market file -> symmetric storage expanded -> CSR; b[r*n+i] = (r+1)*5, x0 = 0 (main.c:41-46).
 // The reference prints nothing and discards x; this front end adds the residual history and timing.
 // Values are cast to single precision as the reference does (main.c:49-53) unless --double is given.
+// --history <file>: the whole residual history delta_k[r] = r_k.r_k (k = 0..nIterations, r < nRHS; what the reference computes and
+// drops, clcg.c:274-292,384-387) as raw little-endian fp64, (nIterations + 1) x nRHS values -- pairs (re, im) for complex solves.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -14,17 +16,19 @@
 
 int main(int argc, char *argv[]) {
     if (argc < 5) {
-        fprintf(stderr, "Usage: %s <input matrix file> <number of RHS> <is complex> <number of iterations> [--double] [--device N] [--quiet]\n", argv[0]);
+        fprintf(stderr, "Usage: %s <input matrix file> <number of RHS> <is complex> <number of iterations> [--double] [--device N] [--quiet] [--history <file>]\n", argv[0]);
         return 1;
     }
     const char *path = argv[1];
     const int nRHS = atoi(argv[2]), isComplex = atoi(argv[3]), nIterations = atoi(argv[4]);
     bool dbl = false, quiet = false;
     int device = 0;
+    const char *history_path = nullptr;
     for (int i = 5; i < argc; ++i) {
         if (!strcmp(argv[i], "--double")) dbl = true;
         else if (!strcmp(argv[i], "--quiet")) quiet = true;
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--history") && i + 1 < argc) history_path = argv[++i];
     }
     if (nRHS < 1 || nIterations < 0) { fprintf(stderr, "bad nRHS / nIterations\n"); return 1; }
 
@@ -58,6 +62,18 @@ int main(int argc, char *argv[]) {
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     cgamd_mm_free(vals); cgamd_mm_free(ptr); cgamd_mm_free(cols);
     if (rc != CGAMD_OK) { fprintf(stderr, "error -- cg failed (%d): %s\n", rc, cgamd_last_error()); return 2; }
+    if (history_path) {
+        const bool cplx = dtype == CGAMD_C64 || dtype == CGAMD_C128;
+        const size_t count = (size_t)(nIterations + 1) * nRHS * (cplx ? 2 : 1);
+        std::vector<double> out(count);
+        for (size_t i = 0; i < count; ++i)
+            out[i] = (dtype == CGAMD_F32 || dtype == CGAMD_C64) ? (double)((const float *)hist.data())[i] : ((const double *)hist.data())[i];
+        FILE *f = fopen(history_path, "wb");
+        if (!f || fwrite(out.data(), sizeof(double), count, f) != count || fclose(f) != 0) {
+            fprintf(stderr, "error -- could not write the residual history to %s\n", history_path);
+            return 3;
+        }
+    }
     if (!quiet) {
         auto mag = [&](size_t idx) {
             switch (dtype) {

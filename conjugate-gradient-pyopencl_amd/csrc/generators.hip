@@ -11,6 +11,8 @@
 // matrices produced by the unmodified reference (pattern exact, values to 1e-15) and to the CPU restatement at N = 500.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "cgamd_internal.h"
 #include "device_types.h"
 #include "launch_util.h"
@@ -252,6 +254,96 @@ template <typename T> static int gen2d_impl(int N, void *vals, int *ptr, int *co
 }
 int launch_gen_poisson2d(int dtype, int N, void *vals, int *ptr, int *cols, hipStream_t st) {
     CG_DISPATCH(dtype, gen2d_impl, N, vals, ptr, cols, st);
+}
+
+}  // namespace cgamd
+
+// =================================================================================================
+// Right-hand sides of the reference's Helmholtz drivers on an N x N node grid (reference helmFE_var.py:333-389), b[row][col] at
+// row N + col:   kind 0  rhs(N, k)   plane-wave impedance data on the boundary nodes (:333-368), evaluated node by node in the
+//                                    reference's operation order -- including its quirk that the RIGHT boundary is integrated over the
+//                                    TOP boundary's points (:355-356) -- in complex double, then rounded to the requested type;
+//                kind 1  rhsL(N, k)  k^2 on the left boundary, corners excluded (:370-377);
+//                kind 2  rhsA(N, k)  k^2 on the four boundary lines (:379-389) -- BASELINE config 3's right-hand side rhsA(500, 12).
+// =================================================================================================
+namespace cgamd {
+namespace {
+
+struct Cd { double re, im; };
+CG_DEV Cd cmul(Cd a, Cd b) { return Cd{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+CG_DEV Cd cadd(Cd a, Cd b) { return Cd{a.re + b.re, a.im + b.im}; }
+CG_DEV Cd cscale(double s, Cd a) { return Cd{s * a.re - 0.0 * a.im, s * a.im + 0.0 * a.re}; }      // (s + 0i) a as numpy forms it
+// exp(1. * 1.j * k * (p . a)) for a = (1, 1) / sqrt(2): the argument is purely imaginary
+CG_DEV Cd wave(double k, double a0, double a1, double px, double py) {
+    const double s = px * a0 + py * a1;
+    const double th = k * s;
+    return Cd{cos(th), sin(th)};
+}
+template <typename T> CG_DEV void put_c(T *b, long long i, Cd v);
+template <> CG_DEV void put_c<float2>(float2 *b, long long i, Cd v) { b[i] = make_float2((float)v.re, (float)v.im); }
+template <> CG_DEV void put_c<double2>(double2 *b, long long i, Cd v) { b[i] = make_double2(v.re, v.im); }
+template <> CG_DEV void put_c<float>(float *b, long long i, Cd v) { b[i] = (float)v.re; }
+template <> CG_DEV void put_c<double>(double *b, long long i, Cd v) { b[i] = v.re; }
+
+template <typename T> __global__ void gen_rhs_kernel(int kind, int N, double k, T *b) {
+    const long long n = (long long)N * N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / N), col = (int)(i % N);
+        Cd v{0.0, 0.0};
+        if (kind == 2) {
+            if (row == 0 || row == N - 1 || col == 0 || col == N - 1) v.re = k * k;
+        } else if (kind == 1) {
+            if (col == 0 && row >= 1 && row <= N - 2) v.re = k * k;
+        } else if (row == 0 || row == N - 1 || col == 0 || col == N - 1) {
+            const double a0 = 1. / sqrt(2.), a1 = 1. / sqrt(2.);
+            const double h = 1. / (N - 1.), step = 1.0 / (N - 1);
+            auto X = [&](int j) { return 0.0 + j * step; };                 // numpy.arange(0.0, 1.00001, 1.0 / (N - 1))
+            auto Y = [&](int j) { return (X(j + 1) + X(j)) / 2.0; };         // mid points
+            // multipliers i k (a.n - 1) on each side: 1.j * k * (real) = (0 + k i)(r + 0 i)
+            auto mult = [&](double r) { return Cd{0.0 * r - k * 0.0, 0.0 * 0.0 + k * r}; };
+            const Cd multbot = mult(-a1 - 1.), multtop = mult(a1 - 1.), multleft = mult(-a0 - 1.), multright = mult(a0 - 1.);
+            auto side = [&](Cd m, double p0x, double p0y, double p1x, double p1y, double p2x, double p2y) {
+                const Cd sum = cadd(cadd(wave(k, a0, a1, p0x, p0y), wave(k, a0, a1, p1x, p1y)), wave(k, a0, a1, p2x, p2y));
+                return cmul(cscale(h / 3., m), sum);
+            };
+            auto corner = [&](Cd m, double p0x, double p0y, double p1x, double p1y) {      // (h/6) m (2 e(p0) + e(p1))
+                const Cd two{2.0, 0.0};
+                const Cd e0 = wave(k, a0, a1, p0x, p0y), e1 = wave(k, a0, a1, p1x, p1y);
+                return cmul(cscale(h / 6., m), cadd(Cd{2.0 * e0.re - 0.0 * e0.im, 2.0 * e0.im + 0.0 * e0.re}, e1));
+                (void)two;
+            };
+            const bool cr = (row == 0 || row == N - 1) && (col == 0 || col == N - 1);
+            if (!cr) {
+                // the reference assigns bottom, top, left, right in this order inside one loop over j: for a non-corner node exactly one applies
+                if (row == 0) { const int j = col; v = side(multbot, Y(j - 1), 0., X(j), 0., Y(j), 0.); }
+                else if (row == N - 1) { const int j = col; v = side(multtop, Y(j - 1), 1., X(j), 1., Y(j), 1.); }
+                else if (col == 0) { const int j = row; v = side(multleft, 0., Y(j - 1), 0., X(j), 0., Y(j)); }
+                else { const int j = row; v = side(multright, Y(j - 1), 1., X(j), 1., Y(j), 1.); }     // (sic: the top boundary's points)
+            } else if (row == 0 && col == 0) {
+                v = cadd(corner(multleft, 0., Y(0), 0., 0.), corner(multbot, Y(0), 0., 0., 0.));
+            } else if (row == 0 && col == N - 1) {
+                v = cadd(corner(multbot, Y(N - 2), 0., 1., 0.), corner(multright, 1., Y(0), 1., 0.));
+            } else if (row == N - 1 && col == 0) {
+                v = cadd(corner(multleft, 0., Y(N - 2), 0., 1.), corner(multtop, Y(0), 1., 0., 1.));
+            } else {
+                v = cadd(corner(multtop, Y(N - 2), 1., 1., 1.), corner(multright, 1., Y(N - 2), 1., 1.));
+            }
+        }
+        put_c<T>(b, i, v);
+    }
+}
+
+template <typename T> int gen_rhs_impl(int kind, int N, double k, void *b, hipStream_t st) {
+    const long long n = (long long)N * N;
+    const int g = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL((gen_rhs_kernel<T>), dim3(g), dim3(256), 0, st, kind, N, k, static_cast<T *>(b));
+    return check_launch("gen_rhs");
+}
+
+}  // namespace
+
+int launch_gen_rhs(int dtype, int kind, int N, double k, void *b, hipStream_t st) {
+    CG_DISPATCH(dtype, gen_rhs_impl, kind, N, k, b, st);
 }
 
 }  // namespace cgamd

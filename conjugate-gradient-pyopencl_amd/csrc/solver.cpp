@@ -568,7 +568,11 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
             if (int rc = run_cg_resident_wide(s->dtype, s->resw, s->n, s->nrhs, s->vals, s->ptr, s->cols, s->x, s->r, d0, d1,
                                               keeps_new_d && s->iters > 0, s->sc, s->iters, K, s->resw_sync, s->n_cus, st, &untouched, s->tol_req,
                                               &stop)) {
-                if (!untouched) return rc;
+                if (!untouched) {            // x / r / d / delta may be partly advanced: the handle demands a fresh set_rhs
+                    s->rhs_set = false;
+                    s->resw.ok = false;
+                    return rc;
+                }
                 s->resw.ok = false;          // the chip is shared with something that does not yield: this handle keeps the launched loops
                 if (int rc2 = launch_dot_partials(s->dtype, s->n, s->r, s->r, s->n, s->nrhs, s->part_rr, s->vgrid, st)) return rc2;
                 if (s->tol_req > 0.) { s->tol_served = false; return rc; }      // (the launched loops have no device-side stop: the caller checks from the host)
@@ -600,7 +604,11 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
             s->tol_served = s->tol_req > 0.;
             if (int rc = run_cg_resident(s->dtype, s->res, s->n, s->nrhs, s->vals, s->ptr, s->cols, s->x, s->r, s->d, s->d2, s->part_rr,
                                          s->vgrid, s->plan.n_partials, s->sc, s->iters, K, s->res_sync, s->n_cus, st, &untouched, s->tol_req, &stop)) {
-                if (!untouched) return rc;
+                if (!untouched) {            // (see above)
+                    s->rhs_set = false;
+                    s->res_ok = false;
+                    return rc;
+                }
                 s->res_ok = false;           // no group could form (CUs held by other work): this handle keeps the launched loops
                 if (s->tol_req > 0.) { s->tol_served = false; return rc; }
                 return cgamd_solver_iterate(s, left);

@@ -110,3 +110,29 @@ def local_rect(ctx, N, k, eps, eta, L, Nhoriz, Nvert, dtype=np.complex64, device
                                    ptr(data), ptr(indptr), ptr(indices), None))
     ctx.synchronize()
     return indptr, indices, data
+
+
+def _rhs(ctx, kind, N, k, dtype, device):
+    import torch
+    lib = _lib.load()
+    dev = device if device is not None else torch.device("cuda", ctx.device)
+    b = torch.empty(N * N, dtype=torch_dtype(dtype), device=dev)
+    torch.cuda.synchronize(dev)
+    check(lib.cgamd_gen_rhs(ctx.handle, _lib.DTYPE_CODE[np.dtype(dtype)], kind, N, float(k), ptr(b)))
+    ctx.synchronize()
+    return b
+
+
+def rhs(ctx, N, k, dtype=np.complex64, device=None):
+    """reference helmFE_var.rhs(N, k) (helmFE_var.py:333-368), flattened: plane-wave impedance data on the boundary nodes"""
+    return _rhs(ctx, 0, N, k, dtype, device)
+
+
+def rhsL(ctx, N, k, dtype=np.complex64, device=None):
+    """reference helmFE_var.rhsL(N, k) (helmFE_var.py:370-377), flattened"""
+    return _rhs(ctx, 1, N, k, dtype, device)
+
+
+def rhsA(ctx, N, k, dtype=np.complex64, device=None):
+    """reference helmFE_var.rhsA(N, k) (helmFE_var.py:379-389), flattened -- BASELINE config 3: rhsA(500, 12)"""
+    return _rhs(ctx, 2, N, k, dtype, device)

@@ -225,6 +225,11 @@ int cgamd_gen_helm_fe_var(cgamd_ctx *ctx, int dtype, int N, double omega, const 
 int cgamd_gen_local_rect(cgamd_ctx *ctx, int dtype, int N, double k, double eps, double eta, double L, int Nhoriz, int Nvert,
                          void *aValues, int *aPointers, int *aCols, long long *nnz_out);
 
+/* Right-hand sides of the reference's Helmholtz drivers on an N x N node grid (helmFE_var.py:333-389), written to device memory
+ * as N * N values, entry (row, col) at row * N + col: kind 0 = rhs(N, k) (plane-wave boundary data; complex types only), 1 = rhsL(N, k)
+ * (k^2 on the left boundary without its corners), 2 = rhsA(N, k) (k^2 on the four boundary lines: BASELINE config 3 uses rhsA(500, 12)). */
+int cgamd_gen_rhs(cgamd_ctx *ctx, int dtype, int kind, int N, double k, void *b);
+
 /* ---- Matrix-Market ingest (reference main.c:20-33 via BeBOP) ---------------
  * Reads a coordinate file (real/complex/integer/pattern x general/symmetric/hermitian/skew-symmetric),
  * expands symmetric storage, sums duplicates, converts 1-based -> 0-based CSR with sorted columns.

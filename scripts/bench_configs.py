@@ -21,12 +21,13 @@ ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
 NPD = {"f32": np.float32, "f64": np.float64, "c64": np.complex64, "c128": np.complex128}
 
 
-def run(name, indptr, indices, data, dtype, nrhs, iters=200, reps=30):
+def run(name, indptr, indices, data, dtype, nrhs, iters=200, reps=30, b1=None):
     n = indptr.numel() - 1
     nnz = indices.numel()
     tdt = pkg.generators.torch_dtype(dtype)
     s = pkg.Solver(ctx, n, nnz, data, indptr, indices, nrhs, flags=pkg._lib.MATRIX_ON_DEVICE | (pkg._lib.NO_GRAPH if "nograph" in sys.argv else 0), dtype=dtype)
-    b = torch.full((n * nrhs,), 5.0, dtype=tdt, device=dev)
+    # b1: one right-hand side from the device generators (config 3: rhsA(500, 12)), repeated; else the CLI's b = 5 (main.c:44)
+    b = b1.repeat(nrhs) if b1 is not None else torch.full((n * nrhs,), 5.0, dtype=tdt, device=dev)
     torch.cuda.synchronize()
     s.set_rhs(b, None, on_device=True)
     s.iterate(20)
@@ -76,11 +77,12 @@ if "c3" in which or "c3c64" in which:
     N = 500          # helmFE_var(N=500, omega=12, C=1, rho=0.15), generated on the device (csrc/generators.hip)
     if "c3" in which:
         ip, ix, da = pkg.generators.helm_fe_var(ctx, N, 12.0, None, 0.15, dtype=np.complex128)
-        run("C3 Helmholtz FE N=250k c128", ip, ix, da, np.complex128, 1)
+        run("C3 Helmholtz FE N=250k c128, b = rhsA(500, 12)", ip, ix, da, np.complex128, 1, b1=pkg.generators.rhsA(ctx, N, 12.0, dtype=np.complex128))
     if "c3c64" in which:
         ip, ix, da = pkg.generators.helm_fe_var(ctx, N, 12.0, None, 0.15, dtype=np.complex64)
-        run("C3 Helmholtz FE N=250k c64 (reference dtype)", ip, ix, da, np.complex64, 1)
-        run("C3 Helmholtz FE N=250k c64 nrhs=9 (as_prec shape)", ip, ix, da, np.complex64, 9, iters=100)
+        bA = pkg.generators.rhsA(ctx, N, 12.0, dtype=np.complex64)
+        run("C3 Helmholtz FE N=250k c64 (reference dtype), b = rhsA(500, 12)", ip, ix, da, np.complex64, 1, b1=bA)
+        run("C3 Helmholtz FE N=250k c64 nrhs=9 (as_prec shape)", ip, ix, da, np.complex64, 9, iters=100, b1=bA)
 if "c4" in which:
     ip, ix, da = pkg.generators.poisson2d(ctx, 1000, dtype=np.float64)
     run("C4 SpMM nrhs=32 N=1M f64", ip, ix, da, np.float64, 32, iters=50, reps=10)

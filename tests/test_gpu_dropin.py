@@ -103,3 +103,40 @@ def test_literal_dropin_sequence(tmp_path, golden, cache):
     prev = json.load(open(fn)) if os.path.exists(fn) else {}
     prev["cache" if cache else "no_cache"] = out
     json.dump(prev, open(fn, "w"), indent=1)
+
+
+def test_stateless_cg_keeps_a_few_shapes_per_thread(pkg, gpu):
+    """the reference's as_prec cycles over sub-domains of a few sizes (p_h-PY_C-CL.py:1918-1953); the stateless cg()'s
+    per-thread device-state cache holds the last four shapes (one entry missed every call), an entry is reused only under the
+    tuning configuration it was created with, and results do not depend on hits or misses."""
+    import ctypes
+    lib = pkg._lib.load()
+    split = (ctypes.c_double * 6)()
+    systems = []
+    for N in (10, 14, 18):
+        ip, ix, da = cg_numpy.poisson2d(N)
+        n = N * N
+        systems.append((n, ip.astype(np.intc), ix.astype(np.intc), da.astype(np.float64), np.linspace(1.0, 2.0, n)))
+    lib.cgamd_cg_release_cache()
+
+    def call(k):
+        n, ip, ix, da, b = systems[k]
+        x = np.zeros(n)
+        pkg._lib.check(lib.cgamd_cg(pkg._lib.F64, n, len(da), pkg._lib.ptr(da), pkg._lib.ptr(b), pkg._lib.ptr(ip), pkg._lib.ptr(ix),
+                                    pkg._lib.ptr(x), 1, 20, None, 0))
+        lib.cgamd_cg_last_timing(split)
+        return x, bool(split[5])
+
+    first = [call(k) for k in range(3)]
+    assert [h for _, h in first] == [False, False, False]
+    second = [call(k) for k in range(3)]
+    assert [h for _, h in second] == [True, True, True]
+    for (x0, _), (x1, _) in zip(first, second):
+        assert np.array_equal(x0, x1)
+    pkg._lib.check(lib.cgamd_tune(b"vec_ppt", 1))           # a new configuration: the cached handles were made under the old one
+    try:
+        x2, hit = call(0)
+        assert not hit and np.allclose(x2, first[0][0], rtol=1e-12)
+    finally:
+        pkg._lib.check(lib.cgamd_tune(b"vec_ppt", 0))
+        lib.cgamd_cg_release_cache()
