@@ -257,7 +257,7 @@ def rate_fields(spmv_moved, spmv_csr, spmv_ms, spmv_alone_ms, iter_moved, iter_c
                      "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_ratio": (traffic / spmv_moved) if traffic else None,
                      "moved_bytes_per_launch": spmv_moved, "avg_launch_ms": spmv_ms,
-                     "index_codes": {"distinct_offsets": n_offsets, "index_bytes_per_nonzero": 1 if n_offsets > 0 else 4},
+                     "index_codes": {"distinct_offsets": n_offsets, "index_bytes_per_nonzero": 2 if n_offsets == 65536 else 1 if n_offsets > 0 else 4},
                      "effective_csr_bytes_per_launch": spmv_csr, "effective_csr_gbs": spmv_csr / (spmv_ms * 1e-3) / 1e9},
     }
 

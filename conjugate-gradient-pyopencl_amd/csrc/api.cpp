@@ -46,6 +46,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "spmv_cycle") g_tune.spmv_cycle = value;
     else if (k == "spmv_ilv") g_tune.spmv_ilv = value;
     else if (k == "index_codes") g_tune.index_codes = value;
+    else if (k == "index_codes16") g_tune.index_codes16 = value;
     else if (k == "pad_rows") g_tune.pad_rows = value;
     else if (k == "index_codes_min_mb") g_tune.index_codes_min_mb = value;
     else if (k == "spmv_chunked") g_tune.spmv_chunked = value;

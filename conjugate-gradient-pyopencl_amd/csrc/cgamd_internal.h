@@ -36,11 +36,11 @@ struct SpmvPlan {
     int row_blocks = 0;  // ceil(n / kBlock)
     int max_span = 0;    // largest 4-aligned nnz span of a kBlock-row slice (0 = unknown -> generic kernel)
     int kind = 0;        // kernel chosen by finalize_spmv_plan (0 generic, 5 row-block, 6 its SpMM form, 7 chunked row-block)
-    int chunk_span[3] = {0, 0, 0};   // largest 4-aligned span of a 128 / 64 / 32-row slice
+    int chunk_span[5] = {0, 0, 0, 0, 0};   // largest 4-aligned span of a 128 / 64 / 32 / 16 / 8-row slice
     bool wide = false;   // kind 6 only: small system, one work-group per (row block, RHS) runs the single-RHS kernel
     int max_row = 0;     // longest row (0 = unknown): the row-block kernel's batch length follows it
     int max_quad = 0;    // most non-zeros in 4 consecutive rows starting at a multiple of 4 (row-major SpMM: K-steps per quad)
-    int lpr = 1;         // kind 7: lanes per row (2, 4, 8) = chunks per 256-row block
+    int lpr = 1;         // kind 7: lanes per row (2, 4, 8, 16, 32) = chunks per 256-row block
     int n_partials = 0;  // fused-dot partials per RHS written by that kernel
     int nt = 1;          // matrix stream loaded non-temporally (finalize_spmv_plan: off when the matrix fits the Infinity Cache)
     int vec_nt = 3;      // axpy2_dot streaming hints (see Tuning::vec_nt), resolved by finalize_spmv_plan
@@ -64,6 +64,9 @@ int validate_csr_device(int n, long long nnz, int ncols, const int *ptr_dev, con
 // offsets than that.  Synchronises `st`.
 int build_index_codes(int n, long long nnz, const int *ptr_dev, const int *cols_dev, hipStream_t st, unsigned char **codes_out,
                       int **dict_out, int *distinct_out);
+// 16-bit columns relative to the first column of every 256-row block, for matrices with more offsets than the dictionary holds
+// whose row blocks span fewer than 65 536 columns: *codes_out 2 nnz + 64 bytes, *base_out one int per row block; null when not codable
+int build_index_codes16(int n, long long nnz, const int *ptr_dev, const int *cols_dev, hipStream_t st, unsigned char **codes_out, int **base_out);
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols);
 constexpr int kChunkBytes = 32 * 1024;      // kind 7: preferred LDS chunk slice (4-5 work-groups per CU)
 constexpr int kMaxChunkBytes = 48 * 1024;   //         largest accepted, with 8 lanes per row (3 work-groups per CU)
@@ -116,6 +119,7 @@ struct Tuning {
     int spmv_chunked = 1;   // rows too dense for the row-block kernel: chunked row-block kernel (0 = generic kernel)
     int pad_rows = 1;       // sizes that are not whole 16-byte packs are carried with 1-3 empty rows appended (0 = as passed)
     int index_codes = 1;    // single-RHS row-block SpMV on one-byte column codes (0 = always aCols)
+    int index_codes16 = 1;  // ... and, where the matrix has more than 256 offsets, on 16-bit block-relative columns (0 = aCols then)
     int index_codes_min_mb = 32;    // ... for matrices above this size (N = 1M 7-point fp64, 83 MB: CG 35.4 -> 33.2 us/iteration; 2.56M rows
                                     // 76.4 -> 68.1; 10M 274 -> 241; smaller systems run the resident / two-launch loops, which read aCols)
     int spmv_ilv = -1;      // slice staging: value stream interleaved across lanes in 16-byte chunks (1), quads per lane (0), -1 auto

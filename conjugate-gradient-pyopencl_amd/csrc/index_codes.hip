@@ -114,4 +114,72 @@ int build_index_codes(int n, long long nnz, const int *ptr_dev, const int *cols_
     return CGAMD_OK;
 }
 
+// ---- 16-bit block-relative columns ---------------------------------------------------------------------------------------
+// For matrices with more than 256 distinct (column - row) offsets -- unstructured meshes, banded random patterns, everything a
+// Matrix-Market file may hold (reference main.c:20-33) -- whose 256-row blocks still span fewer than 65 536 columns each (any
+// matrix with a bandwidth below ~32k: a reasonable ordering of a mesh): codes16[j] = aCols[j] - base[rb(j)], base[rb] = the
+// smallest column of row block rb.  2 instead of 4 index bytes per non-zero; exact like the one-byte codes.
+__global__ __launch_bounds__(256) void rowblock_colrange_kernel(int n, const int *__restrict__ ptr, const int *__restrict__ cols, int row_blocks,
+                                                                int *__restrict__ base, int *flag) {
+    __shared__ int smin, smax;
+    const int rb = blockIdx.x;
+    if (threadIdx.x == 0) { smin = 0x7fffffff; smax = -1; }
+    __syncthreads();
+    const int p0 = ptr[rb * 256], p1 = ptr[min(rb * 256 + 256, n)];
+    int cmin = 0x7fffffff, cmax = -1;
+    for (int j = p0 + (int)threadIdx.x; j < p1; j += 256) { cmin = min(cmin, cols[j]); cmax = max(cmax, cols[j]); }
+    atomicMin(&smin, cmin);
+    atomicMax(&smax, cmax);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base[rb] = smax >= 0 ? smin : 0;
+        if (smax >= 0 && smax - smin > 65535) atomicOr(flag, 1);
+    }
+}
+__global__ __launch_bounds__(256) void index_encode16_kernel(int n, const int *__restrict__ ptr, const int *__restrict__ cols,
+                                                             const int *__restrict__ base, unsigned short *__restrict__ codes) {
+    const int rb = blockIdx.x;
+    const int p0 = ptr[rb * 256], p1 = ptr[min(rb * 256 + 256, n)], b = base[rb];
+    for (int j = p0 + (int)threadIdx.x; j < p1; j += 256) codes[j] = (unsigned short)(cols[j] - b);
+}
+
+// *codes_out (2 nnz + 64 bytes) and *base_out (row_blocks ints) are device allocations the caller frees; both null when some row
+// block spans 65 536 columns or more.  Synchronises `st`.
+int build_index_codes16(int n, long long nnz, const int *ptr_dev, const int *cols_dev, hipStream_t st, unsigned char **codes_out, int **base_out) {
+    *codes_out = nullptr;
+    *base_out = nullptr;
+    if (n <= 0 || nnz <= 0) return CGAMD_OK;
+    const int row_blocks = (n + 255) / 256;
+    int *base = nullptr, *flag = nullptr;
+    CG_HIP(hipMalloc((void **)&base, sizeof(int) * (size_t)row_blocks + 16));
+    flag = base + row_blocks;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
+    int bad = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rowblock_colrange_kernel, dim3(row_blocks), dim3(256), 0, st, n, ptr_dev, cols_dev, row_blocks, base, flag);
+        e = hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess || bad) {
+        (void)hipFree(base);
+        return e == hipSuccess ? CGAMD_OK : fail(CGAMD_ERR_HIP, std::string("build_index_codes16: ") + hipGetErrorString(e));
+    }
+    unsigned char *codes = nullptr;
+    e = hipMalloc((void **)&codes, 2 * (size_t)nnz + 64);
+    if (e == hipSuccess) e = hipMemsetAsync(codes + 2 * (size_t)nnz, 0, 64, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(index_encode16_kernel, dim3(row_blocks), dim3(256), 0, st, n, ptr_dev, cols_dev, base, reinterpret_cast<unsigned short *>(codes));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        if (codes) (void)hipFree(codes);
+        (void)hipFree(base);
+        return fail(CGAMD_ERR_HIP, std::string("build_index_codes16: ") + hipGetErrorString(e));
+    }
+    *codes_out = codes;
+    *base_out = base;
+    return CGAMD_OK;
+}
+
 }  // namespace cgamd

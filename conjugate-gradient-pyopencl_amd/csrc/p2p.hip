@@ -337,7 +337,7 @@ static int spmv_p2p_impl(const SpmvPlan &plan, int n, long long nnz, const void 
     g.x = p2p_args(e);
     g.halo = static_cast<const T *>(e.my_halo);
     g.n_local = e.n_local; g.rotate = rotate; g.push_chunks = p2p_push_chunks(e);
-    const bool coded = plan.codes && plan.codes_for == cols && tune().index_codes != 0;
+    const bool coded = plan.codes && !plan.codes16 && plan.codes_for == cols && tune().index_codes != 0;
     a.codes = coded ? plan.codes : nullptr;
     a.dict = coded ? plan.dict : nullptr;
     const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);

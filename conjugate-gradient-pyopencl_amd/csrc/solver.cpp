@@ -197,7 +197,7 @@ static int setup_resident_wide(cgamd_solver *s) {
 static int setup_index_codes(cgamd_solver *s) {
     if (s->codes) { (void)hipFree(s->codes); s->codes = nullptr; }
     if (s->dict) { (void)hipFree(s->dict); s->dict = nullptr; }
-    s->plan.codes = nullptr; s->plan.dict = nullptr; s->plan.codes_for = nullptr;
+    s->plan.codes = nullptr; s->plan.dict = nullptr; s->plan.codes_for = nullptr; s->plan.codes16 = false;
     s->n_offsets = 0;
     const size_t matrix_bytes = (size_t)s->nnz * (dtype_size(s->dtype) + 4);
     // a handle whose iterations run in the chip-wide resident loop (matrix in registers) would pay the two coding passes at every
@@ -207,7 +207,11 @@ static int setup_index_codes(cgamd_solver *s) {
         matrix_bytes <= ((size_t)s->tune.index_codes_min_mb << 20))
         return CGAMD_OK;
     if (int rc = build_index_codes(s->n, s->nnz, s->ptr, s->cols, s->ctx->stream, &s->codes, &s->dict, &s->n_offsets)) return rc;
-    if (s->codes) { s->plan.codes = s->codes; s->plan.dict = s->dict; s->plan.codes_for = s->cols; }
+    if (s->codes) { s->plan.codes = s->codes; s->plan.dict = s->dict; s->plan.codes_for = s->cols; s->plan.codes16 = false; return CGAMD_OK; }
+    // more than 256 distinct offsets (unstructured patterns, Matrix-Market inputs): 16-bit columns relative to the row block's first
+    if (s->tune.index_codes16 == 0) return CGAMD_OK;
+    if (int rc = build_index_codes16(s->n, s->nnz, s->ptr, s->cols, s->ctx->stream, &s->codes, &s->dict)) return rc;
+    if (s->codes) { s->plan.codes = s->codes; s->plan.dict = s->dict; s->plan.codes_for = s->cols; s->plan.codes16 = true; s->n_offsets = 65536; }
     return CGAMD_OK;
 }
 

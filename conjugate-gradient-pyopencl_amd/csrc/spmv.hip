@@ -164,7 +164,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     T *sv = reinterpret_cast<T *>(dyn_smem);                       // [cap]
     int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));   // [cap] (coded form: cap BYTES)
     __shared__ A red[BLOCK / kWave];
-    constexpr bool CODED = POL == -3;
+    constexpr bool CODED = POL == -3, CODED16 = POL == -4;
     __shared__ int sdict[CODED ? BLOCK : 1];
 
     const int t = threadIdx.x;
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
+    [[maybe_unused]] const int cbase = CODED16 ? a.dict[rb] : 0;      // first column of the row block (16-bit codes are relative to it)
     stage_slice<T, BLOCK, NT, POL>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc, a.codes);
     const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
     __syncthreads();
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
         for (int j = 0; j < UNROLL; ++j) {
             const int idx = min(k + j, e - 1);
             if constexpr (CODED) cj[j] = reinterpret_cast<const unsigned char *>(sc)[idx];
+            else if constexpr (CODED16) cj[j] = cbase + reinterpret_cast<const unsigned short *>(sc)[idx];
             else cj[j] = sc[idx];
             av[j] = sv[idx];
         }
@@ -238,19 +240,20 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
 // stencil / FE rows consecutive columns), the LPR partial sums meet in a shuffle tree.  The generic kernel, which these
 // matrices used before, runs the 27-point stencil at 50 % of the HBM roofline.
 // -------------------------------------------------------------------------------------------------
-template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int LPR, int UNROLL, bool CODED = false>
+template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int LPR, int UNROLL, int CODED = 0>
 __global__ __launch_bounds__(BLOCK) void spmv_rowblock_chunked_kernel(SpmvArgs<T> a) {
     using A = typename VT<T>::acc;
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     T *sv = reinterpret_cast<T *>(dyn_smem);
     int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));      // CODED: cap bytes of column codes
     __shared__ A red[BLOCK / kWave];
-    __shared__ int sdict[CODED ? BLOCK : 1];
+    __shared__ int sdict[CODED == 1 ? BLOCK : 1];
     constexpr int RC = BLOCK / LPR;                 // rows per chunk
     const int t = threadIdx.x, j = t / LPR, l = t % LPR;
-    if constexpr (CODED) sdict[t] = a.dict[t];      // visible after the first staging barrier
+    if constexpr (CODED == 1) sdict[t] = a.dict[t];      // visible after the first staging barrier
     const int rb = rowblock_of(blockIdx.x, a.row_blocks, a.cycle);
     if (rb < 0) return;
+    [[maybe_unused]] const int cbase = CODED == 2 ? a.dict[rb] : 0;
     A dot1 = vzero<A>();
     for (int c = 0; c < LPR; ++c) {
         const int c0 = rb * BLOCK + c * RC;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_chunked_kernel(SpmvArgs<T
         const int p0 = a.ptr[c0], p1 = a.ptr[min(c0 + RC, a.n)];
         const int cfirst = p0 & ~3;
         if (c) __syncthreads();                     // the previous chunk's walk is over before LDS is overwritten
-        stage_slice<T, BLOCK, NT, CODED ? -3 : -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc, a.codes);
+        stage_slice<T, BLOCK, NT, CODED == 1 ? -3 : CODED == 2 ? -4 : -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc, a.codes);
         const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
         __syncthreads();
         T sum = vzero<T>();
@@ -272,11 +275,12 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_chunked_kernel(SpmvArgs<T
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int idx = min(k + u * LPR, last);
-                if constexpr (CODED) cj[u] = reinterpret_cast<const unsigned char *>(sc)[idx];
+                if constexpr (CODED == 1) cj[u] = reinterpret_cast<const unsigned char *>(sc)[idx];
+                else if constexpr (CODED == 2) cj[u] = cbase + reinterpret_cast<const unsigned short *>(sc)[idx];
                 else cj[u] = sc[idx];
                 av[u] = sv[idx];
             }
-            if constexpr (CODED) {
+            if constexpr (CODED == 1) {
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) cj[u] = row + sdict[cj[u]];
             }
@@ -550,12 +554,12 @@ template <int BLOCK> __global__ void rowblock_halo_flag_kernel(int n, const int 
 
 // largest (4-aligned) non-zero span of any BLOCK-row slice: decides whether the fast path applies
 template <int BLOCK> __global__ void spmv_span_kernel(int n, const int *__restrict__ ptr, int row_blocks, int *out) {
-    // out[0]: span of BLOCK-row slices; out[1..3]: of BLOCK/2, BLOCK/4, BLOCK/8-row slices (chunked row-block kernel);
-    // out[4]: most non-zeros in 4 consecutive rows starting at a multiple of 4 (row-major SpMM); out[5]: longest row
-    int m[4] = {0, 0, 0, 0}, mq = 0, mr = 0;
+    // out[0]: span of BLOCK-row slices; out[1..5]: of BLOCK/2 ... BLOCK/32-row slices (chunked row-block kernel: 2 ... 32 lanes per row);
+    // out[6]: most non-zeros in 4 consecutive rows starting at a multiple of 4 (row-major SpMM); out[7]: longest row
+    int m[6] = {0, 0, 0, 0, 0, 0}, mq = 0, mr = 0;
     for (int rb = blockIdx.x * blockDim.x + threadIdx.x; rb < row_blocks; rb += gridDim.x * blockDim.x) {
 #pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
+        for (int lv = 0; lv < 6; ++lv) {
             const int rows = BLOCK >> lv;
             for (int c = 0; c < (1 << lv); ++c) {
                 const int ra = rb * BLOCK + c * rows;
@@ -568,10 +572,10 @@ template <int BLOCK> __global__ void spmv_span_kernel(int n, const int *__restri
         for (int ra = rb * BLOCK; ra < min(rb * BLOCK + BLOCK, n); ++ra) mr = max(mr, ptr[ra + 1] - ptr[ra]);
     }
 #pragma unroll
-    for (int lv = 0; lv < 4; ++lv)
+    for (int lv = 0; lv < 6; ++lv)
         if (m[lv] > 0) atomicMax(out + lv, m[lv]);
-    if (mq > 0) atomicMax(out + 4, mq);
-    if (mr > 0) atomicMax(out + 5, mr);
+    if (mq > 0) atomicMax(out + 6, mq);
+    if (mr > 0) atomicMax(out + 7, mr);
 }
 
 // cgamd_solver_iterate_timed: the next SpMV launch of this thread carries a start / stop event pair ON THE DISPATCH ITSELF
@@ -629,13 +633,18 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         // value stream interleaved across the lanes in 16-byte chunks (stage_slice_ilv): "spmv_ilv" 1/0, -1 = auto
         const bool ilv = tune().spmv_ilv >= 0 ? (tune().spmv_ilv != 0) : kIlvDefault<T>;
         // one-byte column codes instead of aCols (build_index_codes; the codes belong to THIS cols array)
-        const bool coded = ilv && nrhs == 1 && plan.codes && plan.codes_for == cols && tune().index_codes != 0;
-        a.codes = coded ? plan.codes : nullptr;
-        a.dict = coded ? plan.dict : nullptr;
-        const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
+        const bool coded_any = ilv && nrhs == 1 && plan.codes && plan.codes_for == cols && tune().index_codes != 0;
+        const bool coded = coded_any && !plan.codes16, coded16 = coded_any && plan.codes16;
+        a.codes = coded_any ? plan.codes : nullptr;
+        a.dict = coded_any ? plan.dict : nullptr;      // (16-bit form: the first column of every row block)
+        const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15)
+                                 : coded16 ? (((size_t)a.cap * (sizeof(T) + 2) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
 #define CG_RB(NT, UNR)                                                                                                  \
     do {                                                                                                                \
-        if (coded) {                                                                                                    \
+        if (coded16) {                                                                                                  \
+            if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -4>), g5, block, lds, st, a);        \
+            else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -4>), g5, block, lds, st, a);            \
+        } else if (coded) {                                                                                             \
             if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -3>), g5, block, lds, st, a);        \
             else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -3>), g5, block, lds, st, a);            \
         } else if (ilv) {                                                                                                      \
@@ -646,9 +655,12 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
             else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR>), g5, block, lds, st, a);                \
         }                                                                                                               \
     } while (0)
-#define CG_RBX(NT, UNR)      /* batch lengths 5 and 7: the two staged forms only */                                     \
+#define CG_RBX(NT, UNR)      /* batch lengths 5 and 7: the staged forms only */                                         \
     do {                                                                                                                \
-        if (coded) {                                                                                                    \
+        if (coded16) {                                                                                                  \
+            if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -4>), g5, block, lds, st, a);        \
+            else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -4>), g5, block, lds, st, a);            \
+        } else if (coded) {                                                                                             \
             if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -3>), g5, block, lds, st, a);        \
             else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -3>), g5, block, lds, st, a);            \
         } else {                                                                                                        \
@@ -663,35 +675,42 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         const int fit = plan.max_row <= 0 ? 8 : plan.max_row <= 4 ? 4 : plan.max_row == 5 ? 5 : plan.max_row <= 7 ? 7 : 8;
         const int unroll = tune().spmv_unroll ? tune().spmv_unroll : (sizeof(T) > 8 ? 4 : fit);
         if (unroll == 4) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
-        else if (unroll == 5 && (coded || ilv)) { if (nt) CG_RBX(true, 5); else CG_RBX(false, 5); }
-        else if (unroll == 7 && (coded || ilv)) { if (nt) CG_RBX(true, 7); else CG_RBX(false, 7); }
+        else if (unroll == 5 && (coded_any || ilv)) { if (nt) CG_RBX(true, 5); else CG_RBX(false, 5); }
+        else if (unroll == 7 && (coded_any || ilv)) { if (nt) CG_RBX(true, 7); else CG_RBX(false, 7); }
         else { if (nt) CG_RB(true, 8); else CG_RB(false, 8); }
 #undef CG_RB
 #undef CG_RBX
         return check_launch("spmv_rowblock");
     }
     if (vec && nrhs == 1 && plan.kind == 7 && !rb_list) {
-        const int span = plan.chunk_span[plan.lpr == 2 ? 0 : plan.lpr == 4 ? 1 : 2];
+        const int span = plan.chunk_span[plan.lpr == 2 ? 0 : plan.lpr == 4 ? 1 : plan.lpr == 8 ? 2 : plan.lpr == 16 ? 3 : 4];
         a.cap = (span + 3) & ~3;
         a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
-        const bool coded = plan.codes && plan.codes_for == cols && tune().index_codes != 0;
-        a.codes = coded ? plan.codes : nullptr;
-        a.dict = coded ? plan.dict : nullptr;
-        const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
+        const bool coded_any = plan.codes && plan.codes_for == cols && tune().index_codes != 0;
+        const bool coded = coded_any && !plan.codes16, coded16 = coded_any && plan.codes16;
+        a.codes = coded_any ? plan.codes : nullptr;
+        a.dict = coded_any ? plan.dict : nullptr;
+        const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15)
+                                 : coded16 ? (((size_t)a.cap * (sizeof(T) + 2) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
         const dim3 g7(rowblock_grid(plan.row_blocks, a.cycle));
         const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
         constexpr int U = sizeof(T) > 8 ? 4 : 8;
 #define CG_CH(NT, L)                                                                                                     \
     do {                                                                                                                  \
-        if (coded) {                                                                                                      \
-            if (fuse) hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, true, L, U, true>), g7, block, lds, st, a);   \
-            else hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, false, L, U, true>), g7, block, lds, st, a);       \
+        if (coded16) {                                                                                                    \
+            if (fuse) hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, true, L, U, 2>), g7, block, lds, st, a);      \
+            else hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, false, L, U, 2>), g7, block, lds, st, a);          \
+        } else if (coded) {                                                                                               \
+            if (fuse) hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, true, L, U, 1>), g7, block, lds, st, a);      \
+            else hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, false, L, U, 1>), g7, block, lds, st, a);          \
         } else if (fuse) hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, true, L, U>), g7, block, lds, st, a);   \
         else hipLaunchKernelGGL((spmv_rowblock_chunked_kernel<T, kBlock, NT, false, L, U>), g7, block, lds, st, a);       \
     } while (0)
         if (plan.lpr == 2) { if (nt) CG_CH(true, 2); else CG_CH(false, 2); }
         else if (plan.lpr == 4) { if (nt) CG_CH(true, 4); else CG_CH(false, 4); }
-        else { if (nt) CG_CH(true, 8); else CG_CH(false, 8); }
+        else if (plan.lpr == 8) { if (nt) CG_CH(true, 8); else CG_CH(false, 8); }
+        else if (plan.lpr == 16) { if (nt) CG_CH(true, 16); else CG_CH(false, 16); }
+        else { if (nt) CG_CH(true, 32); else CG_CH(false, 32); }
 #undef CG_CH
         return check_launch("spmv_rowblock_chunked");
     }
@@ -772,18 +791,18 @@ int validate_csr_device(int n, long long nnz, int ncols, const int *ptr_dev, con
 int compute_spmv_plan(const int *ptr_dev, const int *cols_dev, int n, int *scratch_dev, hipStream_t st, SpmvPlan *plan) {
     // (1) largest slice span -> which kernels apply, LDS size
     const int row_blocks = (n + kBlock - 1) / kBlock;
-    CG_HIP(hipMemsetAsync(scratch_dev, 0, 6 * sizeof(int), st));
+    CG_HIP(hipMemsetAsync(scratch_dev, 0, 8 * sizeof(int), st));
     int g = (row_blocks + 255) / 256;
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL((spmv_span_kernel<kBlock>), dim3(g), dim3(256), 0, st, n, ptr_dev, row_blocks, scratch_dev);
     if (int rc = check_launch("spmv_span")) return rc;
-    int spans[6] = {0, 0, 0, 0, 0, 0};
-    CG_HIP(hipMemcpyAsync(spans, scratch_dev, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
+    int spans[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    CG_HIP(hipMemcpyAsync(spans, scratch_dev, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     CG_HIP(hipStreamSynchronize(st));
     plan->max_span = spans[0];
-    plan->max_row = spans[5];
-    for (int lv = 0; lv < 3; ++lv) plan->chunk_span[lv] = spans[lv + 1];
-    plan->max_quad = spans[4];
+    plan->max_row = spans[7];
+    for (int lv = 0; lv < 5; ++lv) plan->chunk_span[lv] = spans[lv + 1];
+    plan->max_quad = spans[6];
     (void)cols_dev;
     return CGAMD_OK;
 }
@@ -817,14 +836,16 @@ void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nn
         if (nrhs == 1 && tune().spmv_chunked != 0) {
             const size_t ebytes = dtype_size(dtype) + 4;
             const size_t want = (size_t)(tune().spmv_chunk_kb > 0 ? tune().spmv_chunk_kb * 1024 : kChunkBytes);
-            for (int lv = 0; lv < 3 && kind == 0; ++lv)
+            // (16 and 32 lanes per row -- chunks of 16 / 8 rows -- take rows of ~100 entries, the upstream report's m_t1 shape: the
+            // generic kernel ran that at 6.5 % of the roofline, profiles/r3/configs_irregular.log)
+            for (int lv = 0; lv < 5 && kind == 0; ++lv)
                 if (plan->chunk_span[lv] > 0 && (size_t)plan->chunk_span[lv] * ebytes <= want) {
                     kind = 7;
                     plan->lpr = 2 << lv;
                 }
-            if (kind == 0 && plan->chunk_span[2] > 0 && (size_t)plan->chunk_span[2] * ebytes <= (size_t)kMaxChunkBytes) {
+            if (kind == 0 && plan->chunk_span[4] > 0 && (size_t)plan->chunk_span[4] * ebytes <= (size_t)kMaxChunkBytes) {
                 kind = 7;
-                plan->lpr = 8;
+                plan->lpr = 32;
             }
         }
     }

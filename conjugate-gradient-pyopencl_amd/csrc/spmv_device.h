@@ -7,6 +7,8 @@
 
 namespace cgamd {
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 // =================================================================================================
 // SpMV / SpMM, CSR-stream: a work-group owns BLOCK consecutive rows at a time.  Their non-zeros are one
 // contiguous slice of aValues/aCols, streamed with 16 B coalesced non-temporal loads (4 nnz per lane
@@ -116,7 +118,9 @@ template <> struct Chunk16<float> { using V = f32x4; };
 template <> struct Chunk16<double> { using V = f64x2; };
 template <> struct Chunk16<float2> { using V = f32x4; };
 template <> struct Chunk16<double2> { using V = f64x2; };
-template <typename T, int BLOCK, bool NT, bool FULL, bool CODED = false>
+// CODED: 0 = column indices (4 bytes), 1 = one-byte codes into the matrix's offset dictionary, 2 = 16-bit columns relative to the
+// row block's first column (index_codes.hip); the code arrays are padded, so they need no tail handling
+template <typename T, int BLOCK, bool NT, bool FULL, int CODED = 0>
 CG_DEV void stage_slice_ilv(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
                             T *sv, int *sc, const unsigned char *__restrict__ codes = nullptr) {
     using V = typename Chunk16<T>::V;
@@ -127,15 +131,21 @@ CG_DEV void stage_slice_ilv(const T *__restrict__ vals, const int *__restrict__ 
         V ch[2][NV];
         i32x4 cc[2];
         unsigned cw[2];
+        u32x2 cw2[2];
         long long ev[2][NV], qc[2];
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg) {
             const long long rbase = base + (long long)rg * 4 * BLOCK;
             qc[rg] = rbase + 4 * t;
-            if constexpr (CODED) {      // four one-byte codes per lane; the code array is padded, no tail handling
+            if constexpr (CODED == 1) {      // four one-byte codes per lane
                 if (qc[rg] < p1) {
                     const unsigned *cp = reinterpret_cast<const unsigned *>(codes + qc[rg]);
                     cw[rg] = NT ? __builtin_nontemporal_load(cp) : *cp;
+                }
+            } else if constexpr (CODED == 2) {      // four 16-bit codes per lane
+                if (qc[rg] < p1) {
+                    const u32x2 *cp = reinterpret_cast<const u32x2 *>(codes + 2 * qc[rg]);
+                    cw2[rg] = NT ? __builtin_nontemporal_load(cp) : *cp;
                 }
             } else if (qc[rg] < p1 && (FULL || qc[rg] + 4 <= nnz)) cc[rg] = ld16<i32x4, NT>(cols + qc[rg]);
 #pragma unroll
@@ -148,8 +158,10 @@ CG_DEV void stage_slice_ilv(const T *__restrict__ vals, const int *__restrict__ 
         for (int rg = 0; rg < 2; ++rg) {
             if (qc[rg] < p1) {
                 const int o = (int)(qc[rg] - cfirst);
-                if constexpr (CODED) {
+                if constexpr (CODED == 1) {
                     *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(sc) + o) = cw[rg];
+                } else if constexpr (CODED == 2) {
+                    *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned char *>(sc) + 2 * o) = cw2[rg];
                 } else if (FULL || qc[rg] + 4 <= nnz) {
                     *reinterpret_cast<i32x4 *>(sc + o) = cc[rg];
                 } else {
@@ -175,9 +187,10 @@ template <typename T> constexpr bool kIlvDefault = true;   // N=10M SpMV: f64 18
 template <typename T, int BLOCK, bool NT, int POL = -1>
 CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1, T *sv,
                         int *sc, const unsigned char *__restrict__ codes = nullptr) {
-    if (POL == -3) {       // lane-interleaved value chunks + one-byte column codes
-        if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true, true>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
-        else stage_slice_ilv<T, BLOCK, NT, false, true>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
+    if (POL == -3 || POL == -4) {       // lane-interleaved value chunks + one-byte column codes / 16-bit block-relative columns
+        constexpr int C = POL == -3 ? 1 : 2;
+        if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true, C>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
+        else stage_slice_ilv<T, BLOCK, NT, false, C>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
         return;
     }
     if (POL == -2) {       // lane-interleaved value chunks

@@ -176,6 +176,9 @@ int cgamd_solver_loop_launches(cgamd_solver *s);
  * the value is the number of distinct (column - row) offsets of the matrix (at most 256; stencil / structured-grid FE matrices
  * have 5 to 27).  Built at create / reload for matrices above 32 MB (tuning key "index_codes_min_mb"; smaller systems run
  * the resident or two-launch loops; "index_codes" 0 disables).  Exact: the kernel rebuilds the same column, results do not change by a bit.
+ * 65536: the matrix has more offsets than that, and the SpMV reads 16-bit columns relative to the first column of every 256-row block
+ * (2 index bytes per non-zero; any matrix whose row blocks span fewer than 65 536 columns each: banded random patterns, meshes in a
+ * bandwidth-reducing order, what Matrix-Market files hold; tuning key "index_codes16" 0 disables).  Exact like the one-byte form.
  * 0: the kernel reads aCols as the reference's does (kernel/real/spmv.cl:21-27). */
 int cgamd_solver_index_codes(cgamd_solver *s);
 int cgamd_transpose(cgamd_ctx *ctx, int dtype, int rows, int cols, const void *in, void *out);

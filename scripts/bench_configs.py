@@ -25,6 +25,7 @@ def run(name, indptr, indices, data, dtype, nrhs, iters=200, reps=30, b1=None):
     n = indptr.numel() - 1
     nnz = indices.numel()
     tdt = pkg.generators.torch_dtype(dtype)
+    torch.cuda.synchronize()        # (matrices built with torch ops live on torch's stream; the solver reads them on its own)
     s = pkg.Solver(ctx, n, nnz, data, indptr, indices, nrhs, flags=pkg._lib.MATRIX_ON_DEVICE | (pkg._lib.NO_GRAPH if "nograph" in sys.argv else 0), dtype=dtype)
     # b1: one right-hand side from the device generators (config 3: rhsA(500, 12)), repeated; else the CLI's b = 5 (main.c:44)
     b = b1.repeat(nrhs) if b1 is not None else torch.full((n * nrhs,), 5.0, dtype=tdt, device=dev)
@@ -110,6 +111,68 @@ if "c4" in which or "c4mfma" in which:
             print(json.dumps({"config": f"C4 SpMM MFMA row-major nrhs={nrhs} N=1M {nm}", "spmm_us": us, "spmm_gbs": sb / us / 1e3,
                               "spmm_pct_of_8tbs": 100 * sb / us / 1e3 / 8000}), flush=True)
         s.close()
+if "irregular" in which:
+    # Patterns that are NOT a stencil: generated on the device, no download.  Each line: SpMV time, the rate of
+    # the bytes the kernel moves (its own index bytes), the effective CSR rate, and which index form the handle chose
+    # (index_codes: 0 = aCols, 1..256 = one-byte codes, 65536 = 16-bit block-relative columns).
+    def csr_from_coo(rows, cols, vals, n):
+        key = rows.to(torch.int64) * n + cols.to(torch.int64)
+        key, order = torch.sort(key)
+        keep = torch.ones_like(key, dtype=torch.bool)
+        keep[1:] = key[1:] != key[:-1]                      # (generated patterns may repeat an entry: first one wins)
+        key, order = key[keep], order[keep]
+        r = (key // n).to(torch.int64)
+        ip = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        ip[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+        return ip.to(torch.int32), (key % n).to(torch.int32), vals[order].contiguous()
+
+    def spd_from_pattern(rows, cols, n, gen):
+        # symmetric pattern, off-diagonal values in (-1, -0.5), diagonal = 1e-3 - sum of the row's off-diagonals: SPD
+        rr, cc = torch.cat([rows, cols]), torch.cat([cols, rows])
+        off = rr != cc
+        rr, cc = rr[off], cc[off]
+        lo, hi = torch.minimum(rr, cc), torch.maximum(rr, cc)
+        h = (lo.to(torch.int64) * 2654435761 + hi.to(torch.int64) * 40503) % 1000003          # the same value for (i, j) and (j, i)
+        v = -(0.5 + 0.5 * (h.to(torch.float64) / 1000003.0))
+        ip, ix, da = csr_from_coo(rr, cc, v, n)
+        rowsum = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, torch.repeat_interleave(torch.arange(n, device=dev), (ip[1:] - ip[:-1]).long()), da)
+        d = torch.arange(n, device=dev)
+        return csr_from_coo(torch.cat([torch.repeat_interleave(torch.arange(n, device=dev), (ip[1:] - ip[:-1]).long()), d]),
+                            torch.cat([ix.long(), d]), torch.cat([da, 1e-3 - rowsum]), n)
+
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    # (1) the headline matrix under a random symmetric permutation: every row's neighbours are anywhere
+    ip, ix, da = pkg.generators.laplace3d(ctx, 250, 200, 200, dtype=np.float64)
+    n = ip.numel() - 1
+    perm = torch.randperm(n, device=dev, generator=gen)
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (ip[1:] - ip[:-1]).long())
+    ip2, ix2, da2 = csr_from_coo(perm[rows], perm[ix.long()], da, n)
+    del ip, ix, da, rows
+    run("irregular: 10M 7-pt Laplacian, random symmetric permutation f64", ip2, ix2, da2, np.float64, 1, iters=50, reps=10)
+    del ip2, ix2, da2
+    torch.cuda.empty_cache()
+    # (2) the report's m_t1 shape (n = 97 578, ~100 entries per row): random columns inside a band of +-5000
+    n, per = 100_000, 50
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), per)
+    cols = rows + torch.randint(-5000, 5001, (n * per,), device=dev, generator=gen)
+    cols = torch.where(cols < 0, -cols, torch.where(cols > n - 1, 2 * (n - 1) - cols, cols))      # reflected at the ends (clamping would make
+                                                                                                  # rows 0 and n - 1 hubs of thousands of entries)
+    ip, ix, da = spd_from_pattern(rows, cols, n, gen)
+    run("irregular: banded random n=100k, ~100 per row (m_t1 shape) f64", ip, ix, da, np.float64, 1, iters=200, reps=30)
+    # (3) the report's parabolic_fem shape (n = 525 825, ~7 per row): a P1 mesh pattern whose nodes are renumbered at random inside
+    # windows of 4096 -- the offsets of an unstructured mesh in a bandwidth-reducing order: hundreds of distinct ones, bounded band
+    N = 725
+    ipf, ixf, daf = pkg.generators.helm_fe_var(ctx, N, 12.0, None, 0.15, dtype=np.complex64)
+    n = N * N
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (ipf[1:] - ipf[:-1]).long())
+    win = 4096
+    keys = (torch.arange(n, device=dev) // win).to(torch.float64) + torch.rand(n, device=dev, dtype=torch.float64, generator=gen) * 0.999
+    order = torch.argsort(keys)
+    perm = torch.empty_like(order)
+    perm[order] = torch.arange(n, device=dev)
+    ip, ix, da = spd_from_pattern(perm[rows], perm[ixf.long()], n, gen)
+    del ipf, ixf, daf
+    run("irregular: mesh-like n=525k, ~7 per row, locally renumbered (parabolic_fem shape) f64", ip, ix, da, np.float64, 1, iters=200, reps=30)
 if "asprec" in which:
     # the reference's own sub-domain solve (as_prec, p_h-PY_C-CL.py:1918-1953): complex64, ~16k rows (helmFE_var(128) has the
     # pattern and size of local_rect for W_s + 2 ol = 128), n_my = 9 right-hand sides, CGMaxIT = 256 fixed iterations

@@ -5,7 +5,7 @@ parity with the oracle as everywhere else."""
 import numpy as np
 import pytest
 
-from conftest import rand_csr
+from conftest import rand_csr, rand_vec
 
 pytestmark = pytest.mark.gpu
 
@@ -17,6 +17,7 @@ def tuned(pkg):
     lib = pkg._lib.load()
     yield lambda **kv: [pkg._lib.check(lib.cgamd_tune(k.encode(), v)) for k, v in kv.items()]
     lib.cgamd_tune(b"index_codes", 1)
+    lib.cgamd_tune(b"index_codes16", 1)
     lib.cgamd_tune(b"index_codes_min_mb", 32)
     lib.cgamd_tune(b"resident", 1)
 
@@ -103,12 +104,21 @@ def test_irregular_matrices(pkg, tuned):
     import scipy.sparse as sp
     A = sp.csr_matrix((da, ix, ip), shape=(n, n))
     assert np.allclose(y1, A @ np.linspace(-1, 1, n), rtol=1e-12, atol=1e-12)
-    # scattered columns: not codable
+    # scattered columns: too many offsets for the dictionary; a system this small still gets 16-bit block-relative columns
+    # (every row block spans fewer than 65 536 columns), one whose row blocks span more keeps aCols
     ip2, ix2, da2 = rand_csr(rng, 4000, 6, np.float64, empty_rows=True)
     tuned(index_codes=1)
     k2, y2, _, _ = _run(pkg, ctx, ip2, ix2, da2, np.float64, rng.standard_normal(4000), 3)
     A2 = sp.csr_matrix((da2, ix2, ip2), shape=(4000, 4000))
-    assert k2 == 0 and np.allclose(y2, A2 @ np.linspace(-1, 1, 4000), rtol=1e-12, atol=1e-12)
+    assert k2 == 65536 and np.allclose(y2, A2 @ np.linspace(-1, 1, 4000), rtol=1e-12, atol=1e-12)
+    tuned(index_codes16=0)
+    k3, y3, _, _ = _run(pkg, ctx, ip2, ix2, da2, np.float64, rng.standard_normal(4000), 3)
+    assert k3 == 0 and np.array_equal(y3, y2)
+    tuned(index_codes16=1)
+    ip4, ix4, da4 = rand_csr(rng, 90_000, 6, np.float64)           # columns anywhere in 90 000: not codable at all
+    k4, y4, _, _ = _run(pkg, ctx, ip4, ix4, da4, np.float64, rng.standard_normal(90_000), 3)
+    A4 = sp.csr_matrix((da4, ix4, ip4), shape=(90_000, 90_000))
+    assert k4 == 0 and np.allclose(y4, A4 @ np.linspace(-1, 1, 90_000), rtol=1e-12, atol=1e-12)
     ctx.close()
 
 
@@ -208,3 +218,83 @@ def test_dense_rows_chunked_kernel(pkg, tuned, dt):
     ref = sp.csr_matrix((da.astype(np.complex128 if dt[0] == "c" else np.float64), ix, ip)) @ np.linspace(-1, 1, m ** 3).astype(dtype)
     assert np.allclose(y1, ref, rtol=1e-12 if dt == "f64" else 2e-5, atol=1e-12 if dt == "f64" else 1e-4)
     ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex64])
+@pytest.mark.parametrize("per_row", [7, 60])
+def test_block_relative_16bit_codes_are_exact(pkg, gpu, tuned, dtype, per_row):
+    """matrices with more than 256 distinct (column - row) offsets -- unstructured patterns, what Matrix-Market files hold (reference
+    main.c:20-33) -- whose 256-row blocks span fewer than 65 536 columns: the SpMV reads 16-bit columns relative to the block's first
+    column (cgamd_solver_index_codes() == 65536), also in the chunked kernel for denser rows, and rebuilds the very same column:
+    products and whole residual histories are bit-identical to the aCols kernel's."""
+    import scipy.sparse as sp
+    import torch
+    ctx, queue, kernels = gpu
+    rng = np.random.default_rng(per_row)
+    n = 30_000
+    rows = np.repeat(np.arange(n), per_row)
+    cols = rows + rng.integers(-3000, 3001, len(rows))
+    cols = np.where(cols < 0, -cols, np.where(cols > n - 1, 2 * (n - 1) - cols, cols))      # reflected at the ends: no hub rows
+    P = sp.coo_matrix((rng.uniform(-1.0, -0.5, len(rows)), (rows, cols)), shape=(n, n)).tocsr()
+    P = P + P.T
+    A = sp.csr_matrix(P + sp.diags(np.asarray(abs(P).sum(axis=1)).ravel() + 1e-2))
+    A.sort_indices()
+    ip, ix = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    da = A.data.astype(dtype) * ((1 + 0.25j) if np.dtype(dtype).kind == "c" else 1)
+    b = np.linspace(1.0, 2.0, n).astype(dtype)
+    xs = rand_vec(rng, n, dtype)
+    dev = torch.device("cuda", 0)
+
+    def run():
+        s = pkg.Solver(ctx, n, len(da), da, ip, ix, 1, dtype=dtype)
+        y = torch.empty(n, dtype=pkg.generators.torch_dtype(dtype), device=dev)
+        xt = torch.from_numpy(xs).to(dev)
+        torch.cuda.synchronize()
+        s.spmv(xt, y, fused_dot=True)
+        ctx.synchronize()
+        s.set_rhs(b, None)
+        s.iterate(25)
+        out = (s.index_codes, y.cpu().numpy(), s.history().copy(), s.x().copy())
+        s.close()
+        return out
+
+    tuned(resident=0, index_codes=1, index_codes_min_mb=0)
+    k1, y1, h1, x1 = run()
+    tuned(index_codes16=0)
+    k0, y0, h0, x0 = run()
+    tuned(index_codes16=1, resident=1, index_codes_min_mb=32)
+    assert k1 == 65536 and k0 == 0
+    assert np.array_equal(y1, y0) and np.array_equal(h1, h0, equal_nan=True) and np.array_equal(x1, x0, equal_nan=True)
+    ref = A.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64) * (((1 + 0.25j) if np.dtype(dtype).kind == "c" else 1)) @ xs
+    assert np.max(np.abs(y1 - ref)) < (1e-3 if np.dtype(dtype) == np.complex64 else 1e-9) * np.max(np.abs(ref))
+
+
+def test_matrix_market_input_reaches_the_coded_kernel(pkg, gpu, tuned, tmp_path):
+    """the documented user entry (reference main.c:20-33): a Matrix-Market file whose pattern is no stencil gets an index form too"""
+    import scipy.sparse as sp
+    ctx, queue, kernels = gpu
+    rng = np.random.default_rng(9)
+    n = 20_000
+    rows = np.repeat(np.arange(n), 5)
+    cols = rows + rng.integers(-800, 801, len(rows))
+    cols = np.where(cols < 0, -cols, np.where(cols > n - 1, 2 * (n - 1) - cols, cols))      # reflected at the ends: no hub rows
+    keep = rows > cols
+    L = sp.coo_matrix((rng.uniform(-1.0, -0.5, keep.sum()), (rows[keep], cols[keep])), shape=(n, n)).tocsr().tocoo()
+    deg = np.asarray(abs(L + L.T).sum(axis=1)).ravel()
+    p = str(tmp_path / "irregular.mtx")
+    pkg.mmio.mmwrite(p, n, np.concatenate([L.row, np.arange(n)]), np.concatenate([L.col, np.arange(n)]),
+                     np.concatenate([L.data, deg + 0.01]), "real", "symmetric")
+    n_, ip, ix, da = pkg.mmio.mmread(p)
+    tuned(resident=0, index_codes_min_mb=0)
+    try:
+        s = pkg.Solver(ctx, n_, len(da), da, ip, ix, 1, dtype=np.float64)
+        assert s.index_codes == 65536
+        b = np.linspace(1.0, 2.0, n_) * np.where(np.arange(n_) % 3 == 0, -1.0, 1.0)      # (b = 5 is an eigenvector of this matrix)
+        x, h = s.solve(b, None, 20)
+        s.close()
+    finally:
+        tuned(resident=1, index_codes_min_mb=32)
+    import cg_oracle
+    xo, ho = cg_oracle.cg(ip, ix, da, b, n_iterations=20, mode=cg_oracle.MODE_SEQUENTIAL)
+    keep = np.abs(ho[:, 0]) / np.abs(ho[0, 0]) > 1e-8
+    assert keep.sum() >= 10 and np.max(np.abs(h[keep, 0] - ho[keep, 0]) / np.abs(ho[keep, 0])) < 1e-10
