@@ -166,9 +166,9 @@ def main():
     pkg = importlib.import_module(PKG)
     lib = pkg._lib
     tune = os.environ.get("CG_TUNE", "")
-    if shared and "resident_lock" not in tune:
+    if shared and "dev.resident_lock" not in tune:
         # ranks of this job share a GPU: their slab launches must run at the same time (no per-GPU serialisation of resident launches)
-        tune = ",".join(filter(None, [tune, "resident_lock=0"]))
+        tune = ",".join(filter(None, [tune, "dev.resident_lock=0"]))
     if shared and "vec_grid" not in tune:
         # ranks sharing one GPU must leave each other's spinning work-groups room to run
         per_dev = (world + max(ndev, 1) - 1) // max(ndev, 1)

@@ -38,45 +38,41 @@ int cgamd_tune(const char *key, int value) {
     bool known = true;
     g_tune_generation.fetch_add(1, std::memory_order_relaxed);     // cached cg() handles were created under the old configuration
     tune_set([&](Tuning &g_tune) {
-    if (k == "spmv_variant") g_tune.spmv_variant = value;
-    else if (k == "spmv_nt") g_tune.spmv_nt = value;
-    else if (k == "spmv_grid") g_tune.spmv_grid = value;
-    else if (k == "vec_grid") g_tune.vec_grid = value;
-    else if (k == "vec_ppt") g_tune.vec_ppt = value;
-    else if (k == "spmv_cycle") g_tune.spmv_cycle = value;
-    else if (k == "spmv_ilv") g_tune.spmv_ilv = value;
-    else if (k == "index_codes") g_tune.index_codes = value;
+    // public keys (include/cgamd.h)
+    if (k == "index_codes") g_tune.index_codes = value;
     else if (k == "index_codes16") g_tune.index_codes16 = value;
-    else if (k == "pad_rows") g_tune.pad_rows = value;
     else if (k == "index_codes_min_mb") g_tune.index_codes_min_mb = value;
-    else if (k == "spmv_chunked") g_tune.spmv_chunked = value;
-    else if (k == "spmm_group") g_tune.spmm_group = value;
-    else if (k == "spmm_ynt") g_tune.spmm_ynt = value;
-    else if (k == "spmv_chunk_kb") g_tune.spmv_chunk_kb = value;
-    else if (k == "spmv_slice_kb") g_tune.spmv_slice_kb = value;
-    else if (k == "fold_alpha") g_tune.fold_alpha = value;
-    else if (k == "two_launch") g_tune.two_launch = value;
-    else if (k == "spmm_wide_max") g_tune.spmm_wide_max = value;
-    else if (k == "defer_x") g_tune.defer_x = value;
-    else if (k == "alpha_two_level") g_tune.alpha_two_level = value;
-    else if (k == "spmv_unroll") g_tune.spmv_unroll = value;
-    else if (k == "spmm_rb") g_tune.spmm_rb = value;
-    else if (k == "spmm_wgs") g_tune.spmm_wgs = value;
-    else if (k == "spmm_tq") g_tune.spmm_tq = value;
-    else if (k == "spmm_nq") g_tune.spmm_nq = value;
-    else if (k == "spmm_rowmajor") g_tune.spmm_rowmajor = value;
     else if (k == "resident") g_tune.resident = value;
     else if (k == "resident_min") g_tune.resident_min = value;
-    else if (k == "resident_window") g_tune.resident_window = value;
     else if (k == "resident_wide") g_tune.resident_wide = value;
-    else if (k == "resident_wide_rpt") g_tune.resident_wide_rpt = value;
     else if (k == "resident_wide_min") g_tune.resident_wide_min = value;
     else if (k == "resident_claim_ms") g_tune.resident_claim_ms = value;
-    else if (k == "resident_lock") g_tune.resident_lock = value;
-    else if (k == "slab_cus") g_tune.slab_cus = value;
-    else if (k == "resident_test_short_grid") g_tune.resident_test_short_grid = value;
+    else if (k == "two_launch") g_tune.two_launch = value;
+    else if (k == "spmm_rowmajor") g_tune.spmm_rowmajor = value;
+    else if (k == "pad_rows") g_tune.pad_rows = value;
+    else if (k == "spmv_nt") g_tune.spmv_nt = value;
     else if (k == "vec_nt") g_tune.vec_nt = value;
-    else if (k == "vec_skew") g_tune.vec_skew = value & ~15;
+    else if (k == "spmv_cycle") g_tune.spmv_cycle = value;
+    else if (k == "vec_grid") g_tune.vec_grid = value;
+    // development hooks: tests, rehearsals, profiling (not part of the documented interface)
+    else if (k == "dev.no_fold_alpha") g_tune.dev_no_fold_alpha = value;
+    else if (k == "dev.generic_spmv") g_tune.dev_generic_spmv = value;
+    else if (k == "dev.resident_lock") g_tune.resident_lock = value;
+    else if (k == "dev.slab_cus") g_tune.slab_cus = value;
+    else if (k == "dev.resident_test_short_grid") g_tune.resident_test_short_grid = value;
+    else if (k == "dev.resident_wide_rpt") g_tune.resident_wide_rpt = value;
+    else if (k == "dev.resident_window") g_tune.resident_window = value;
+    else if (k == "dev.vec_ppt") g_tune.vec_ppt = value;
+    else if (k == "dev.spmv_unroll") g_tune.spmv_unroll = value;
+    else if (k == "dev.spmv_grid") g_tune.spmv_grid = value;
+    else if (k == "dev.spmv_slice_kb") g_tune.spmv_slice_kb = value;
+    else if (k == "dev.spmv_chunk_kb") g_tune.spmv_chunk_kb = value;
+    else if (k == "dev.spmv_chunked") g_tune.spmv_chunked = value;
+    else if (k == "dev.spmm_ynt") g_tune.spmm_ynt = value;
+    else if (k == "dev.spmm_group") g_tune.spmm_group = value;
+    else if (k == "dev.spmm_rb") g_tune.spmm_rb = value;
+    else if (k == "dev.spmm_wgs") g_tune.spmm_wgs = value;
+    else if (k == "dev.spmm_wide_max") g_tune.spmm_wide_max = value;
     else known = false;
     });
     if (!known) return fail(CGAMD_ERR_INVALID, "tune: unknown key " + k);

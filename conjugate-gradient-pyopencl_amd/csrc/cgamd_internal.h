@@ -74,59 +74,48 @@ constexpr int kMaxSpmmSliceBytes = 64 * 1024;   // SpMM forms (nRHS > 1, row-maj
 constexpr int kMaxSliceBytes = 40 * 1024;   // variant 5: largest 256-row LDS slice (4 work-groups per CU); denser rows -> chunked kernel.
                                             // 27-point f32 (55 KB): 114 us one lane per row, 91 us chunked; 7-point c128 (36 KB): 314 vs 357
 
-// run-time tuning knobs (cgamd_tune); defaults are the shipped configuration
+// run-time tuning (cgamd_tune); defaults are the shipped configuration.  PUBLIC keys (include/cgamd.h): the 15
+// of the first block.  The second block are development hooks (key prefix "dev."): what the tests need to force a loop family or a
+// failure, and rehearsal switches; experiments that were decided have no knob any more.
 struct Tuning {
-    int spmv_variant = 5;   // 5 = row-block kernel (matrix through LDS, one row block per work-group), 0 = generic chunked
-    int spmv_nt = -1;       // non-temporal matrix loads: 1 on, 0 off, -1 auto = on unless the matrix fits the 256 MB Infinity
-                            // Cache (below that the re-used matrix is served from the cache; finalize_spmv_plan)
-    int spmv_unroll = 0;    // row walk: LDS reads + gathers in flight per lane (4 or 8; 0 = 8, or 4 for 16-byte values)
-    int spmm_ynt = -1;      // row-major SpMM y stores: 0 plain, 1 non-temporal, 2 write-through sc1 (-1 = default: 2)
-    int spmm_group = 0;     // SpMM: right-hand sides per register group (0 = equal-width groups of at most 8, 4 for complex128)
-    int spmm_rb = 0;        // SpMM: right-hand sides per launch (0 = all in one launch)
-    int spmm_wgs = 0;       // row-major SpMM sweep: work-groups per XCD (0 = 64: 256 strips of 16 rows open per XCD)
-    int spmm_tq = 0;        // fp64 row-major SpMM: 8 = always the generic 8-K-steps-per-quad instance (experiment)
-    int spmm_nq = 0;        // fp64 row-major SpMM: 2 = 8-row strips where they fit (experiment; default 16-row strips)
-    int spmm_rowmajor = 1;  // 1: solvers keep the block row-major where that loop is the faster one (f64 x 32); 2: for every supported type
-                            // (f32 16/32/64, f64 16/32, complex64 16/32); 0: never
-                            // and multiply on the matrix cores (0 = RHS-major VALU kernel as for every other width)
-    int vec_skew = 0;       // bytes added to the pitch between the solver's vectors (multiple of 16)
-    int vec_nt = -1;        // -1 auto (by working-set size, finalize_spmv_plan); axpy2_dot: bit0 = x loaded/stored non-temporally (touched once per iteration), bit1 = q loaded
-                            // non-temporally (its last use): d and r, which are re-read, keep the caches; measured -10..-22 us/iteration
-    int alpha_two_level = 1; // cg_alpha over >= 16384 partials: 32 work-groups + last-arrival combine (0 = one work-group)
-    int defer_x = 1;        // fused loop: x += alpha d rides in the aypx launch (10 vector passes per iteration instead of 11)
-    int fold_alpha = 1;     // small systems (<= 2048 d.q partials): alpha in the prologue of axpy2_dot, three launches per iteration
-    int two_launch = 1;     // ... and beta / d = beta d + r inside the next SpMV launch: two launches per iteration
-    int resident = 1;       // systems of at most 32768 rows (a group of 1024-row work-groups inside one XCD) whose matrix slices fit LDS:
-                            // all iterations of an iterate() call in ONE launch (resident.hip); 0 = never, 2 = always in the cross-XCD
-                            // form (write-through stores; up to 65536 rows; slower than launches, kept for the any-placement tests)
-    int resident_min = 8;   // ... for iterate() calls of at least this many iterations
-    int resident_wide = 1;  // single right-hand side, systems the one-XCD loop cannot hold (rows of <= 8 entries, <= 256 work-groups of 2048 /
-                            // 4096 rows: up to ~1M rows): one chip-wide resident group, matrix in registers; 0 = launched loops
-    int resident_wide_min = 16; // ... for iterate() calls of at least this many iterations (a launch costs ~70-150 us of set-up: break-even
-                               // against the launched loops at 4 / 12 / 24 iterations for 1M / 250k / 90k rows, scripts/short_calls.py)
-    int resident_claim_ms = 200;   // resident loops: how long a call waits for the GPU's resident-launch lock, and work-groups for their group to fill (CUs held by other kernels), before the
-                               // launch gives up untouched and the handle goes back to the launched loops
-    int slab_cus = 0;              // slab loop: CUs (= members at most) a handle may use; 0 = all of the device's (ranks that share a GPU in a
-                                   // rehearsal must fit side by side)
-    int resident_lock = 1;         // 0: no per-GPU serialisation of resident launches (ranks of ONE job that share a GPU in a rehearsal must run
-                                   // their slab launches at the same time; never needed with one rank per GPU)
-    int resident_test_short_grid = 0; // test hook: launch one work-group too few, so that no group can fill
-    int resident_wide_rpt = 0; // rows per thread of the chip-wide loop: 0 = the smallest that fits (4, then 8), or 4 / 8
-    int resident_window = 1; // ... staging the column range of a member's rows in LDS once per iteration (0 = per-non-zero gathers)
-    int spmm_wide_max = -1; // multi-RHS, RHS-major: largest row_blocks x nRHS for the one-work-group-per-RHS form (-1 = 4096, 0 = never)
-    int spmv_slice_kb = 0;  // largest 256-row LDS slice the one-lane-per-row kernel accepts, in KB (0 = kMaxSliceBytes)
-    int spmv_chunk_kb = 0;  // chunked row-block kernel: preferred LDS chunk in KB (0 = kChunkBytes); smaller -> more lanes per row
-    int spmv_chunked = 1;   // rows too dense for the row-block kernel: chunked row-block kernel (0 = generic kernel)
-    int pad_rows = 1;       // sizes that are not whole 16-byte packs are carried with 1-3 empty rows appended (0 = as passed)
+    // ---- public
     int index_codes = 1;    // single-RHS row-block SpMV on one-byte column codes (0 = always aCols)
     int index_codes16 = 1;  // ... and, where the matrix has more than 256 offsets, on 16-bit block-relative columns (0 = aCols then)
-    int index_codes_min_mb = 32;    // ... for matrices above this size (N = 1M 7-point fp64, 83 MB: CG 35.4 -> 33.2 us/iteration; 2.56M rows
-                                    // 76.4 -> 68.1; 10M 274 -> 241; smaller systems run the resident / two-launch loops, which read aCols)
-    int spmv_ilv = -1;      // slice staging: value stream interleaved across lanes in 16-byte chunks (1), quads per lane (0), -1 auto
+    int index_codes_min_mb = 32;    // ... for matrices above this size (smaller systems run the resident / two-launch loops, which read aCols)
+    int resident = 1;       // systems of at most 32768 rows whose matrix slices fit LDS: all iterations of an iterate() call in ONE launch
+                            // (resident.hip); 0 = never, 2 = always in the cross-XCD form (up to 65536 rows; for the any-placement tests)
+    int resident_min = 8;   // ... for iterate() calls of at least this many iterations
+    int resident_wide = 1;  // systems the one-XCD loop cannot hold (rows of <= 10 entries, up to ~1M rows): chip-wide resident groups; 0 = launched
+    int resident_wide_min = 16; // ... for iterate() calls of at least this many iterations (also the slab loop's threshold, slab.hip)
+    int resident_claim_ms = 200;   // resident loops: how long a call waits for the GPU's resident-launch lock, and work-groups for their group to
+                               // fill (CUs held by other kernels), before the launch gives up untouched and the handle takes the launched loops
+    int two_launch = 1;     // small systems: beta / d = beta d + r inside the next SpMV launch, two launches per iteration (0 = three / four)
+    int spmm_rowmajor = 1;  // 1: solvers keep the block row-major where that loop is the faster one (f64 x 32); 2: for every supported type
+                            // (f32 16/32/64, f64 16/32, complex64 16/32); 0: never
+    int pad_rows = 1;       // sizes that are not whole 16-byte packs are carried with 1-3 empty rows appended (0 = as passed)
+    int spmv_nt = -1;       // non-temporal matrix loads: 1 on, 0 off, -1 auto = on unless the matrix fits the 256 MB Infinity Cache
+    int vec_nt = -1;        // -1 auto (by working-set size); bit0 = x loaded/stored non-temporally, bit1 = q loaded non-temporally
     int spmv_cycle = 64;    // row-block schedule: block-cyclic over the XCDs, cycle length in row blocks (1 = contiguous eighths)
-    int spmv_grid = 0;      // generic kernel: 0 = auto (<= kMaxGrid persistent work-groups)
-    int vec_grid = 0;       // vector kernels: 0 = auto
-    int vec_ppt = 0;        // vector kernels: 16-byte packs per thread the grid is sized for (0 = by size: 1, 2 or 4)
+    int vec_grid = 0;       // vector kernels: work-groups, 0 = auto
+    // ---- development hooks ("dev." keys): tests, rehearsals, profiling
+    int dev_no_fold_alpha = 0;      // 1: small systems keep the separate cg_alpha launch (the four-launch family at sizes that would fold it)
+    int dev_generic_spmv = 0;       // 1: the generic chunked CSR stream for every matrix (the row-block kernels' fallback, tested against them)
+    int resident_lock = 1;          // 0: no per-GPU serialisation of resident launches (ranks of ONE job sharing a GPU in a rehearsal)
+    int slab_cus = 0;               // slab loop: CUs (= members at most) a handle may use; 0 = all (ranks that share a GPU must fit side by side)
+    int resident_test_short_grid = 0; // launch one work-group too few, so that no group can fill (the untouched-fallback tests)
+    int resident_wide_rpt = 0;      // rows per thread of the chip-wide loop: 0 = the smallest that fits (4, then 8), or 4 / 8
+    int resident_window = 1;        // one-XCD resident loop: stage the column range of a member's rows in LDS (0 = per-non-zero gathers)
+    int vec_ppt = 0;                // vector kernels: 16-byte packs per thread the grid is sized for (0 = by size: 1, 2 or 4)
+    int spmv_unroll = 0;            // row walk: gathers in flight per lane (0 = fitted to the longest row)
+    int spmv_grid = 0;              // generic kernel: work-groups, 0 = auto
+    int spmv_slice_kb = 0;          // largest 256-row LDS slice the one-lane-per-row kernel accepts, in KB (0 = kMaxSliceBytes)
+    int spmv_chunk_kb = 0;          // chunked row-block kernel: preferred LDS chunk in KB (0 = kChunkBytes)
+    int spmv_chunked = 1;           // rows too dense for the row-block kernel: chunked row-block kernel (0 = generic kernel)
+    int spmm_ynt = -1;              // row-major SpMM y stores: 0 plain, 1 non-temporal, 2 write-through sc1 (-1 = default: 2)
+    int spmm_group = 0;             // SpMM: right-hand sides per register group (0 = equal-width groups of at most 8, 4 for complex128)
+    int spmm_rb = 0;                // SpMM: right-hand sides per launch (0 = all in one launch)
+    int spmm_wgs = 0;               // row-major SpMM sweep: work-groups per XCD (0 = 64)
+    int spmm_wide_max = -1;         // multi-RHS, RHS-major: largest row_blocks x nRHS for the one-work-group-per-RHS form (-1 = 4096, 0 = never)
 };
 // g_tune is the process-wide configuration cgamd_tune edits (under a mutex).  Nothing on a compute path reads it
 // directly: every solver / distributed handle copies it at creation (tune_snapshot()), and each C-ABI entry installs the

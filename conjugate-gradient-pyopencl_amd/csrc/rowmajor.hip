@@ -523,8 +523,8 @@ template <typename K> static int rm_blocks_per_cu(K kernel) {
 struct RmInstance { int tq, nq, rows, per_cu; };
 template <typename T, int NH, bool CPLX> static RmInstance rm_instance(int max_quad, bool dot) {
     RmInstance r;
-    const bool tq5 = max_quad > 0 && max_quad <= 20 && tune().spmm_tq != 8;
-    const bool nq2 = sizeof(T) == 8 && tq5 && tune().spmm_nq == 2;
+    const bool tq5 = max_quad > 0 && max_quad <= 20;
+    constexpr bool nq2 = false;       // (8-row strips at 4 waves per SIMD: measured 3 % faster stand-alone, slower inside CG; dropped)
     r.tq = tq5 ? 5 : 8; r.nq = nq2 ? 2 : 4; r.rows = 4 * r.nq;
 #define CG_OCC(TQ, NQ) (dot ? rm_blocks_per_cu(spmm_rm_kernel<T, NH, TQ, NQ, CPLX, true>) : rm_blocks_per_cu(spmm_rm_kernel<T, NH, TQ, NQ, CPLX, false>))
     if constexpr (sizeof(T) == 8) r.per_cu = nq2 ? CG_OCC(5, 2) : tq5 ? CG_OCC(5, 4) : CG_OCC(8, 4);

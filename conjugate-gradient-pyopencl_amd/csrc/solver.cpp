@@ -50,7 +50,6 @@ struct cgamd_solver {
     hipGraph_t g1g[2] = {nullptr, nullptr}, gUg[2] = {nullptr, nullptr};
     int U = 8;
     bool graph_failed = false;
-    bool defer_x = true;    // x += alpha d in the aypx launch (fixed at creation: captured graphs depend on it)
     // row-major multi-RHS path (rowmajor.hip): x, r, d, q, b hold [n][nrhs]; rm_ok is decided at creation, `rm` per set_rhs
     bool rm_ok = false, rm = false;
     int rm_nwg = 0, rm_vgrid = 0;
@@ -154,16 +153,12 @@ static int enqueue_iteration(cgamd_solver *s, int k, hipStream_t st) {
         if ((rc = enqueue_spmv(s, k, st))) return rc;
         const bool fold = fold_alpha_ok(s->plan.n_partials);      // small system: alpha in the next launch's prologue
         if (!fold && (rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
-        if (s->defer_x) {     // r -= alpha q (+ r.r) ; then beta, x += alpha d, d = beta d + r : 3 + 5 vector passes
-            if (fold) rc = launch_axpy_dot_alpha(dt, n, s->q, s->r, n, s->part_dq, s->plan.n_partials, s->sc, nr, s->part_rr, s->vgrid, st);
-            else rc = launch_axpy_dot(dt, n, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
-            if (rc) return rc;
-            return launch_aypx_beta_x(dt, n, s->r, s->d, s->x, n, s->part_rr, s->vgrid, nr, s->sc, st, s->plan.vec_nt);
-        }
-        if (fold) rc = launch_axpy2_dot_alpha(dt, n, s->d, s->x, s->q, s->r, n, s->part_dq, s->plan.n_partials, s->sc, nr, s->part_rr, s->vgrid, st);
-        else rc = launch_axpy2_dot(dt, n, s->d, s->x, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
+        // r -= alpha q (+ r.r) ; then beta, x += alpha d, d = beta d + r : 3 + 5 vector passes (x is read by nothing inside the loop, so
+        // its update rides in the aypx launch, which reads d anyway)
+        if (fold) rc = launch_axpy_dot_alpha(dt, n, s->q, s->r, n, s->part_dq, s->plan.n_partials, s->sc, nr, s->part_rr, s->vgrid, st);
+        else rc = launch_axpy_dot(dt, n, s->q, s->r, n, s->sc.alpha, nr, s->part_rr, s->vgrid, st, s->plan.vec_nt);
         if (rc) return rc;
-        return launch_aypx_beta(dt, n, s->r, s->d, n, s->part_rr, s->vgrid, nr, s->sc, st);
+        return launch_aypx_beta_x(dt, n, s->r, s->d, s->x, n, s->part_rr, s->vgrid, nr, s->sc, st, s->plan.vec_nt);
     }
     if ((rc = enqueue_spmv(s, k, st))) return rc;
     if ((rc = launch_dot_partials(dt, n, s->d, s->q, n, nr, s->part_rr, s->vgrid, st))) return rc;
@@ -293,7 +288,6 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     s->tune = tune_snapshot();
     TuneScope ts(&s->tune);
     s->ctx = ctx; s->dtype = dtype; s->n = size; s->n_user = size; s->nnz = nnz; s->nrhs = nRHS; s->flags = flags;
-    s->defer_x = tune().defer_x != 0;
     // Row-major block + matrix-core SpMM inside the loop: by default only where the whole iteration is faster than the RHS-major
     // one (measured in one process at N = 1M, profiles/r2_experiments/spmm_ab12.log: f64 x 32 +8 %; f64 x 16, f32 x 32 equal within
     // 1 %, complex64 x 16 slower).  spmm_rowmajor = 2 takes it for every supported type, 0 never.
@@ -352,8 +346,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     {
         // the five vectors live in one slab, each at a 4 KiB-aligned offset plus a per-vector skew: the update kernels
         // stream up to four of them in lock-step, and equal strides between them alias onto the same HBM channels
-        const size_t skew = (size_t)(tune().vec_skew >= 0 ? tune().vec_skew : 0);
-        const size_t pitch = ((vbytes + 4095) & ~(size_t)4095) + skew;
+        const size_t pitch = (vbytes + 4095) & ~(size_t)4095;
         if (!rc) rc = dmalloc(&s->slab, pitch * 6 + 4096, "vectors");
         if (!rc && n_int != size && hipMemsetAsync(s->slab, 0, pitch * 6 + 4096, ctx->stream) != hipSuccess)     // the padding rows of b
             rc = fail(CGAMD_ERR_HIP, "hipMemsetAsync(vectors)");
@@ -834,7 +827,7 @@ long long cgamd_solver_spmv_moved_bytes(cgamd_solver *s) {
 long long cgamd_solver_iter_moved_bytes(cgamd_solver *s) {
     if (!s) return 0;
     const long long V = (long long)dtype_size(s->dtype);
-    const long long passes = (s->flags & CGAMD_UNFUSED) ? 14 : s->mdiag ? 12 : (s->defer_x || s->rm || fused2_now(s)) ? 10 : 11;
+    const long long passes = (s->flags & CGAMD_UNFUSED) ? 14 : s->mdiag ? 12 : 10;
     return s->nnz * (V + index_bytes_per_nnz(s)) + ((long long)s->n_user + 1) * 4 + passes * s->n_user * V * s->nrhs;
 }
 

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs<T> a) {
 //     (profiles/r1_experiments/ab*.log, pmc_*_summary.txt).
 // LDS is sized at launch from the plan's largest slice (values + columns).
 // -------------------------------------------------------------------------------------------------
-template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL, int POL = -1>
+template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL, int POL = -2>
 __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
     using A = typename VT<T>::acc;
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
@@ -630,32 +630,16 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         dim3 g5(rb_list ? (rb_count > 0 ? rb_count : 1) : rowblock_grid(plan.row_blocks, a.cycle), nrhs);
         if (rb_list && rb_count <= 0) return CGAMD_OK;
         const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
-        // value stream interleaved across the lanes in 16-byte chunks (stage_slice_ilv): "spmv_ilv" 1/0, -1 = auto
-        const bool ilv = tune().spmv_ilv >= 0 ? (tune().spmv_ilv != 0) : kIlvDefault<T>;
+        // (the value stream is staged interleaved across the lanes in 16-byte chunks, stage_slice_ilv: N=10M SpMV f64 186 -> 165 us,
+        // c64 186 -> 166, c128 435 -> 314, f32 109 -> 105; the plain staging has no instance any more)
         // one-byte column codes instead of aCols (build_index_codes; the codes belong to THIS cols array)
-        const bool coded_any = ilv && nrhs == 1 && plan.codes && plan.codes_for == cols && tune().index_codes != 0;
+        const bool coded_any = nrhs == 1 && plan.codes && plan.codes_for == cols && tune().index_codes != 0;
         const bool coded = coded_any && !plan.codes16, coded16 = coded_any && plan.codes16;
         a.codes = coded_any ? plan.codes : nullptr;
         a.dict = coded_any ? plan.dict : nullptr;      // (16-bit form: the first column of every row block)
         const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15)
                                  : coded16 ? (((size_t)a.cap * (sizeof(T) + 2) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
 #define CG_RB(NT, UNR)                                                                                                  \
-    do {                                                                                                                \
-        if (coded16) {                                                                                                  \
-            if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -4>), g5, block, lds, st, a);        \
-            else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -4>), g5, block, lds, st, a);            \
-        } else if (coded) {                                                                                             \
-            if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -3>), g5, block, lds, st, a);        \
-            else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -3>), g5, block, lds, st, a);            \
-        } else if (ilv) {                                                                                                      \
-            if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -2>), g5, block, lds, st, a);        \
-            else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR, -2>), g5, block, lds, st, a);            \
-        } else {                                                                                                        \
-            if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR>), g5, block, lds, st, a);            \
-            else CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, false, UNR>), g5, block, lds, st, a);                \
-        }                                                                                                               \
-    } while (0)
-#define CG_RBX(NT, UNR)      /* batch lengths 5 and 7: the staged forms only */                                         \
     do {                                                                                                                \
         if (coded16) {                                                                                                  \
             if (fuse) CG_LAUNCH_EV((spmv_rowblock_kernel<T, kBlock, NT, true, UNR, -4>), g5, block, lds, st, a);        \
@@ -675,11 +659,10 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         const int fit = plan.max_row <= 0 ? 8 : plan.max_row <= 4 ? 4 : plan.max_row == 5 ? 5 : plan.max_row <= 7 ? 7 : 8;
         const int unroll = tune().spmv_unroll ? tune().spmv_unroll : (sizeof(T) > 8 ? 4 : fit);
         if (unroll == 4) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
-        else if (unroll == 5 && (coded_any || ilv)) { if (nt) CG_RBX(true, 5); else CG_RBX(false, 5); }
-        else if (unroll == 7 && (coded_any || ilv)) { if (nt) CG_RBX(true, 7); else CG_RBX(false, 7); }
+        else if (unroll == 5) { if (nt) CG_RB(true, 5); else CG_RB(false, 5); }
+        else if (unroll == 7) { if (nt) CG_RB(true, 7); else CG_RB(false, 7); }
         else { if (nt) CG_RB(true, 8); else CG_RB(false, 8); }
 #undef CG_RB
-#undef CG_RBX
         return check_launch("spmv_rowblock");
     }
     if (vec && nrhs == 1 && plan.kind == 7 && !rb_list) {
@@ -822,7 +805,7 @@ void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nn
     if (tune().vec_nt >= 0) plan->vec_nt = tune().vec_nt;
     else if (!plan->nt) plan->vec_nt = (matrix_bytes + 5 * vector_bytes <= 200 * MB) ? 0 : 3;
     else plan->vec_nt = (matrix_bytes <= 512 * MB) ? 0 : 3;
-    int kind = tune().spmv_variant;
+    int kind = tune().dev_generic_spmv ? 0 : 5;
     const bool vec = aligned16(vals) && aligned16(cols);
     if (!vec || plan->max_span <= 0) kind = 0;
     plan->lpr = 1;

@@ -64,52 +64,9 @@ inline int rowblock_grid(int row_blocks, int cycle) {
     return per_xcd * 8;
 }
 
-// 4 consecutive matrix entries (values + columns) starting at the 4-aligned entry q: 16-byte loads.  FULL = the
-// caller knows q + 4 <= nnz; otherwise the guarded scalar path covers the last, partial quad of the matrix.
-template <typename T, bool NT, bool FULL> CG_DEV void load_quad(const T *__restrict__ vals, const int *__restrict__ cols,
-                                                                long long nnz, long long q, T (&v)[4], int (&c)[4]) {
-    if (FULL || q + 4 <= nnz) {
-        ld4<NT>(vals + q, v);
-        const i32x4 cc = ld16<i32x4, NT>(cols + q);
-        c[0] = cc.x; c[1] = cc.y; c[2] = cc.z; c[3] = cc.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool ok = q + k < nnz;
-            v[k] = ok ? vals[q + k] : vzero<T>();
-            c[k] = ok ? cols[q + k] : 0;
-        }
-    }
-}
-
-// Park the slice [cfirst, p1) of aValues/aCols raw in LDS.  Every lane issues the loads of TWO quads before it
-// waits for either (a plain loop made hipcc wait for quad 1 before issuing quad 2: one more dependent HBM
-// round trip per work-group, and the work-group's lifetime is a chain of such round trips).
-template <typename T, int BLOCK, bool NT, bool FULL>
-CG_DEV void stage_slice_impl(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1,
-                             T *sv, int *sc) {
-    const int t = threadIdx.x;
-    for (long long base = cfirst; base < p1; base += 8 * BLOCK) {
-        const long long q0 = base + 4 * t, q1 = q0 + 4 * BLOCK;
-        const bool h0 = q0 < p1, h1 = q1 < p1;
-        T v0[4], v1[4];
-        int c0[4], c1[4];
-        if (h0) load_quad<T, NT, FULL>(vals, cols, nnz, q0, v0, c0);
-        if (h1) load_quad<T, NT, FULL>(vals, cols, nnz, q1, v1, c1);
-        if (h0) {
-            const int o = (int)(q0 - cfirst);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { sv[o + k] = v0[k]; sc[o + k] = c0[k]; }
-        }
-        if (h1) {
-            const int o = (int)(q1 - cfirst);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { sv[o + k] = v1[k]; sc[o + k] = c1[k]; }
-        }
-    }
-}
-// Same job with the VALUE stream interleaved across the lanes in 16-byte chunks: chunk k of a lane is chunk k*64 + lane of
-// its wave's 256-entry span, so every load instruction of a wave covers one contiguous 1 KB (the plain version above gives
+// Park the slice [cfirst, p1) of aValues/aCols in LDS with the VALUE stream interleaved across the lanes in 16-byte chunks:
+// chunk k of a lane is chunk k*64 + lane of
+// its wave's 256-entry span, so every load instruction of a wave covers one contiguous 1 KB (a quad-per-lane mapping gives
 // a lane 4 consecutive entries = 16/32/64 contiguous bytes, and each of its 1/2/4 load instructions touches every cache
 // line of the span partially).  With non-temporal loads the partially used lines of complex128 were fetched again by the
 // later instructions: 435 -> 313 us for the N=10M SpMV.  Columns (4 B) keep the quad mapping: one 16-byte load per lane.
@@ -183,25 +140,15 @@ CG_DEV void stage_slice_ilv(const T *__restrict__ vals, const int *__restrict__ 
     }
 }
 
-template <typename T> constexpr bool kIlvDefault = true;   // N=10M SpMV: f64 186 -> 165 us, c64 186 -> 166, c128 435 -> 314, f32 109 -> 105 (ab_ilv.log)
-template <typename T, int BLOCK, bool NT, int POL = -1>
+// POL: -2 = column indices, -3 = one-byte column codes, -4 = 16-bit block-relative columns.  Only the work-group that owns the very end
+// of the matrix can meet a partial quad: block-uniform branch, so the common path carries no per-lane tail handling (whose control flow
+// made hipcc serialise the loads).
+template <typename T, int BLOCK, bool NT, int POL = -2>
 CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols, long long nnz, int cfirst, int p1, T *sv,
                         int *sc, const unsigned char *__restrict__ codes = nullptr) {
-    if (POL == -3 || POL == -4) {       // lane-interleaved value chunks + one-byte column codes / 16-bit block-relative columns
-        constexpr int C = POL == -3 ? 1 : 2;
-        if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true, C>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
-        else stage_slice_ilv<T, BLOCK, NT, false, C>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
-        return;
-    }
-    if (POL == -2) {       // lane-interleaved value chunks
-        if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true>(vals, cols, nnz, cfirst, p1, sv, sc);
-        else stage_slice_ilv<T, BLOCK, NT, false>(vals, cols, nnz, cfirst, p1, sv, sc);
-        return;
-    }
-    // only the work-group that owns the very end of the matrix can meet a partial quad: block-uniform branch,
-    // so the common path carries no per-lane tail handling (whose control flow made hipcc serialise the loads)
-    if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_impl<T, BLOCK, NT, true>(vals, cols, nnz, cfirst, p1, sv, sc);
-    else stage_slice_impl<T, BLOCK, NT, false>(vals, cols, nnz, cfirst, p1, sv, sc);
+    constexpr int C = POL == -3 ? 1 : POL == -4 ? 2 : 0;
+    if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true, C>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
+    else stage_slice_ilv<T, BLOCK, NT, false, C>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
 }
 
 }  // namespace cgamd

@@ -753,7 +753,7 @@ int launch_aypx_beta_x(int dtype, int n, const void *x, void *y, void *xs, long 
     const int vnt = tune().vec_nt >= 0 ? tune().vec_nt : vec_nt;
     CG_DISPATCH(dtype, aypx_beta_x_impl, n, x, y, xs, ld, partials, P, nrhs, sc, v, vnt, st);
 }
-bool fold_alpha_ok(int n_partials) { return tune().fold_alpha != 0 && n_partials <= kFoldAlphaMax; }
+bool fold_alpha_ok(int n_partials) { return tune().dev_no_fold_alpha == 0 && n_partials <= kFoldAlphaMax; }
 int launch_axpy2_dot_alpha(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *part_dq,
                            int P, const CgScalars &sc, int nrhs, void *partials, int grid, hipStream_t st) {
     const bool vec = vec_ok(dtype, ld, nrhs, {d, x, q, r});
@@ -776,7 +776,7 @@ int launch_cg_delta0(int dtype, const void *partials, int grid, int nrhs, const 
 }
 template <typename T> static int alpha_impl(const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
     using A = typename VT<T>::acc;
-    if (s.stage && s.ticket && grid >= 16384 && tune().alpha_two_level != 0)
+    if (s.stage && s.ticket && grid >= 16384)
         hipLaunchKernelGGL((cg_alpha2_kernel<T>), dim3(kAlphaParts, nrhs), dim3(kScalarBlock), 0, st, static_cast<const A *>(partials),
                            grid, nrhs, (const T *)s.delta, (T *)s.alpha, s.iter, (A *)s.stage, s.ticket);
     else

@@ -50,13 +50,13 @@ const char *cgamd_last_error(void);
 int cgamd_version(void);
 size_t cgamd_dtype_size(int dtype);
 
-/* run-time tuning knobs (A/B experiments and profiling; the defaults are the shipped configuration, -1 = decided per
- * solver): "spmv_variant" (5 = row-block kernel, 0 = generic chunked kernel), "spmv_nt" / "vec_nt" (non-temporal matrix
- * stream / streaming hints of the vector kernels, default -1: by working-set size), "spmv_ilv" (slice staging interleaved
- * across lanes, default on), "spmv_cycle" (block-cyclic schedule over the 8 XCDs, cycle length in row blocks, default
- * 64), "spmv_unroll", "alpha_two_level", "fold_alpha" (alpha in the prologue of the r update for small systems),
- * "defer_x" (x += alpha d in the aypx launch), "spmv_grid" / "vec_grid" (0 = auto).  Read when a solver is created or
- * at launch; not synchronised with running solvers. */
+/* run-time configuration: 15 keys (INTEGRATION.md section 6 has the table).  Loop selection: "resident" (1; 0 = launched loops
+ * only, 2 = cross-XCD form), "resident_min" (8), "resident_wide" (1), "resident_wide_min" (16), "resident_claim_ms" (200),
+ * "two_launch" (1), "spmm_rowmajor" (1; 2 = every supported width, 0 = never).  Matrix stream: "index_codes" (1),
+ * "index_codes16" (1), "index_codes_min_mb" (32), "pad_rows" (1).  Placement / cache policy: "spmv_nt", "vec_nt" (-1 = by
+ * working-set size), "spmv_cycle" (64 row blocks per XCD turn), "vec_grid" (0 = auto).  A handle keeps the configuration it
+ * was created under (snapshot at create); the call is thread-safe.  Unknown key: CGAMD_ERR_INVALID.  Keys that start with
+ * "dev." are test / rehearsal hooks of this repository's own suite and scripts, not part of the interface. */
 int cgamd_tune(const char *key, int value);
 
 /* ---- devices / context (reference cl.py:16-31) -------------------------- */
@@ -128,7 +128,12 @@ int cgamd_solver_reload_matrix(cgamd_solver *s, const void *aValues, const int *
 /* b, x0: nRHS*size values, host (on_device=0) or device (on_device=1) memory; x0 may be NULL (zeros).
  * Computes r = b - A x0, d = r, delta0 = r.r  (reference clcg.c:255-292) and resets the iteration count. */
 int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_device);
-/* enqueue exactly nIterations iterations (reference clcg.c:297-419); asynchronous, no host sync */
+/* Run exactly nIterations iterations (reference clcg.c:297-419).  Handles on a LAUNCHED loop (cgamd_solver_loop_launches() >= 2)
+ * only enqueue: asynchronous, no host sync.  Handles on a RESIDENT loop (loop_launches() 0 or 1, calls of at least
+ * "resident_min" / "resident_wide_min" iterations) synchronise: the call takes the GPU's resident-launch lock (one resident
+ * grid per GPU at a time, across processes; at most "resident_claim_ms" of waiting), launches, and waits for the kernel before
+ * it releases the lock -- so it returns with the iterations done.  When the lock or the CUs cannot be had in that time the call
+ * runs the same iterations on the handle's launched loop instead (asynchronous again); results are those of that loop. */
 int cgamd_solver_iterate(cgamd_solver *s, int nIterations);
 /* Tolerance stop on the device (one right-hand side; handles whose loop is resident, cgamd_solver_loop_launches() < 2): runs until
  * sqrt|r.r| < tol (or NaN), at most maxIterations; *iterations_run = iterations of this call; x is the iterate of exactly that

@@ -24,7 +24,7 @@ def worker(rank, world, port, iters):
     plan.cols_local = plan.cols_local.to(dev); plan.send_index = plan.send_index.to(dev)
     indptr = torch.from_numpy((ip[rb:re + 1] - lo).astype(np.int32)).to(dev); vals = torch.from_numpy(da[lo:hi]).to(dev)
     lib = pkg._lib.load()
-    pkg._lib.check(lib.cgamd_tune(b"index_codes_min_mb", 0)); pkg._lib.check(lib.cgamd_tune(b"resident_lock", 0))
+    pkg._lib.check(lib.cgamd_tune(b"index_codes_min_mb", 0)); pkg._lib.check(lib.cgamd_tune(b"dev.resident_lock", 0))
     bl = torch.from_numpy(b[rb:re]).to(dev)
     out = {}
     for name, fl in (("launched", 0), ("slab", 512)):

@@ -44,7 +44,7 @@ for cfg in args.cfgs:
         pkg._lib.check(lib.cgamd_tune(k.encode(), int(v)))
     s = pkg.Solver(ctx, n, nnz, da, ip, ix, args.nrhs, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=dt)
     for k, v in kv:
-        pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_min": 8, "resident_window": 1, "resident_wide": 1}.get(k, 0)))
+        pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_min": 8, "dev.resident_window": 1, "resident_wide": 1}.get(k, 0)))
     solvers.append((cfg, s, []))
 torch.cuda.synchronize()
 for rnd in range(args.rounds):

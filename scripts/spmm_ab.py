@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of the row-major matrix-core SpMM (csrc/rowmajor.hip) and of the multi-RHS CG loop around it.
 usage: python scripts/spmm_ab.py [--N 1000] [--dtype f64] [--nrhs 32] [--helm 0] cfg1 cfg2 ...
-  cfg = comma-separated key=value tuning pairs (cgamd_tune), e.g.  spmm_wgs=64  spmm_wgs=32,spmm_ynt=1 ;  "cg" in a cfg
+  cfg = comma-separated key=value tuning pairs (cgamd_tune), e.g.  dev.spmm_wgs=64  dev.spmm_wgs=32,dev.spmm_ynt=1 ;  "cg" in a cfg
   also times the CG loop (it/s)."""
 import argparse
 import importlib
@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--helm", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("cfgs", nargs="*", default=["spmm_wgs=64"])
+    ap.add_argument("cfgs", nargs="*", default=["dev.spmm_wgs=64"])
     args = ap.parse_args()
     import torch
     pkg = importlib.import_module("conjugate-gradient-pyopencl_amd")
@@ -77,7 +77,7 @@ def main():
                 res[cfg]["cg_it_s"].append(40 / (time.perf_counter() - t0))
             s.close()
             for k, v in pairs:      # back to defaults (0 = auto for every knob used here except spmm_rowmajor)
-                pkg._lib.check(lib.cgamd_tune(k.encode(), {"spmm_rowmajor": 1, "spmm_ynt": -1}.get(k, 0)))
+                pkg._lib.check(lib.cgamd_tune(k.encode(), {"spmm_rowmajor": 1, "dev.spmm_ynt": -1}.get(k, 0)))
     for cfg in args.cfgs:
         us = min(res[cfg]["spmm_us"])
         out = {"cfg": cfg, "n": n, "nnz": nnz, "dtype": args.dtype, "nrhs": nrhs, "spmm_us_min": round(us, 1),

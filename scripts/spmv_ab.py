@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process interleaved A/B of SpMV / CG-iteration variants (cdna_hip_programming.md §5.4 rule 24).
 usage: python scripts/spmv_ab.py [--grid 250x200x200] [--dtype f64] [--rounds 5] cfg1 cfg2 ...
-  where cfg = comma-separated key=value tuning pairs, e.g.  spmv_variant=0  spmv_variant=2,spmv_grid=1024
+  where cfg = comma-separated key=value tuning pairs, e.g.  index_codes=0  dev.generic_spmv=1,dev.spmv_grid=1024
 """
 import argparse
 import importlib
@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--helm", type=int, default=0, help="use the Helmholtz FE matrix helm_fe_var(N) instead of the 3-D stencil")
     ap.add_argument("--stencil27", type=int, default=0, help="use the 3-D 27-point stencil on an N^3 grid (27 nnz/row: generic kernel)")
-    ap.add_argument("cfgs", nargs="*", default=["spmv_variant=0", "spmv_variant=1", "spmv_variant=2"])
+    ap.add_argument("cfgs", nargs="*", default=["index_codes=1", "index_codes=0", "dev.generic_spmv=1"])
     args = ap.parse_args()
     import torch
     pkg = importlib.import_module("conjugate-gradient-pyopencl_amd")
@@ -60,7 +60,7 @@ def main():
     ys = torch.empty(n, dtype=tdt, device=dev)
     torch.cuda.synchronize()
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-    defaults = {"spmv_variant": 5, "spmv_nt": -1, "spmv_grid": 0, "vec_grid": 0, "spmv_cycle": 64, "spmv_ilv": -1, "defer_x": 1, "spmv_chunked": 1, "spmv_chunk_kb": 0, "spmv_slice_kb": 0, "fold_alpha": 1, "alpha_two_level": 1, "spmv_unroll": 0, "vec_nt": -1, "vec_skew": 0, "index_codes": 1}
+    defaults = {"dev.generic_spmv": 0, "spmv_nt": -1, "dev.spmv_grid": 0, "vec_grid": 0, "spmv_cycle": 64, "dev.spmv_chunked": 1, "dev.spmv_chunk_kb": 0, "dev.spmv_slice_kb": 0, "dev.no_fold_alpha": 0, "dev.spmv_unroll": 0, "vec_nt": -1, "index_codes": 1, "index_codes16": 1}
     solvers = []
     for cfg in args.cfgs:
         kv = dict(defaults)

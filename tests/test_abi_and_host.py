@@ -100,6 +100,34 @@ def test_no_gpu_means_loud_failure_not_fallback(pkg):
     assert np.all(x == 7.0)                                               # untouched: nothing was computed
 
 
+PUBLIC_TUNE_KEYS = {"resident": 1, "resident_min": 8, "resident_wide": 1, "resident_wide_min": 16, "resident_claim_ms": 200,
+                    "two_launch": 1, "spmm_rowmajor": 1, "index_codes": 1, "index_codes16": 1, "index_codes_min_mb": 32, "pad_rows": 1,
+                    "spmv_nt": -1, "vec_nt": -1, "spmv_cycle": 64, "vec_grid": 0}
+
+
+def test_tune_table_is_the_documented_one(pkg):
+    """The public configuration table is the 15 keys of INTEGRATION.md section 6; the knobs of decided experiments are gone (they
+    are an error now, not a silent no-op), test hooks live under the "dev." prefix."""
+    import re
+    lib = pkg._lib.load()
+    assert len(PUBLIC_TUNE_KEYS) == 15
+    for k, v in PUBLIC_TUNE_KEYS.items():
+        assert lib.cgamd_tune(k.encode(), v) == 0, k
+    for k in ("fold_alpha", "alpha_two_level", "defer_x", "spmv_ilv", "spmv_variant", "vec_skew", "spmm_tq", "spmm_nq",
+              "resident_test_short_grid", "resident_lock", "vec_ppt"):
+        assert lib.cgamd_tune(k.encode(), 1) == 1, k
+    assert lib.cgamd_tune(b"dev.resident_test_short_grid", 0) == 0
+    # the source has no other public key, and the documents name exactly these
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg_dir = os.path.dirname(pkg.__file__)
+    api = open(os.path.join(pkg_dir, "csrc", "api.cpp")).read()
+    keys = set(re.findall(r'k == "([^"]+)"', api))
+    assert {k for k in keys if not k.startswith("dev.")} == set(PUBLIC_TUNE_KEYS)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    for k in PUBLIC_TUNE_KEYS:
+        assert "| `%s` |" % k in doc, k
+
+
 def test_argument_validation_without_gpu(pkg):
     lib = pkg._lib.load()
     assert lib.cgamd_dtype_size(0) == 4 and lib.cgamd_dtype_size(1) == 8

@@ -84,7 +84,7 @@ def _worker(rank, world, port, kind, iters, flags, out_dir, coded=False):
         if coded:           # one-byte column codes also for these small local matrices (default: above 32 MB)
             pkg._lib.check(pkg._lib.load().cgamd_tune(b"index_codes_min_mb", 0))
         if flags & 512:     # slab loop: the ranks' resident launches must run at the same time on the shared GPU
-            pkg._lib.check(pkg._lib.load().cgamd_tune(b"resident_lock", 0))
+            pkg._lib.check(pkg._lib.load().cgamd_tune(b"dev.resident_lock", 0))
         s = dmod.DistSolver(ctx, plan, indptr, vals, da.dtype, flags=flags, comm="p2p")
         assert (s.index_codes() > 0) == coded, s.index_codes()
         if flags & 512:

@@ -133,10 +133,10 @@ def test_stateless_cg_keeps_a_few_shapes_per_thread(pkg, gpu):
     assert [h for _, h in second] == [True, True, True]
     for (x0, _), (x1, _) in zip(first, second):
         assert np.array_equal(x0, x1)
-    pkg._lib.check(lib.cgamd_tune(b"vec_ppt", 1))           # a new configuration: the cached handles were made under the old one
+    pkg._lib.check(lib.cgamd_tune(b"dev.vec_ppt", 1))           # a new configuration: the cached handles were made under the old one
     try:
         x2, hit = call(0)
         assert not hit and np.allclose(x2, first[0][0], rtol=1e-12)
     finally:
-        pkg._lib.check(lib.cgamd_tune(b"vec_ppt", 0))
+        pkg._lib.check(lib.cgamd_tune(b"dev.vec_ppt", 0))
         lib.cgamd_cg_release_cache()

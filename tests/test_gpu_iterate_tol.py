@@ -92,10 +92,10 @@ def test_tolerance_run_survives_a_resident_launch_that_cannot_start(pkg, gpu):
     lib = pkg._lib.load()
     pkg._lib.check(lib.cgamd_tune(b"resident_claim_ms", 40))
     try:
-        x1, it1, h1, k1, d1 = _solve(pkg, ctx, ip, ix, da, b, 1e-8, 2000, {"resident_test_short_grid": 1})
+        x1, it1, h1, k1, d1 = _solve(pkg, ctx, ip, ix, da, b, 1e-8, 2000, {"dev.resident_test_short_grid": 1})
     finally:
         pkg._lib.check(lib.cgamd_tune(b"resident_claim_ms", 200))
-        pkg._lib.check(lib.cgamd_tune(b"resident_test_short_grid", 0))
+        pkg._lib.check(lib.cgamd_tune(b"dev.resident_test_short_grid", 0))
     assert k1 == 0 and it1 == it0 and np.array_equal(x1, x0)
 
 

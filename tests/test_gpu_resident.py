@@ -96,7 +96,7 @@ def _run(pkg, ctx, ip, ix, da, B, X0, nrhs, calls, knobs):
         return out
     finally:
         for k in knobs:
-            pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_min": 8, "resident_window": 1, "resident_wide": 1}.get(k, 0)))
+            pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_min": 8, "dev.resident_window": 1, "resident_wide": 1}.get(k, 0)))
 
 
 CASES = [
@@ -135,7 +135,7 @@ def test_resident_loop_is_bit_identical_to_two_launch_loop(pkg, gpu, dtype, kind
     X0 = 0.1 * rand_vec(rng, n * nrhs, wide)
     A = da.astype(dtype)
     # the loop needs the vector launch's "one 16-byte pack per thread" partial structure: the default up to 65536 rows
-    base = {"vec_ppt": 1} if n * nrhs > 262144 and n > 65536 else {}
+    base = {"dev.vec_ppt": 1} if n * nrhs > 262144 and n > 65536 else {}
     if n > 32768:
         base["resident"] = 2                 # groups wider than an XCD: the write-through form, not taken by default (slower than launches)
     res = _run(pkg, ctx, ip, ix, A, B.astype(dtype), X0.astype(dtype), nrhs, calls, dict(base))
@@ -149,7 +149,7 @@ def test_resident_loop_is_bit_identical_to_two_launch_loop(pkg, gpu, dtype, kind
     for key in ("h", "x", "r", "d"):
         assert np.array_equal(wt[key], two[key]), key
     # ... and the form without the LDS window (every non-zero gathers d and r from L2: what irregular patterns get)
-    nw = _run(pkg, ctx, ip, ix, A, B.astype(dtype), X0.astype(dtype), nrhs, calls, dict(base, resident_window=0))
+    nw = _run(pkg, ctx, ip, ix, A, B.astype(dtype), X0.astype(dtype), nrhs, calls, dict(base, **{"dev.resident_window": 0}))
     assert nw["kind"] == (2 if np.dtype(dtype) == np.complex128 else 0)      # complex128 runs resident only with the window
     for key in ("h", "x", "r", "d"):
         assert np.array_equal(nw[key], two[key]), key

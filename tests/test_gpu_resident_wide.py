@@ -111,7 +111,7 @@ def test_resident_launch_that_cannot_form_its_group_falls_back_untouched(pkg, gp
                 pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_claim_ms": 200}.get(k, 0)))
 
     x0, h0, _, k0 = run({"resident": 0})
-    x1, h1, before, after = run({"resident_test_short_grid": 1, "resident_claim_ms": 40})
+    x1, h1, before, after = run({"dev.resident_test_short_grid": 1, "resident_claim_ms": 40})
     assert before == want_kind and after == k0 >= 2          # resident loop chosen at first, launched loops after the failed launch
     assert np.array_equal(h1, h0) and np.array_equal(x1, x0)
 

@@ -64,7 +64,7 @@ def test_handles_keep_their_configuration_while_other_threads_tune(pkg, gpu):
     def tuner():
         i = 0
         while not stop.is_set():
-            for key, vals in ((b"vec_grid", (0, 64, 256)), (b"spmv_cycle", (64, 8)), (b"two_launch", (1, 0)), (b"fold_alpha", (1, 0))):
+            for key, vals in ((b"vec_grid", (0, 64, 256)), (b"spmv_cycle", (64, 8)), (b"two_launch", (1, 0)), (b"dev.no_fold_alpha", (0, 1))):
                 lib.cgamd_tune(key, vals[i % len(vals)])
             i += 1
 
@@ -92,8 +92,8 @@ def test_handles_keep_their_configuration_while_other_threads_tune(pkg, gpu):
         w.join()
     stop.set()
     tt.join()
-    for key in (b"vec_grid", b"spmv_cycle", b"two_launch", b"fold_alpha"):
-        lib.cgamd_tune(key, {b"vec_grid": 0, b"spmv_cycle": 64}.get(key, 1))
+    for key in (b"vec_grid", b"spmv_cycle", b"two_launch", b"dev.no_fold_alpha"):
+        lib.cgamd_tune(key, {b"vec_grid": 0, b"spmv_cycle": 64, b"two_launch": 1}.get(key, 0))
     assert not errors, errors
     for k, (dt, outs) in results.items():
         # one handle = one configuration: its four solves agree bit for bit ...

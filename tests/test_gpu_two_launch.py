@@ -40,7 +40,7 @@ def _run(pkg, ctx, lib, cfg, ip, ix, da, B, X0, nrhs, flags, splits):
         return out
     finally:
         for k in cfg:
-            pkg._lib.check(lib.cgamd_tune(k.encode(), {"spmm_wide_max": -1}.get(k, 1)))
+            pkg._lib.check(lib.cgamd_tune(k.encode(), {"dev.spmm_wide_max": -1, "dev.no_fold_alpha": 0}.get(k, 1)))
 
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
@@ -58,9 +58,9 @@ def test_two_launch_loop_is_bit_identical_to_three_and_four_launch_loops(pkg, gp
     splits = (3, 1, 16, 5, 8)                         # odd and even entry parities, graph of 8 + singles
     two = _run(pkg, ctx, lib, {"two_launch": 1}, ip, ix, da, B, X0, nrhs, flags, splits)
     three = _run(pkg, ctx, lib, {"two_launch": 0}, ip, ix, da, B, X0, nrhs, flags, splits)
-    four = _run(pkg, ctx, lib, {"two_launch": 0, "fold_alpha": 0}, ip, ix, da, B, X0, nrhs, flags, splits)
+    four = _run(pkg, ctx, lib, {"two_launch": 0, "dev.no_fold_alpha": 1}, ip, ix, da, B, X0, nrhs, flags, splits)
     # multi-RHS: the grouped SpMM kernel (one work-group walks the right-hand sides) instead of one work-group per RHS
-    grouped = _run(pkg, ctx, lib, {"spmm_wide_max": 0}, ip, ix, da, B, X0, nrhs, flags, splits)
+    grouped = _run(pkg, ctx, lib, {"dev.spmm_wide_max": 0}, ip, ix, da, B, X0, nrhs, flags, splits)
     for a, b_, c, d_ in zip(two, three, four, grouped):
         assert a.shape == b_.shape == c.shape == d_.shape
         assert np.array_equal(a, b_, equal_nan=True), "two-launch vs three-launch loop differ"
