@@ -72,6 +72,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "dev.spmm_group") g_tune.spmm_group = value;
     else if (k == "dev.spmm_rb") g_tune.spmm_rb = value;
     else if (k == "dev.spmm_wgs") g_tune.spmm_wgs = value;
+    else if (k == "dev.spmm_lead") g_tune.spmm_lead = value;
     else if (k == "dev.spmm_wide_max") g_tune.spmm_wide_max = value;
     else known = false;
     });

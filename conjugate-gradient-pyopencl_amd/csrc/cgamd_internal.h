@@ -115,6 +115,7 @@ struct Tuning {
     int spmm_group = 0;             // SpMM: right-hand sides per register group (0 = equal-width groups of at most 8, 4 for complex128)
     int spmm_rb = 0;                // SpMM: right-hand sides per launch (0 = all in one launch)
     int spmm_wgs = 0;               // row-major SpMM sweep: work-groups per XCD (0 = 64)
+    int spmm_lead = 0;              // row-major SpMM sweep: steps a wave may gather ahead of its XCD's slowest (0 = default, -1 = unpaced)
     int spmm_wide_max = -1;         // multi-RHS, RHS-major: largest row_blocks x nRHS for the one-work-group-per-RHS form (-1 = 4096, 0 = never)
 };
 // g_tune is the process-wide configuration cgamd_tune edits (under a mutex).  Nothing on a compute path reads it
@@ -214,8 +215,12 @@ bool spmm_rm_supported(int dtype, int nrhs, int n);
 // work-groups (= fused-dot partials per RHS) the launch will use for this problem
 int spmm_rm_grid(int dtype, int nrhs, int n, int max_quad, bool dot);
 // max_quad: most non-zeros in 4 consecutive rows (SpmvPlan::max_quad; 0 = unknown), picks the fp64 kernel's K-steps per quad
+// pace: kSpmmPaceInts zeroed ints owned by the caller and used by ONE stream at a time, always for the same problem (the sweep's
+// per-wave progress words, cumulative over launches; one set for the launches with partials, one for those without), or null =
+// unpaced sweep
 int launch_spmm_rm(int dtype, int n, long long nnz, const void *vals, const int *ptr, const int *cols, const void *x, void *y,
-                   int nrhs, void *partials, int max_quad, hipStream_t st);
+                   int nrhs, void *partials, int max_quad, int *pace, hipStream_t st);
+constexpr int kSpmmPaceInts = 2 * 8 * 256 / 4;
 // vector kernels with per-column scalars; partials[r * grid + wg]
 int rm_vec_grid(long long total_elems, int dtype);
 int launch_rm_dot(int dtype, int n, int nrhs, const void *a, const void *b, void *partials, int grid, hipStream_t st);

@@ -73,28 +73,11 @@ template <typename T> struct SpmmRmArgs {
     const T *x;             // [columns][RC] row-major, RC = 16 NH real columns
     T *y;                   // [n][RC]
     double *partials;       // fused d.q: real [RC][nwg] doubles; complex [RC/2][nwg] (re, im) pairs
+    int *pace;              // [8][kPaceWaves] BYTES: steps finished per wave of an XCD's sweep, cumulative mod 256; null = unpaced
+    int lead;               // a wave gathers step g only when every wave of its XCD has finished g - lead steps
 };
+constexpr int kPaceWaves = 256;
 
-// -------------------------------------------------------------------------------------------------
-// The SpMM kernel: T = double (v_mfma_f64_4x4x4_4b) or float (v_mfma_f32_16x16x4; CPLX: values and the X / Y columns are
-// (re, im) pairs), NH = real columns / 16, software-pipelined across strips.
-// A strip's 16 rows are 4 QUADS of 4 rows.  A quad's non-zeros are staged QUAD-ALIGNED in the wave's LDS area: quad q owns
-// slots [q QS, (q+1) QS), QS = 4 TQ, so a K-step (4 consecutive slots) never straddles two quads and every LDS address of
-// the multiply phase is "static offset + lane part".
-//   fp64: the A operand is staged already selected: sval[i][slot] holds the value if the slot's non-zero lies in row i of
-//         its quad, else 0 (tail slots: 0 in all four), so a lane's operand for MFMA (q, u) is ONE ds_read_b64 of
-//         sval[l & 3][q QS + 4u + (l >> 4)] -- no compares, no selects; every quad has its own 4x4x4 accumulators.
-//   fp32: the tile is the whole strip (16 rows); each slot is staged as (value[, imaginary part], row of the strip) and the
-//         lane keeps the value when that row is its A-row (one compare + select per K-step; tail slots carry row 255).
-// (The first version tested row RANGES per K-step and quad in the multiply loop: 80 guarded blocks per strip, ~2 us of
-// issue per strip and wave, 187 us per fp64 SpMM.)  TQ = K-steps per quad and round, a template parameter chosen from the
-// matrix (5: <= 20 non-zeros per 4 rows, the 5-point stencil; 8: anything, longer quads take more rounds).
-// Pipeline per wave, strip k current:   stage(k+1) -> fetch entries(k+2), pointers(k+3) -> gathers(k+1) -> multiply(k)
-// -> store(k): the gathers of two strips are in flight, and nothing a strip waits for is younger (vmcnt is in order) than
-// the loads it does not need yet.  Strips past the wave's last alias it (redundant, discarded) so the loop is branch-free.
-// (Tried and dropped: touching the next-but-one strip's new X rows with one dword load per cache line a step early --
-// 122 -> 149 us and +33 % read traffic; profiles/r2_experiments/spmm_ab8.log.)
-// -------------------------------------------------------------------------------------------------
 template <typename T, int NH, int TQ, int NQ, bool CPLX>
 struct RmGeom {
     static constexpr bool F64 = sizeof(T) == 8;
@@ -123,6 +106,52 @@ __global__ __launch_bounds__(256, (RmGeom<T, NH, TQ, NQ, CPLX>::WAVES)) void spm
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 15, kq = lane >> 4;
     const int xcd = blockIdx.x & 7, W = ((int)gridDim.x >> 3) * 4, wl = ((int)blockIdx.x >> 3) * 4 + wave;
     const int sb = (int)((long long)xcd * a.strips / 8), se = (int)((long long)(xcd + 1) * a.strips / 8);
+
+    // Paced sweep.  The strips are handed out statically (the fused d.q partial of a work-group must not depend on the schedule),
+    // so nothing but the L2's patience keeps a fast wave from running steps ahead of a slow one, and an X row that three strips
+    // 62 apart use (5-point stencil on a 1000-wide grid) was fetched again for the stragglers: FETCH 1.26-1.45x (profiles/r2).
+    // Every wave publishes the number of steps it has finished in its own byte (one shared counter bumped with atomics cost
+    // ~100 ns per bump, serialised at the memory side -- 7 800 strips per XCD = 0.9 ms); before a wave issues the gathers
+    // of step g it wants every wave of its XCD to have finished g - lead steps.  All the words (bytes) of an XCD arrive with ONE 4-byte
+    // load per lane, issued a step early, before that step's gathers, so that waiting for it never waits for gathers (vmcnt
+    // retires in order); only a wave that finds itself ahead polls.  The kernel ends with the slowest wave either way: waiting
+    // costs the leaders nothing that counts.  The wait is ADVISORY (results never depend on it) and bounded: a wave not answered
+    // within kPacePolls polls (grid not co-resident) stops pacing for the rest of the launch.  The words are cumulative over
+    // launches (every wave leaves base + MX, MX = steps of the longest wave), so nothing has to be cleared in between.
+    constexpr int kPacePolls = 256;
+    const int S = se - sb, MX = (S + W - 1) / W;
+    unsigned char *const pw = a.pace ? reinterpret_cast<unsigned char *>(a.pace) + kPaceWaves * xcd : nullptr;     // one BYTE per wave (mod 256)
+    bool paced = pw != nullptr && W <= kPaceWaves && S >= W;
+    const int base = pw && wl < kPaceWaves ? __builtin_amdgcn_readfirstlane((int)pw[wl]) : 0;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pw, 0, pw ? kPaceWaves : 0, 0x00020000);
+    int stepno = 0;                                         // step of s_cur
+    auto pace_load = [&]() -> unsigned { return __builtin_amdgcn_raw_buffer_load_b32(prs, (unsigned)lane * 4u, 0, 16 /* sc1: from the L2 */); };
+    auto pace_ok = [&](unsigned v, int need) -> bool {      // (waves are never 128 steps apart while the pacing holds: mod-256 compare)
+        const int lo = 4 * lane, t = base + need;           // bytes past the sweep's last wave do not count
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ok = ok && (lo + k >= W || (signed char)(unsigned char)((v >> (8 * k)) - (unsigned)t) >= 0);
+        return __builtin_amdgcn_ballot_w64(!ok) == 0;
+    };
+    unsigned pv = 0u;
+    auto pace_wait = [&](int g) {                           // before the gathers of step g
+        if (!paced) return;
+        const int need = g - a.lead;
+        if (need > 0 && !pace_ok(pv, need)) {               // pv: the words as they were a step ago
+            int polls = 0;
+            while (!pace_ok(pace_load(), need)) {
+                if (++polls > kPacePolls) { paced = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        pv = pace_load();                                   // for the next step's check; older than the gathers issued next
+    };
+    auto pace_done = [&](int steps) {
+        // PLAIN store: it lands in the XCD's L2, where the other waves' sc1 loads find it.  A write-through (sc1 / agent-scope)
+        // store of a byte is a read-modify-write of the line at the memory side, ~100 ns each and serialised per line: 7 800 of
+        // them per XCD made the launch 8x longer (scripts/microbench/sload_probe.hip)
+        if (pw && wl < kPaceWaves && lane == 0) asm volatile("global_store_byte %0, %1, off" ::"v"(pw + wl), "v"(base + steps) : "memory");
+    };
 
     double dsum[NH], dcross[CPLX ? NH : 1];
 #pragma unroll
@@ -265,6 +294,7 @@ __global__ __launch_bounds__(256, (RmGeom<T, NH, TQ, NQ, CPLX>::WAVES)) void spm
     auto lrow = [&](int i) -> int { return F64 ? 4 * i + kq : 4 * kq + i; };
 
     const int s0 = sb + wl;
+    if (s0 >= se) pace_done(MX);
     if (s0 < se) {
         auto clampS = [&](int s) -> int { return s < se ? s : se - 1; };
         int s_cur = s0, s_nxt = s0 + W, s_nn = s0 + 2 * W;
@@ -289,11 +319,11 @@ __global__ __launch_bounds__(256, (RmGeom<T, NH, TQ, NQ, CPLX>::WAVES)) void spm
                 for (int i = 0; i < (F64 ? NQ : 4); ++i)
                     xo[i] = *reinterpret_cast<const RV *>(xbase + (size_t)((unsigned)min(rowbase + lrow(i), a.n - 1) * (unsigned)(RC * sizeof(T))));
             }
-            if constexpr (!PIPE) issue(buf, bvC);
+            if constexpr (!PIPE) { pace_wait(stepno); issue(buf, bvC); }
             stage(buf ^ 1, p_nxt, 0, min(clampS(s_nxt) * ROWS, a.n - 1), evN, ecN);
             const int p_n3 = load_ptr(clampS(s_nn + W));
             fetch(p_nn, 0, evN, ecN);
-            if constexpr (PIPE) issue(buf ^ 1, bvN);
+            if constexpr (PIPE) { pace_wait(stepno + 1); issue(buf ^ 1, bvN); }
 
             Acc acc;
             if constexpr (F64) {
@@ -342,7 +372,10 @@ __global__ __launch_bounds__(256, (RmGeom<T, NH, TQ, NQ, CPLX>::WAVES)) void spm
                     }
                 }
             }
+            // the strip's X rows are consumed (the multiply waited for them); a wave's last publish is MX for every wave
+            pace_done(s_nxt >= se ? MX : stepno + 1);
             if (s_nxt >= se) return false;
+            ++stepno;
             s_cur = s_nxt; s_nxt = s_nn; s_nn += W;
             p_cur = p_nxt; p_nxt = p_nn; p_nn = p_n3;
             buf ^= 1;
@@ -517,18 +550,15 @@ template <typename K> static int rm_blocks_per_cu(K kernel) {
     return per > 8 ? 8 : per;
 }
 // which instance runs: K-steps per quad and round (5 when no 4 consecutive rows hold more than 20 non-zeros -- 5-point
-// stencils --, else 8) and strip height.  8-row strips (fp64 only, NQ = 2: half the registers, four waves per SIMD) are an
-// experiment knob: in-process A/B at N = 1M x 32 (profiles/r2_experiments/spmm_ab9.log, spmm_ab10.log) 3 % faster than
-// 16-row strips only with 96 of the 128 resident work-groups per XCD, 13 % slower with all of them, and slower inside CG.
+// stencils --, else 8).  Strips are 16 rows (8-row strips at four waves per SIMD were measured and dropped: 3 % faster only
+// with 96 of the 128 resident work-groups per XCD, slower inside CG; profiles/r2_experiments/spmm_ab9.log, spmm_ab10.log).
 struct RmInstance { int tq, nq, rows, per_cu; };
 template <typename T, int NH, bool CPLX> static RmInstance rm_instance(int max_quad, bool dot) {
     RmInstance r;
     const bool tq5 = max_quad > 0 && max_quad <= 20;
-    constexpr bool nq2 = false;       // (8-row strips at 4 waves per SIMD: measured 3 % faster stand-alone, slower inside CG; dropped)
-    r.tq = tq5 ? 5 : 8; r.nq = nq2 ? 2 : 4; r.rows = 4 * r.nq;
+    r.tq = tq5 ? 5 : 8; r.nq = 4; r.rows = 4 * r.nq;
 #define CG_OCC(TQ, NQ) (dot ? rm_blocks_per_cu(spmm_rm_kernel<T, NH, TQ, NQ, CPLX, true>) : rm_blocks_per_cu(spmm_rm_kernel<T, NH, TQ, NQ, CPLX, false>))
-    if constexpr (sizeof(T) == 8) r.per_cu = nq2 ? CG_OCC(5, 2) : tq5 ? CG_OCC(5, 4) : CG_OCC(8, 4);
-    else r.per_cu = tq5 ? CG_OCC(5, 4) : CG_OCC(8, 4);
+    r.per_cu = tq5 ? CG_OCC(5, 4) : CG_OCC(8, 4);
 #undef CG_OCC
     return r;
 }
@@ -563,9 +593,11 @@ int spmm_rm_grid(int dtype, int nrhs, int n, int max_quad, bool dot) {
 
 template <typename T, int NH, bool CPLX>
 static int spmm_rm_launch(int n, long long nnz, const void *vals, const int *ptr, const int *cols, const void *x, void *y,
-                          void *partials, int max_quad, hipStream_t st) {
+                          void *partials, int max_quad, int *pace, hipStream_t st) {
     SpmmRmArgs<T> a;
     a.n = n; a.nnz = nnz;
+    a.lead = tune().spmm_lead > 0 ? tune().spmm_lead : 3;
+    a.pace = (tune().spmm_lead < 0 || !pace) ? nullptr : pace + (partials ? 0 : 8 * kPaceWaves / 4);
     a.ynt = tune().spmm_ynt >= 0 ? tune().spmm_ynt : 2;      // Y stores write-through (sc1): the lines do not displace X in L2
     a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.cols = cols;
     a.x = static_cast<const T *>(x); a.y = static_cast<T *>(y); a.partials = static_cast<double *>(partials);
@@ -578,22 +610,18 @@ static int spmm_rm_launch(int n, long long nnz, const void *vals, const int *ptr
         if (partials) hipLaunchKernelGGL((spmm_rm_kernel<T, NH, TQ, NQ, CPLX, true>), g, b, 0, st, a);         \
         else hipLaunchKernelGGL((spmm_rm_kernel<T, NH, TQ, NQ, CPLX, false>), g, b, 0, st, a);                 \
     } while (0)
-    if constexpr (sizeof(T) == 8) {
-        if (inst.tq == 5 && inst.nq == 2) CG_SPMM(5, 2); else if (inst.tq == 5) CG_SPMM(5, 4); else CG_SPMM(8, 4);
-    } else {
-        if (inst.tq == 5) CG_SPMM(5, 4); else CG_SPMM(8, 4);
-    }
+    if (inst.tq == 5) CG_SPMM(5, 4); else CG_SPMM(8, 4);
 #undef CG_SPMM
     return rm_check_launch("spmm_rm");
 }
 
 int launch_spmm_rm(int dtype, int n, long long nnz, const void *vals, const int *ptr, const int *cols, const void *x, void *y,
-                   int nrhs, void *partials, int max_quad, hipStream_t st) {
+                   int nrhs, void *partials, int max_quad, int *pace, hipStream_t st) {
     if (n <= 0) return CGAMD_OK;
     const int rc = rm_real_columns(dtype, nrhs);
     if (rc && !spmm_rm_supported(dtype, nrhs, n)) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: the right-hand-side block must be smaller than 4 GiB");
     if (!rc) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: needs f64 with 16 or 32 right-hand sides, f32 with 16, 32 or 64, or complex64 with 16 or 32");
-#define CG_RM(T, NH, C) return spmm_rm_launch<T, NH, C>(n, nnz, vals, ptr, cols, x, y, partials, max_quad, st)
+#define CG_RM(T, NH, C) return spmm_rm_launch<T, NH, C>(n, nnz, vals, ptr, cols, x, y, partials, max_quad, pace, st)
     CG_RM_TYPES(dtype, rc, CG_RM);
 #undef CG_RM
 }

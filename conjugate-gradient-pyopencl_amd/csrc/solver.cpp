@@ -53,6 +53,7 @@ struct cgamd_solver {
     // row-major multi-RHS path (rowmajor.hip): x, r, d, q, b hold [n][nrhs]; rm_ok is decided at creation, `rm` per set_rhs
     bool rm_ok = false, rm = false;
     int rm_nwg = 0, rm_vgrid = 0;
+    int *rm_pace = nullptr;     // progress counters of the paced SpMM sweep (kSpmmPaceInts, zero between launches)
     // event hooks around the SpMV launch of enqueue_iteration (cgamd_solver_iterate_timed)
     hipEvent_t *ev_pair = nullptr;
     // two-launch loop (small systems): d of iteration k lives in dbuf[k & 1] (dbuf[0] = d, the initial r); decided at creation
@@ -119,7 +120,7 @@ static int enqueue_spmv(cgamd_solver *s, int k, hipStream_t st) {
     if (fused2)
         rc = launch_spmv_fused(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, dbuf(s, k), dbuf(s, k + 1), s->r, s->q, nr, s->part_dq,
                                s->part_rr, s->vgrid, s->sc, st);
-    else if (s->rm) rc = launch_spmm_rm(dt, n, s->nnz, s->vals, s->ptr, s->cols, s->d, s->q, nr, s->part_dq, s->plan.max_quad, st);
+    else if (s->rm) rc = launch_spmm_rm(dt, n, s->nnz, s->vals, s->ptr, s->cols, s->d, s->q, nr, s->part_dq, s->plan.max_quad, s->rm_pace, st);
     else if (s->flags & CGAMD_UNFUSED) rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, nullptr, nullptr, st);
     else rc = launch_spmv(dt, s->plan, n, s->nnz, s->vals, s->ptr, s->cols, s->d, n, s->q, n, nr, s->d, s->part_dq, st);
     set_kernel_event_pair(nullptr);
@@ -373,6 +374,8 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     if (!rc) rc = compute_spmv_plan(s->ptr, s->cols, n_int, s->sc.iter, ctx->stream, &s->plan);
     if (!rc) finalize_spmv_plan(&s->plan, dtype, nRHS, n_int, nnz, s->vals, s->cols);
     if (!rc && s->rm_ok) s->rm_nwg = spmm_rm_grid(dtype, nRHS, size, s->plan.max_quad, true);
+    if (!rc && s->rm_ok) rc = dmalloc((void **)&s->rm_pace, sizeof(int) * kSpmmPaceInts, "spmm pace counters");
+    if (!rc && s->rm_ok && hipMemsetAsync(s->rm_pace, 0, sizeof(int) * kSpmmPaceInts, ctx->stream) != hipSuccess) rc = fail(CGAMD_ERR_HIP, "hipMemsetAsync(spmm pace counters)");
     if (!rc) s->fused2 = fused2_ok(s->plan, dtype, nRHS, s->vals, s->cols);
     if (!rc) rc = setup_resident(s);
     if (!rc) rc = setup_index_codes(s);
@@ -443,7 +446,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
         if (s->cols) (void)hipFree(s->cols);
     }
     void *bufs[] = {s->slab, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
-                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync, s->resw_sync, s->codes, s->dict};
+                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync, s->resw_sync, s->codes, s->dict, s->rm_pace};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;
@@ -472,7 +475,7 @@ int cgamd_solver_set_rhs(cgamd_solver *s, const void *b, const void *x0, int on_
             CG_HIP(hipMemsetAsync(s->x, 0, vbytes, st));
         }
         // r = b - A x0 ; d = r ; delta0 = r.r   (clcg.c:255-292)
-        if ((rc = launch_spmm_rm(s->dtype, s->n, s->nnz, s->vals, s->ptr, s->cols, s->x, s->q, s->nrhs, nullptr, s->plan.max_quad, st))) return rc;
+        if ((rc = launch_spmm_rm(s->dtype, s->n, s->nnz, s->vals, s->ptr, s->cols, s->x, s->q, s->nrhs, nullptr, s->plan.max_quad, s->rm_pace, st))) return rc;
         if ((rc = launch_sub(s->dtype, s->n * s->nrhs, s->b, s->q, s->r, (long long)s->n * s->nrhs, 1, st))) return rc;
         CG_HIP(hipMemcpyAsync(s->d, s->r, vbytes, hipMemcpyDeviceToDevice, st));
         if ((rc = launch_rm_dot(s->dtype, s->n, s->nrhs, s->r, s->r, s->part_rr, s->rm_vgrid, st))) return rc;
@@ -785,7 +788,7 @@ int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS
     if (!s || !x || !y) return fail(CGAMD_ERR_INVALID, "spmm_rowmajor: null argument");
     TuneScope ts(&s->tune);
     CG_HIP(hipSetDevice(s->ctx->device));
-    return launch_spmm_rm(s->dtype, s->n_user, s->nnz, s->vals, s->ptr, s->cols, x, y, nRHS, nullptr, s->plan.max_quad, s->ctx->stream);
+    return launch_spmm_rm(s->dtype, s->n_user, s->nnz, s->vals, s->ptr, s->cols, x, y, nRHS, nullptr, s->plan.max_quad, s->rm_pace, s->ctx->stream);
 }
 
 int cgamd_solver_layout(cgamd_solver *s) { return s ? (s->rm ? 1 : 0) : -CGAMD_ERR_INVALID; }

@@ -1,8 +1,10 @@
 #!/bin/bash
+# FETCH_SIZE of the row-major SpMM for a list of tuning configurations (one rocprofv3 --pmc pass each), then their timings
+# usage: pmc_sweep_spmm.sh "cfg1" "cfg2" ...
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for cfg in "spmm_rowmajor=2" "spmm_rowmajor=2,dev.spmm_wgs=32" "spmm_rowmajor=2,dev.spmm_wgs=48" "spmm_rowmajor=2,dev.spmm_ynt=0" "spmm_rowmajor=2,dev.spmm_ynt=1" "spmm_rowmajor=2,dev.spmm_wgs=32,dev.spmm_ynt=0"; do
+for cfg in "$@"; do
   tag=$(echo "$cfg" | tr ',=' '__')
-  PMC_GROUPS="FETCH_SIZE" bash scripts/gpu_pmc_spmm.sh sweep_$tag --dtype f64 --nrhs 32 "$cfg" > gpurun_out/pmc_sweep_$tag.log 2>&1
+  PMC_GROUPS="FETCH_SIZE" bash scripts/gpu_pmc_spmm.sh sweep_$tag --dtype ${SPMM_DTYPE:-f64} --nrhs ${SPMM_NRHS:-32} "$cfg" > gpurun_out/pmc_sweep_$tag.log 2>&1 || exit 1
   echo "$cfg: $(grep -A1 '== FETCH' gpurun_out/pmc_sweep_$tag.log | tail -1 | cut -c60-120)"
 done
-timeout -k 10 200 python scripts/spmm_ab.py --dtype f64 --nrhs 32 --rounds 3 "spmm_rowmajor=2" "spmm_rowmajor=2,dev.spmm_wgs=32" "spmm_rowmajor=2,dev.spmm_wgs=48" "spmm_rowmajor=2,dev.spmm_ynt=0" "spmm_rowmajor=2,dev.spmm_ynt=1" "spmm_rowmajor=2,dev.spmm_wgs=32,dev.spmm_ynt=0" 2>/dev/null | grep cfg | cut -c1-150
+timeout -k 10 200 python scripts/spmm_ab.py --dtype ${SPMM_DTYPE:-f64} --nrhs ${SPMM_NRHS:-32} --rounds 3 "$@" 2>/dev/null | grep cfg | cut -c1-150

@@ -154,6 +154,49 @@ def test_rowmajor_is_the_default_for_large_fp64_x32(pkg, gpu):
     assert np.allclose(h[:, 1:], h[:, :1], rtol=1e-12)          # equal right-hand sides, equal histories
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.complex64])
+def test_paced_sweep_changes_no_bit(pkg, gpu, dtype):
+    """The sweep of the matrix-core SpMM is paced (a wave gathers step g only when its XCD's waves have finished g - lead steps:
+    X is read once instead of 1.3-1.45 times, profiles/r3/pmc_spmm_c4_summary.txt).  The pacing is advisory: histories and
+    iterates of 300 iterations (the per-wave progress bytes wrap around many times: 600 x 600 rows = 3 steps per launch and wave,
+    > 900 launches per handle) are bit-identical to the unpaced sweep, to a lead of one step, and run to run."""
+    import torch
+    ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
+    N, nrhs = 600, 32
+    ip, ix, da = pkg.generators.poisson2d(ctx, N, dtype=dtype)
+    tdt = pkg.generators.torch_dtype(dtype)
+    b = (torch.rand(N * N * nrhs, dtype=torch.float64, device=torch.device("cuda", 0)) + 0.5).to(tdt)
+    torch.cuda.synchronize()
+
+    def run(lead):
+        pkg._lib.check(lib.cgamd_tune(b"spmm_rowmajor", 2))
+        pkg._lib.check(lib.cgamd_tune(b"dev.spmm_lead", lead))
+        pkg._lib.check(lib.cgamd_tune(b"resident_wide", 0))
+        try:
+            s = pkg.Solver(ctx, N * N, int(ix.numel()), da, ip, ix, nrhs, flags=pkg._lib.MATRIX_ON_DEVICE, dtype=dtype)
+            s.set_rhs(b, None, on_device=True)
+            assert lib.cgamd_solver_layout(s.handle) == 1
+            for k in (150, 1, 149):
+                s.iterate(k)
+            out = (s.x(), s.history())
+            s.set_rhs(b, None, on_device=True)           # a second solve on the same handle: the progress bytes carry on
+            s.iterate(300)
+            out = out + (s.x(), s.history())
+            s.close()
+            return out
+        finally:
+            pkg._lib.check(lib.cgamd_tune(b"spmm_rowmajor", 1))
+            pkg._lib.check(lib.cgamd_tune(b"dev.spmm_lead", 0))
+            pkg._lib.check(lib.cgamd_tune(b"resident_wide", 1))
+
+    unpaced, paced, again, tight = run(-1), run(0), run(0), run(1)
+    for a, b_, c, d in zip(unpaced, paced, again, tight):
+        assert np.array_equal(a, b_) and np.array_equal(b_, c) and np.array_equal(a, d)
+    assert np.array_equal(paced[0], paced[2]) and np.array_equal(paced[1], paced[3])
+    assert np.all(np.isfinite(paced[1]))
+
+
 def test_rowmajor_handle_falls_back_for_preconditioned_and_unfused_loops(pkg, gpu):
     """the diagonal-preconditioned recurrence and the reference op structure keep the RHS-major kernels"""
     ctx, queue, kernels = gpu
