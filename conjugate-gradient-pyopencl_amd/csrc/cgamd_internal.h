@@ -42,6 +42,7 @@ struct SpmvPlan {
     int max_quad = 0;    // most non-zeros in 4 consecutive rows starting at a multiple of 4 (row-major SpMM: K-steps per quad)
     int lpr = 1;         // kind 7: lanes per row (2, 4, 8, 16, 32) = chunks per 256-row block
     int n_partials = 0;  // fused-dot partials per RHS written by that kernel
+    int fold_max = 0;    // most d.q partials the folded alpha sums (0 = default; handles the chip-wide resident loop takes over: 4096)
     int nt = 1;          // matrix stream loaded non-temporally (finalize_spmv_plan: off when the matrix fits the Infinity Cache)
     int vec_nt = 3;      // axpy2_dot streaming hints (see Tuning::vec_nt), resolved by finalize_spmv_plan
     // one-byte column codes of the single-RHS row-block kernel (build_index_codes; owned by the caller, not by the plan)
@@ -172,6 +173,9 @@ struct CgScalars {
     int history_cap = 0;
     void *stage = nullptr;     // optional, two-level cg_alpha: acc[nrhs][32] part sums
     unsigned *ticket = nullptr;   //          and one zero-initialised ticket counter per RHS
+    // order of the prologue sums over the d.q / r.r partials: 0 = thread-strided; K > 0 = member-blocked (reduce_device.h
+    // thread_partials): handles the chip-wide resident loop can take over, K = 256-row (256-pack) blocks of one resident member
+    int kdq = 0, krr = 0;
 };
 // ten-vector-pass iteration (x update deferred into the aypx launch): see kernels.hip
 int launch_axpy_dot(int dtype, int n, const void *q, void *r, long long ld, const void *alpha, int nrhs, void *partials, int grid,
@@ -181,7 +185,7 @@ int launch_axpy_dot_alpha(int dtype, int n, const void *q, void *r, long long ld
 int launch_aypx_beta_x(int dtype, int n, const void *x, void *y, void *xs, long long ld, const void *partials, int P, int nrhs,
                        const CgScalars &sc, hipStream_t st, int vec_nt = 3);
 // small systems: alpha = delta / sum(part_dq) in the prologue (three-launch iteration); fold_alpha_ok says when
-bool fold_alpha_ok(int n_partials);
+bool fold_alpha_ok(int n_partials, int fold_max = 0);      // fold_max 0 = the default limit (2048 partials)
 // two-launch iteration (kernels.hip "Two-launch iteration"): the SpMV launch computes beta and d_new = beta d_old + r on the
 // fly; d_old / d_new are different buffers.  fused2_ok: the plan's row-block kernels apply and the system is small enough
 bool fused2_ok(const SpmvPlan &plan, int dtype, int nrhs, const void *vals, const int *cols);
@@ -263,6 +267,7 @@ private:
 };
 
 // wide resident loop (resident.hip): chip-wide groups (one right-hand side each at a time), matrix rows in registers
+constexpr int kResWideBlocksPerRpt = 2;     // 256-row blocks of a chip-wide resident member per row of a thread (512 threads: resident_device.h)
 struct ResidentWidePlan {
     bool ok = false;
     int rpt = 0, unroll = 0, G = 0, NG = 1, wcap = 0;      // NG concurrent groups of G work-groups

@@ -513,6 +513,35 @@ template <typename T> struct ResWideArgs {
     long long *prof;                // diagnostics (CGAMD_RESIDENT_PROF=1)
 };
 
+// The member's value in the launched loops' member-blocked prologue sums (reduce_device.h thread_partials, K = 2 N): the
+// 256-thread block sums of its N per-thread values -- block 2 i + (t >> 8): wave tree, then ((w0 + w1) + w2) + w3, exactly
+// block_sum<256> of the launched kernels -- added in block order starting from zero.  Result valid in thread 0.  Every wave's
+// outstanding stores are acknowledged before the barrier (see wg_sum).
+CG_DEV double shfl_acc(double v, int l) { return __shfl(v, l, kWave); }
+CG_DEV double2 shfl_acc(double2 v, int l) { return make_double2(__shfl(v.x, l, kWave), __shfl(v.y, l, kWave)); }
+template <typename A, int N> CG_DEV A member_sum(A (&v)[N], A (*wsn)[kResThreads / kWave]) {
+    static_assert(kResThreads == 512 && kResThreads / 256 == kResWideBlocksPerRpt, "two 256-thread blocks per value");
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        v[i] = wave_sum(v[i]);
+        if (lane == 0) wsn[i][wave] = v[i];
+    }
+    drain_stores();
+    __syncthreads();
+    A tot = vzero<A>();
+    if (t < kWave) {
+        A b = vzero<A>();
+        if (lane < 2 * N) {
+            const A *w = &wsn[lane >> 1][4 * (lane & 1)];
+            b = vadd(vadd(vadd(w[0], w[1]), w[2]), w[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 2 * N; ++c) tot = vadd(tot, shfl_acc(b, c));
+    }
+    return tot;
+}
+
 template <typename T, int RPT, int U>
 __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideArgs<T> a) {
     using A = typename VT<T>::acc;
@@ -525,6 +554,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
     T *qs = reinterpret_cast<T *>(dyn_smem);         // q of my rows
     T *win = qs + ROWS;                              // beta d + r of the column range of my rows; last entry: the zero cell
     __shared__ ResShared sh;
+    __shared__ A wsn[RPT][kResThreads / kWave];      // wave sums of the per-block partials (member_sum)
     const int t = threadIdx.x;
 
     if (t == 0) {
@@ -752,8 +782,8 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         }
         __syncthreads();
         RES_STAMP(2)
-        // ---- q = A d_new for my rows, d.q
-        A dot = vzero<A>();
+        // ---- q = A d_new for my rows, d.q (one partial per 256 rows, as the launched SpMV forms them)
+        A dotv[RPT];
 #pragma unroll
         for (int h = 0; h < RPT; ++h) {
             T sum = vzero<T>();
@@ -763,10 +793,10 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                 sum = vfma(mv[h][j], win[idx], sum);
             }
             qs[t + h * kResThreads] = sum;
-            if (live[h]) dot = vadd(dot, to_acc(vmul(*reinterpret_cast<const T *>(wb + own_off[h]), sum)));
+            dotv[h] = live[h] ? to_acc(vmul(*reinterpret_cast<const T *>(wb + own_off[h]), sum)) : vzero<A>();
         }
         RES_STAMP(3)
-        A tot = wg_sum(dot, sh);
+        A tot = member_sum<A, RPT>(dotv, wsn);
         if (t == 0) put_granule<false>(g_dq + (size_t)m * W, tag0 + 2 * k + 1, tot);
         RES_STAMP(4)
         T al, al_unused;
@@ -778,21 +808,23 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                                }, xlead, xpublish, xs_dq, tag0 + 2 * k + 1)) return;
         RES_STAMP(5)
         if (leader && t == 0) a.alpha[rhs] = al;
-        A acc = vzero<A>();
+        A accv[PPT];                                 // r.r per pack = per thread of the launched vector kernel (one pack per thread)
 #pragma unroll
-        for (int j = 0; j < PPT; ++j)
+        for (int j = 0; j < PPT; ++j) {
+            accv[j] = vzero<A>();
             if (pk[j]) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const T qv = qs[(t + j * kResThreads) * E + e];
                     px[j].v[e] = vadd(px[j].v[e], vmul(al, pd[j].v[e]));
                     pr[j].v[e] = vsub(pr[j].v[e], vmul(al, qv));
-                    acc = vadd(acc, to_acc(vmul(pr[j].v[e], pr[j].v[e])));
+                    accv[j] = vadd(accv[j], to_acc(vmul(pr[j].v[e], pr[j].v[e])));
                 }
                 if (pub[j]) st_pack_coh<false>(at_off(rr, poff[j]), pr[j]);
             }
+        }
         RES_STAMP(6)
-        tot = wg_sum(acc, sh);
+        tot = member_sum<A, PPT>(accv, wsn);
         if (t == 0) put_granule<false>(g_rr + (size_t)m * W, tag0 + 2 * k + 2, tot);
         RES_STAMP(7)
     }

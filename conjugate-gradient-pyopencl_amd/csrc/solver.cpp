@@ -53,6 +53,7 @@ struct cgamd_solver {
     // row-major multi-RHS path (rowmajor.hip): x, r, d, q, b hold [n][nrhs]; rm_ok is decided at creation, `rm` per set_rhs
     bool rm_ok = false, rm = false;
     int rm_nwg = 0, rm_vgrid = 0;
+    size_t part_rr_cap = 0;
     int *rm_pace = nullptr;     // progress counters of the paced SpMM sweep (kSpmmPaceInts, zero between launches)
     // event hooks around the SpMV launch of enqueue_iteration (cgamd_solver_iterate_timed)
     hipEvent_t *ev_pair = nullptr;
@@ -152,7 +153,7 @@ static int enqueue_iteration(cgamd_solver *s, int k, hipStream_t st) {
     }
     if (!(s->flags & CGAMD_UNFUSED)) {
         if ((rc = enqueue_spmv(s, k, st))) return rc;
-        const bool fold = fold_alpha_ok(s->plan.n_partials);      // small system: alpha in the next launch's prologue
+        const bool fold = fold_alpha_ok(s->plan.n_partials, s->plan.fold_max);      // small system: alpha in the next launch's prologue
         if (!fold && (rc = launch_cg_alpha(dt, s->part_dq, s->plan.n_partials, nr, s->sc, st))) return rc;
         // r -= alpha q (+ r.r) ; then beta, x += alpha d, d = beta d + r : 3 + 5 vector passes (x is read by nothing inside the loop, so
         // its update rides in the aypx launch, which reads d anyway)
@@ -172,21 +173,48 @@ static int enqueue_iteration(cgamd_solver *s, int k, hipStream_t st) {
 }
 
 // the resident loop applies where the two-launch loop does and the matrix slices fit LDS (needs the row pointers on the host)
-static int setup_resident_wide(cgamd_solver *s) {
+// The launched loops of a handle the chip-wide resident loop can take over produce ITS bits (and the other way round): one
+// 16-byte pack per thread in the vector launches (the r.r partial of a work-group = 256 consecutive packs), alpha folded whatever
+// the size, and every prologue sum in the member-blocked order (reduce_device.h thread_partials; K = the blocks of one member).
+// So iterate(15) twice and iterate(30) return the same bits although the first takes the launched loop and the second the
+// resident one.  Called whenever the wide plan may have changed; captured graphs hold grids and orders, so they go when it did.
+static void apply_wide_order(cgamd_solver *s) {
+    const int E = (int)(16 / dtype_size(s->dtype));
+    const bool wide = s->resw.ok && !s->res_ok;      // (where the one-XCD resident loop applies it runs, with the strided order)
+    const int kdq = wide ? kResWideBlocksPerRpt * s->resw.rpt : 0, krr = wide ? kdq / E : 0;
+    const int vgrid = wide ? (s->n / E + kBlock - 1) / kBlock : vec_grid(s->n, s->dtype, s->nrhs);
+    const int fold_max = wide ? 4096 : 0;
+    if (kdq == s->sc.kdq && krr == s->sc.krr && vgrid == s->vgrid && fold_max == s->plan.fold_max) return;
+    destroy_graphs(s);
+    s->sc.kdq = kdq; s->sc.krr = krr; s->vgrid = vgrid; s->plan.fold_max = fold_max;
+    s->fused2 = fused2_ok(s->plan, s->dtype, s->nrhs, s->vals, s->cols);
+}
+
+// the resident loop applies where the two-launch loop does and the matrix slices fit LDS (needs the row pointers on the host)
+static int setup_resident_wide_plan(cgamd_solver *s) {
     s->resw.ok = false;
     if (tune().resident_wide == 0 || tune().resident == 0 || (s->flags & CGAMD_UNFUSED)) return CGAMD_OK;
     if (s->rm_ok && tune().spmm_rowmajor >= 2) return CGAMD_OK;      // the row-major loop was asked for
     if (!aligned16(s->x) || !aligned16(s->r) || !aligned16(s->d) || !aligned16(s->d2)) return CGAMD_OK;
+    if (s->plan.kind != 5 && s->plan.kind != 6) return CGAMD_OK;    // the launched loops' 256-row d.q partials are what the members reproduce
+    if (s->n % (int)(16 / dtype_size(s->dtype)) != 0) return CGAMD_OK;
     if (!s->n_cus) CG_HIP(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device));
     ResidentWidePlan wp;
     if (int rc = resident_wide_plan(s->dtype, s->n, s->nnz, s->nrhs, s->n_cus, s->ptr, s->cols, s->sc.iter, s->ctx->stream, &wp)) return rc;
     if (!wp.ok) return CGAMD_OK;
+    if ((size_t)((s->n / (int)(16 / dtype_size(s->dtype)) + kBlock - 1) / kBlock) > s->part_rr_cap) return CGAMD_OK;     // (cannot happen: sized at creation)
     if (s->resw_sync && wp.sync_bytes > s->resw.sync_bytes) { (void)hipFree(s->resw_sync); s->resw_sync = nullptr; }
     if (!s->resw_sync)
         if (int rc = dmalloc(&s->resw_sync, wp.sync_bytes, "wide resident sync words")) return rc;
     s->resw = wp;
     s->rm_ok = false;       // the chip-wide resident groups keep the caller's RHS-major layout (and beat the row-major loop: 1M x 32 fp64)
     return CGAMD_OK;
+}
+static int setup_resident_wide(cgamd_solver *s) {
+    const int rc = setup_resident_wide_plan(s);
+    s->res_ok = false;
+    apply_wide_order(s);
+    return rc;
 }
 
 // (re)build the one-byte column codes for the matrix now in s->cols; dropped when they do not apply
@@ -211,7 +239,13 @@ static int setup_index_codes(cgamd_solver *s) {
     return CGAMD_OK;
 }
 
+static int setup_resident_local(cgamd_solver *s);
 static int setup_resident(cgamd_solver *s) {
+    const int rc = setup_resident_local(s);
+    apply_wide_order(s);
+    return rc;
+}
+static int setup_resident_local(cgamd_solver *s) {
     s->res_ok = false;
     if (int rc = setup_resident_wide(s)) return rc;
     if (!s->fused2 || tune().resident == 0 || s->n > 65536) return CGAMD_OK;
@@ -360,7 +394,9 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     // the row-major SpMM writes one d.q partial per work-group of its sweep: at most 8 XCDs x 32 CUs x 8 work-groups
     s->part_dq_cap = (size_t)std::max(std::max(s->plan.grid, s->plan.row_blocks), s->rm_ok ? 2048 : 0);
     if (!rc) rc = dmalloc(&s->part_dq, acc_size(dtype) * s->part_dq_cap * nRHS, "partials_dq");
-    if (!rc) rc = dmalloc(&s->part_rr, acc_size(dtype) * (size_t)std::max(s->vgrid, s->rm_vgrid) * nRHS, "partials_rr");
+    // (handles the chip-wide resident loop may take over size their vector launches one pack per thread: apply_wide_order)
+    s->part_rr_cap = (size_t)std::max(std::max(s->vgrid, s->rm_vgrid), n_int <= (1 << 20) + 4096 ? (int)((n_int / (16 / vs) + kBlock - 1) / kBlock) : 0);
+    if (!rc) rc = dmalloc(&s->part_rr, acc_size(dtype) * s->part_rr_cap * nRHS, "partials_rr");
     if (!rc) rc = dmalloc(&s->sc.alpha, vs * nRHS, "alpha");
     if (!rc) rc = dmalloc(&s->sc.beta, vs * nRHS, "beta");
     if (!rc) rc = dmalloc(&s->sc.delta, vs * nRHS, "delta");
@@ -531,7 +567,7 @@ int cgamd_solver_set_preconditioner(cgamd_solver *s, const void *m, int on_devic
     const size_t vs = dtype_size(s->dtype);
     int rc = CGAMD_OK;
     if (!s->mdiag) rc = dmalloc(&s->mdiag, (size_t)s->n * vs, "preconditioner");
-    if (!rc && !s->part_rz) rc = dmalloc(&s->part_rz, acc_size(s->dtype) * (size_t)s->vgrid * s->nrhs, "partials_rz");
+    if (!rc && !s->part_rz) rc = dmalloc(&s->part_rz, acc_size(s->dtype) * s->part_rr_cap * s->nrhs, "partials_rz");
     if (!rc && !s->rho2) rc = dmalloc(&s->rho2, 2 * vs * (size_t)s->nrhs, "rho");
     if (rc) return rc;
     if (s->n != s->n_user) CG_HIP(hipMemsetAsync(s->mdiag, 0, (size_t)s->n * vs, s->ctx->stream));
@@ -801,7 +837,7 @@ int cgamd_solver_loop_launches(cgamd_solver *s) {
     if (fused2_now(s) && s->res_ok && !(s->flags & CGAMD_NO_GRAPH)) return 0;
     if (s->resw.ok && !(s->flags & CGAMD_NO_GRAPH)) return 1;       // chip-wide resident group (not bit-identical to the launched loops)
     if (fused2_now(s)) return 2;
-    return fold_alpha_ok(s->plan.n_partials) ? 3 : 4;
+    return fold_alpha_ok(s->plan.n_partials, s->plan.fold_max) ? 3 : 4;
 }
 
 int cgamd_solver_index_codes(cgamd_solver *s) { return s ? s->n_offsets : -CGAMD_ERR_INVALID; }

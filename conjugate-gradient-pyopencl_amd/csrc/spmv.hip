@@ -410,7 +410,7 @@ template <typename T> struct FusedArgs {
     const T *r;                     // residual (RHS-major like x)
     T *dnew;                        // search direction of this iteration (x = previous one)
     const typename VT<T>::acc *part_rr;
-    int P;                          // r.r partials per RHS
+    int P, K;                       // r.r partials per RHS; order of their sum (reduce_device.h thread_partials)
     T *delta, *beta, *history;
     int history_cap;
     const int *iter;
@@ -439,8 +439,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_fused_kernel(SpmvArgs<T> a, FusedA
         const int it = *f.iter;
         A acc = vzero<A>();
         if (it > 0) {
-            const A *p = f.part_rr + (long long)rhs * f.P;
-            for (int i = t; i < f.P; i += BLOCK) acc = vadd(acc, p[i]);
+            acc = thread_partials<BLOCK>(f.part_rr + (long long)rhs * f.P, f.P, f.K);
         }
         const A tot = block_sum<BLOCK>(acc, red);
         if (t == 0) {
@@ -498,9 +497,7 @@ __global__ __launch_bounds__(BLOCK) void cg_tail_kernel(FusedArgs<T> f, int nrhs
     __shared__ A red[BLOCK / kWave];
     const int it = *f.iter, r = blockIdx.x;
     if (it <= 0) return;
-    A acc = vzero<A>();
-    const A *p = f.part_rr + (long long)r * f.P;
-    for (int i = threadIdx.x; i < f.P; i += BLOCK) acc = vadd(acc, p[i]);
+    const A acc = thread_partials<BLOCK>(f.part_rr + (long long)r * f.P, f.P, f.K);
     const A tot = block_sum<BLOCK>(acc, red);
     if (threadIdx.x == 0) {
         const T dnT = from_acc<T>(tot);
@@ -868,7 +865,7 @@ int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, h
 // ---- two-launch iteration: SpMV fused with the previous iteration's beta / aypx ---------------------------------
 bool fused2_ok(const SpmvPlan &plan, int dtype, int nrhs, const void *vals, const int *cols) {
     (void)dtype;
-    if (tune().two_launch == 0 || !fold_alpha_ok(plan.n_partials)) return false;
+    if (tune().two_launch == 0 || !fold_alpha_ok(plan.n_partials, plan.fold_max)) return false;
     if (!aligned16(vals) || !aligned16(cols)) return false;
     // measured (profiles/r2/configs_two_launch.log): the second gather pays for the saved launch up to a few hundred
     // thousand rows; at N = 1M (3907 row blocks) the three/four-launch loops are faster
@@ -890,7 +887,7 @@ static int spmv_fused_impl(const SpmvPlan &plan, int n, long long nnz, const voi
     a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
     FusedArgs<T> f;
     f.r = static_cast<const T *>(r); f.dnew = static_cast<T *>(d_new);
-    f.part_rr = static_cast<const A *>(part_rr); f.P = P;
+    f.part_rr = static_cast<const A *>(part_rr); f.P = P; f.K = sc.krr;
     f.delta = (T *)sc.delta; f.beta = (T *)sc.beta; f.history = (T *)sc.history; f.history_cap = sc.history_cap; f.iter = sc.iter;
     const dim3 g(rowblock_grid(plan.row_blocks, a.cycle), nrhs), b(kBlock);
     const bool nt = tune().spmv_nt >= 0 ? (tune().spmv_nt != 0) : (plan.nt != 0);
@@ -908,7 +905,7 @@ int launch_spmv_fused(int dtype, const SpmvPlan &plan, int n, long long nnz, con
 template <typename T> static int cg_tail_impl(const void *part_rr, int P, int nrhs, const CgScalars &sc, hipStream_t st) {
     using A = typename VT<T>::acc;
     FusedArgs<T> f;
-    f.r = nullptr; f.dnew = nullptr; f.part_rr = static_cast<const A *>(part_rr); f.P = P;
+    f.r = nullptr; f.dnew = nullptr; f.part_rr = static_cast<const A *>(part_rr); f.P = P; f.K = sc.krr;
     f.delta = (T *)sc.delta; f.beta = (T *)sc.beta; f.history = (T *)sc.history; f.history_cap = sc.history_cap; f.iter = sc.iter;
     hipLaunchKernelGGL((cg_tail_kernel<T, kBlock>), dim3(nrhs), dim3(kBlock), 0, st, f, nrhs);
     return check_launch("cg_tail");

@@ -84,7 +84,7 @@ constexpr int kFoldAlphaMax = 2048;     // N <= 524k rows; beyond, the separate 
 template <typename T, int BLOCK, bool VEC>
 __global__ __launch_bounds__(BLOCK) void axpy2_dot_alpha_kernel(int n, const T *__restrict__ d, T *__restrict__ x,
                                                                 const T *__restrict__ q, T *__restrict__ rv, long long ld,
-                                                                const typename VT<T>::acc *__restrict__ part_dq, int P,
+                                                                const typename VT<T>::acc *__restrict__ part_dq, int P, int K,
                                                                 const T *__restrict__ delta, T *alpha, int *iter,
                                                                 typename VT<T>::acc *__restrict__ partials) {
     using A = typename VT<T>::acc;
@@ -92,9 +92,7 @@ __global__ __launch_bounds__(BLOCK) void axpy2_dot_alpha_kernel(int n, const T *
     __shared__ T alpha_s;
     const int r = blockIdx.y;
     {
-        A acc = vzero<A>();
-        const A *p = part_dq + (long long)r * P;
-        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, p[i]);
+        const A acc = thread_partials<BLOCK>(part_dq + (long long)r * P, P, K);
         const A dq = block_sum<BLOCK>(acc, red);
         if (threadIdx.x == 0) {
             const T dqT = from_acc<T>(dq);      // the reference rounds d.q to the value type before dividing (clcg.c:318-327)
@@ -157,7 +155,7 @@ __global__ __launch_bounds__(BLOCK) void axpy_dot_kernel(int n, const T *__restr
 // small systems: alpha in the prologue (see axpy2_dot_alpha_kernel)
 template <typename T, int BLOCK, bool VEC>
 __global__ __launch_bounds__(BLOCK) void axpy_dot_alpha_kernel(int n, const T *__restrict__ q, T *__restrict__ rv, long long ld,
-                                                               const typename VT<T>::acc *__restrict__ part_dq, int P,
+                                                               const typename VT<T>::acc *__restrict__ part_dq, int P, int K,
                                                                const T *__restrict__ delta, T *alpha, int *iter,
                                                                typename VT<T>::acc *__restrict__ partials) {
     using A = typename VT<T>::acc;
@@ -165,9 +163,7 @@ __global__ __launch_bounds__(BLOCK) void axpy_dot_alpha_kernel(int n, const T *_
     __shared__ T alpha_s;
     const int r = blockIdx.y;
     {
-        A acc = vzero<A>();
-        const A *p = part_dq + (long long)r * P;
-        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, p[i]);
+        const A acc = thread_partials<BLOCK>(part_dq + (long long)r * P, P, K);
         const A dq = block_sum<BLOCK>(acc, red);
         if (threadIdx.x == 0) {
             const T dqT = from_acc<T>(dq);
@@ -250,16 +246,14 @@ __global__ __launch_bounds__(BLOCK) void ewise_kernel(int n, const T *__restrict
 // alone writes delta/beta/history[iter].  The iteration counter was advanced by cg_alpha.
 template <typename T, int BLOCK, bool VEC>
 __global__ __launch_bounds__(BLOCK) void aypx_beta_kernel(int n, const T *__restrict__ x, T *__restrict__ y, long long ld,
-                                                          const typename VT<T>::acc *__restrict__ partials, int P,
+                                                          const typename VT<T>::acc *__restrict__ partials, int P, int K,
                                                           int nrhs, T *delta, T *beta, T *history, int history_cap, const int *iter) {
     using A = typename VT<T>::acc;
     __shared__ A red[BLOCK / kWave];
     __shared__ T beta_s;
     const int r = blockIdx.y;
     {
-        A acc = vzero<A>();
-        const A *p = partials + (long long)r * P;
-        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, p[i]);
+        const A acc = thread_partials<BLOCK>(partials + (long long)r * P, P, K);
         const A tot = block_sum<BLOCK>(acc, red);
         if (threadIdx.x == 0) {
             const int it = *iter;
@@ -297,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_kernel(int n, const T *__rest
 // the same with the deferred x += alpha d (ten-vector-pass iteration): xs = solution vector, alpha of THIS iteration
 template <typename T, int BLOCK, bool VEC, int VNT>
 __global__ __launch_bounds__(BLOCK) void aypx_beta_x_kernel(int n, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ xs,
-                                                            long long ld, const typename VT<T>::acc *__restrict__ partials, int P,
+                                                            long long ld, const typename VT<T>::acc *__restrict__ partials, int P, int K,
                                                             int nrhs, const T *__restrict__ alpha, T *delta, T *beta, T *history,
                                                             int history_cap, const int *iter) {
     using A = typename VT<T>::acc;
@@ -305,9 +299,7 @@ __global__ __launch_bounds__(BLOCK) void aypx_beta_x_kernel(int n, const T *__re
     __shared__ T beta_s;
     const int r = blockIdx.y;
     {
-        A acc = vzero<A>();
-        const A *p = partials + (long long)r * P;
-        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, p[i]);
+        const A acc = thread_partials<BLOCK>(partials + (long long)r * P, P, K);
         const A tot = block_sum<BLOCK>(acc, red);
         if (threadIdx.x == 0) {
             const int it = *iter;
@@ -530,11 +522,11 @@ __global__ __launch_bounds__(kScalarBlock) void cg_delta0_kernel(const typename 
 // alpha[r] = delta[r] / (d.q)[r].  Block 0 also advances the iteration counter: the counter is only READ by
 // the cg_beta kernel of the same iteration (a later launch), never inside this launch.
 template <typename T>
-__global__ __launch_bounds__(kScalarBlock) void cg_alpha_kernel(const typename VT<T>::acc *partials, int grid, int nrhs,
+__global__ __launch_bounds__(kScalarBlock) void cg_alpha_kernel(const typename VT<T>::acc *partials, int grid, int K, int nrhs,
                                                        const T *delta, T *alpha, int *iter) {
     __shared__ typename VT<T>::acc smem[kScalarBlock / kWave];
     const int r = blockIdx.x;
-    const auto dq = sum_partials_block(partials + (long long)r * grid, grid, smem);
+    const auto dq = sum_partials_block(partials + (long long)r * grid, grid, smem, K);
     if (threadIdx.x == 0) {
         // the reference rounds dq to the value type before dividing (clcg.c:318-327)
         const T dqT = from_acc<T>(dq);
@@ -701,8 +693,8 @@ static int axpy2_alpha_impl(int n, const void *d, void *x, const void *q, void *
                             const CgScalars &sc, int nrhs, void *partials, int grid, bool vec, hipStream_t st) {
     dim3 g(grid, nrhs), blk(kBlock);
     using A = typename VT<T>::acc;
-    if (vec) hipLaunchKernelGGL((axpy2_dot_alpha_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const A *)part_dq, P, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
-    else hipLaunchKernelGGL((axpy2_dot_alpha_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const A *)part_dq, P, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
+    if (vec) hipLaunchKernelGGL((axpy2_dot_alpha_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const A *)part_dq, P, sc.kdq, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
+    else hipLaunchKernelGGL((axpy2_dot_alpha_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)d, (T *)x, (const T *)q, (T *)r, ld, (const A *)part_dq, P, sc.kdq, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
     return check_launch("axpy2_dot_alpha");
 }
 template <typename T>
@@ -726,8 +718,8 @@ static int axpy_dot_alpha_impl(int n, const void *q, void *r, long long ld, cons
                                void *partials, int grid, bool vec, hipStream_t st) {
     dim3 g(grid, nrhs), blk(kBlock);
     using A = typename VT<T>::acc;
-    if (vec) hipLaunchKernelGGL((axpy_dot_alpha_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)q, (T *)r, ld, (const A *)part_dq, P, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
-    else hipLaunchKernelGGL((axpy_dot_alpha_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)q, (T *)r, ld, (const A *)part_dq, P, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
+    if (vec) hipLaunchKernelGGL((axpy_dot_alpha_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)q, (T *)r, ld, (const A *)part_dq, P, sc.kdq, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
+    else hipLaunchKernelGGL((axpy_dot_alpha_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)q, (T *)r, ld, (const A *)part_dq, P, sc.kdq, (const T *)sc.delta, (T *)sc.alpha, sc.iter, (A *)partials);
     return check_launch("axpy_dot_alpha");
 }
 int launch_axpy_dot_alpha(int dtype, int n, const void *q, void *r, long long ld, const void *part_dq, int P, const CgScalars &sc,
@@ -740,7 +732,7 @@ static int aypx_beta_x_impl(int n, const void *x, void *y, void *xs, long long l
                             const CgScalars &sc, bool vec, int vnt, hipStream_t st) {
     dim3 g(vec_grid(n, VT<T>::dtype, nrhs), nrhs), blk(kBlock);
     auto *pp = static_cast<const typename VT<T>::acc *>(partials);
-#define CG_AX(V, N) hipLaunchKernelGGL((aypx_beta_x_kernel<T, kBlock, V, N>), g, blk, 0, st, n, (const T *)x, (T *)y, (T *)xs, ld, pp, P, nrhs, \
+#define CG_AX(V, N) hipLaunchKernelGGL((aypx_beta_x_kernel<T, kBlock, V, N>), g, blk, 0, st, n, (const T *)x, (T *)y, (T *)xs, ld, pp, P, sc.krr, nrhs, \
                                        (const T *)sc.alpha, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (const int *)sc.iter)
     if (vec && (vnt & 1)) CG_AX(true, 1); else if (vec) CG_AX(true, 0); else CG_AX(false, 0);
 #undef CG_AX
@@ -753,7 +745,7 @@ int launch_aypx_beta_x(int dtype, int n, const void *x, void *y, void *xs, long 
     const int vnt = tune().vec_nt >= 0 ? tune().vec_nt : vec_nt;
     CG_DISPATCH(dtype, aypx_beta_x_impl, n, x, y, xs, ld, partials, P, nrhs, sc, v, vnt, st);
 }
-bool fold_alpha_ok(int n_partials) { return tune().dev_no_fold_alpha == 0 && n_partials <= kFoldAlphaMax; }
+bool fold_alpha_ok(int n_partials, int fold_max) { return tune().dev_no_fold_alpha == 0 && n_partials <= (fold_max > 0 ? fold_max : kFoldAlphaMax); }
 int launch_axpy2_dot_alpha(int dtype, int n, const void *d, void *x, const void *q, void *r, long long ld, const void *part_dq,
                            int P, const CgScalars &sc, int nrhs, void *partials, int grid, hipStream_t st) {
     const bool vec = vec_ok(dtype, ld, nrhs, {d, x, q, r});
@@ -781,7 +773,7 @@ template <typename T> static int alpha_impl(const void *partials, int grid, int 
                            grid, nrhs, (const T *)s.delta, (T *)s.alpha, s.iter, (A *)s.stage, s.ticket);
     else
         hipLaunchKernelGGL((cg_alpha_kernel<T>), dim3(nrhs), dim3(kScalarBlock), 0, st, static_cast<const A *>(partials),
-                           grid, nrhs, (const T *)s.delta, (T *)s.alpha, s.iter);
+                           grid, s.kdq, nrhs, (const T *)s.delta, (T *)s.alpha, s.iter);
     return check_launch("cg_alpha");
 }
 int launch_cg_alpha(int dtype, const void *partials, int grid, int nrhs, const CgScalars &s, hipStream_t st) {
@@ -820,8 +812,8 @@ static int aypx_beta_impl(int n, const void *x, void *y, long long ld, const voi
                           const CgScalars &sc, bool vec, hipStream_t st) {
     dim3 g(vec_grid(n, VT<T>::dtype, nrhs), nrhs), blk(kBlock);
     auto *pp = static_cast<const typename VT<T>::acc *>(partials);
-    if (vec) hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter);
-    else hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter);
+    if (vec) hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, sc.krr, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter);
+    else hipLaunchKernelGGL((aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)x, (T *)y, ld, pp, P, sc.krr, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, sc.iter);
     return check_launch("aypx_beta");
 }
 int launch_aypx_beta(int dtype, int n, const void *x, void *y, long long ld, const void *partials, int P, int nrhs,

@@ -1,7 +1,9 @@
 """Chip-wide resident loop (csrc/resident.hip, cg_resident_wide_kernel): one group of up to 256 work-groups for a single
 right-hand side, the matrix in registers, all iterations of an iterate() call in one launch -- BASELINE configs 2 (1M rows,
-2-D 5-point, fp64) and 3 (250k rows, helmFE_var(500), complex64).  It forms one partial sum per work-group, so it is held
-to the oracle (fp64: 1e-10 on delta_k, as every loop) and to the launched loop within rounding, not to bit-identity."""
+2-D 5-point, fp64) and 3 (250k rows, helmFE_var(500), complex64).  It is held to the oracle (fp64: 1e-10 on delta_k, as every
+loop), and to the launched loops of the SAME handle bit for bit: a handle this loop can take over runs its launched loops with
+the member-blocked order of the partial sums (csrc/reduce_device.h thread_partials), which is the order the members of the
+resident group form them in -- so the bits do not depend on how a solve is cut into iterate() calls."""
 import numpy as np
 import pytest
 
@@ -83,6 +85,57 @@ def test_wide_resident_loop_against_oracle_and_launched_loop(pkg, gpu, dtype, ki
     assert ex < (1e-10 if wide64 else 5e-3), ex
 
 
+@pytest.mark.parametrize("dtype,kind,nrhs", [
+    (np.float64, "poisson1000", 1),              # config 2 at full size (3907 d.q partials: the folded alpha reaches up to 4096 on these handles)
+    (np.complex128, "helm500", 1),               # config 3 at full size, the build's wide type
+    (np.complex64, "helm500", 1),                # ... and the reference's
+    (np.float32, "poisson300", 1),
+    (np.float64, "poisson300", 3),               # three right-hand sides, claimed in turn by one group
+    (np.float64, "band50000", 1),                # irregular rows, last member partial
+])
+def test_bits_do_not_depend_on_the_call_lengths(pkg, gpu, dtype, kind, nrhs):
+    """iterate(30) (chip-wide resident loop), iterate(15) twice (launched loops: calls below resident_wide_min), 16 + 14 (resident,
+    then launched on its state), 14 + 16 (the other way round) and the launched loops alone (resident_wide_min out of reach) return the
+    same x and the same residual history, bit for bit (results depended on the call length)."""
+    ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
+    if kind == "helm500":
+        ip, ix, da = cg_numpy.helm_fe_var(500, 12.0, np.ones((499, 499)), 0.15, 500, 500)
+    elif kind.startswith("band"):
+        from test_gpu_resident import _banded_spd
+        ip, ix, da = _banded_spd(int(kind[4:]), 3, 0.8, 50)
+    else:
+        ip, ix, da = cg_numpy.poisson2d(int(kind[7:]))
+    n = len(ip) - 1
+    wide_t = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    rng = np.random.default_rng(n + nrhs)
+    b = np.concatenate([(1.0 + r + rand_vec(rng, n, wide_t)) for r in range(nrhs)]).astype(dtype)
+    A = da.astype(dtype)
+
+    def run(calls, wide_min=16):
+        pkg._lib.check(lib.cgamd_tune(b"resident_wide_min", wide_min))
+        try:
+            s = pkg.Solver(ctx, n, len(ix), A, ip, ix, nrhs)
+            s.set_rhs(b, None)
+            kind_ = lib.cgamd_solver_loop_launches(s.handle)
+            for c in calls:
+                s.iterate(c)
+            out = (s.x(), s.history(), kind_)
+            s.close()
+            return out
+        finally:
+            pkg._lib.check(lib.cgamd_tune(b"resident_wide_min", 16))
+
+    whole = run([30])
+    assert whole[2] == 1
+    for calls, wm in (([15, 15], 16), ([16, 14], 16), ([14, 16], 16), ([30], 1 << 20), ([7, 1, 22], 16)):
+        other = run(calls, wm)
+        assert other[2] == 1                     # the same kind of handle: the resident loop can take it over
+        assert np.array_equal(whole[1], other[1]), (calls, wm, "history")
+        assert np.array_equal(whole[0], other[0]), (calls, wm, "x")
+    assert np.all(np.isfinite(whole[1]))
+
+
 @pytest.mark.parametrize("n_side,nrhs,want_kind", [(128, 3, 0), (300, 1, 1)])
 def test_resident_launch_that_cannot_form_its_group_falls_back_untouched(pkg, gpu, n_side, nrhs, want_kind):
     """CUs held by other work: a resident launch whose group never fills gives up before touching anything (bounded wait), and
@@ -108,11 +161,13 @@ def test_resident_launch_that_cannot_form_its_group_falls_back_untouched(pkg, gp
             return out
         finally:
             for k in knobs:
-                pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_claim_ms": 200}.get(k, 0)))
+                pkg._lib.check(lib.cgamd_tune(k.encode(), {"resident": 1, "resident_claim_ms": 200, "resident_wide_min": 16}.get(k, 0)))
 
-    x0, h0, _, k0 = run({"resident": 0})
+    # the launched loops of the same kind of handle (one the chip-wide loop can take over sums its partials in the members' order)
+    x0, h0, _, k0 = run({"resident": 0} if want_kind == 0 else {"resident_wide_min": 1 << 20})
     x1, h1, before, after = run({"dev.resident_test_short_grid": 1, "resident_claim_ms": 40})
-    assert before == want_kind and after == k0 >= 2          # resident loop chosen at first, launched loops after the failed launch
+    assert before == want_kind and after >= 2                # resident loop chosen at first, launched loops after the failed launch
+    assert k0 == (after if want_kind == 0 else 1)
     assert np.array_equal(h1, h0) and np.array_equal(x1, x0)
 
 
