@@ -517,8 +517,16 @@ template <typename T> struct ResWideArgs {
 // 256-thread block sums of its N per-thread values -- block 2 i + (t >> 8): wave tree, then ((w0 + w1) + w2) + w3, exactly
 // block_sum<256> of the launched kernels -- added in block order starting from zero.  Result valid in thread 0.  Every wave's
 // outstanding stores are acknowledged before the barrier (see wg_sum).
-CG_DEV double shfl_acc(double v, int l) { return __shfl(v, l, kWave); }
-CG_DEV double2 shfl_acc(double2 v, int l) { return make_double2(__shfl(v.x, l, kWave), __shfl(v.y, l, kWave)); }
+template <int L> CG_DEV double lane_of(double v) {     // lane L's value in every lane (v_readlane: no LDS trip)
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, L), hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), L);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int L> CG_DEV double2 lane_of(double2 v) { return make_double2(lane_of<L>(v.x), lane_of<L>(v.y)); }
+template <typename A, int C, int N2> struct BlockChain {       // tot = (((0 + b_0) + b_1) + ...) + b_{N2-1}
+    static CG_DEV A run(A tot, A b) { return BlockChain<A, C + 1, N2>::run(vadd(tot, lane_of<C>(b)), b); }
+};
+template <typename A, int N2> struct BlockChain<A, N2, N2> { static CG_DEV A run(A tot, A) { return tot; } };
 template <typename A, int N> CG_DEV A member_sum(A (&v)[N], A (*wsn)[kResThreads / kWave]) {
     static_assert(kResThreads == 512 && kResThreads / 256 == kResWideBlocksPerRpt, "two 256-thread blocks per value");
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
@@ -536,8 +544,7 @@ template <typename A, int N> CG_DEV A member_sum(A (&v)[N], A (*wsn)[kResThreads
             const A *w = &wsn[lane >> 1][4 * (lane & 1)];
             b = vadd(vadd(vadd(w[0], w[1]), w[2]), w[3]);
         }
-#pragma unroll
-        for (int c = 0; c < 2 * N; ++c) tot = vadd(tot, shfl_acc(b, c));
+        tot = BlockChain<A, 0, 2 * N>::run(tot, b);
     }
     return tot;
 }

@@ -183,7 +183,7 @@ static void apply_wide_order(cgamd_solver *s) {
     const bool wide = s->resw.ok && !s->res_ok;      // (where the one-XCD resident loop applies it runs, with the strided order)
     const int kdq = wide ? kResWideBlocksPerRpt * s->resw.rpt : 0, krr = wide ? kdq / E : 0;
     const int vgrid = wide ? (s->n / E + kBlock - 1) / kBlock : vec_grid(s->n, s->dtype, s->nrhs);
-    const int fold_max = wide ? 4096 : 0;
+    const int fold_max = 0;      // (alpha folded beyond 2048 partials was tried for these handles: every work-group summing 3907 partials, 1M rows 30 -> 52 us)
     if (kdq == s->sc.kdq && krr == s->sc.krr && vgrid == s->vgrid && fold_max == s->plan.fold_max) return;
     destroy_graphs(s);
     s->sc.kdq = kdq; s->sc.krr = krr; s->vgrid = vgrid; s->plan.fold_max = fold_max;
