@@ -274,7 +274,7 @@ struct ResidentWidePlan {
     size_t lds_bytes = 0, sync_bytes = 0;
 };
 int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, const int *ptr_dev, const int *cols_dev, int *scratch_dev,
-                       hipStream_t st, ResidentWidePlan *out);
+                       hipStream_t st, ResidentWidePlan *out, bool small_ok = false);
 // state in and out: x, r, d of iteration k in (k & 1 ? d1 : d0), delta / beta / alpha / history / iter; d_ready: on entry d is
 // already beta d + r (three / four-launch loops); on exit d is always the direction of the last iteration (two-launch
 // convention) and the launched loops' r.r partials are NOT maintained -- the caller converts / rebuilds

@@ -1129,11 +1129,11 @@ static int resident_wide_launch(const ResWideArgs<T> &a, size_t lds, int grid, h
 // solving one after the other where that beats the launched loops' streaming cost per right-hand side (a small model, below).
 // Synchronises `st` (a pass over the matrix per candidate).
 int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, const int *ptr_dev, const int *cols_dev, int *scratch_dev,
-                       hipStream_t st, ResidentWidePlan *out) {
+                       hipStream_t st, ResidentWidePlan *out, bool small_ok) {
     out->ok = false;
     const int mode = tune().resident_wide;
-    // systems the one-XCD loop could hold by size stay with the loops that are bit-identical to each other
-    if (mode == 0 || nrhs < 1 || n_cus < 8 || n <= 32768) return CGAMD_OK;
+    // systems the one-XCD loop could hold by size: only when the caller found that it does not (small_ok)
+    if (mode == 0 || nrhs < 1 || n_cus < 8 || (n <= 32768 && !small_ok) || n < 2048) return CGAMD_OK;
     const int E = (int)(16 / dtype_size(dtype));
     if (n % E) return CGAMD_OK;
     const int forced = tune().resident_wide_rpt;

@@ -200,7 +200,9 @@ static int setup_resident_wide_plan(cgamd_solver *s) {
     if (s->n % (int)(16 / dtype_size(s->dtype)) != 0) return CGAMD_OK;
     if (!s->n_cus) CG_HIP(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->ctx->device));
     ResidentWidePlan wp;
-    if (int rc = resident_wide_plan(s->dtype, s->n, s->nnz, s->nrhs, s->n_cus, s->ptr, s->cols, s->sc.iter, s->ctx->stream, &wp)) return rc;
+    // (systems of up to 32768 rows only where the two-launch loop is the handle's launched loop and the one-XCD loop cannot hold them:
+    // complex128 with 7-entry rows, 1024 rows x 20 bytes per entry do not fit LDS)
+    if (int rc = resident_wide_plan(s->dtype, s->n, s->nnz, s->nrhs, s->n_cus, s->ptr, s->cols, s->sc.iter, s->ctx->stream, &wp, s->fused2)) return rc;
     if (!wp.ok) return CGAMD_OK;
     if ((size_t)((s->n / (int)(16 / dtype_size(s->dtype)) + kBlock - 1) / kBlock) > s->part_rr_cap) return CGAMD_OK;     // (cannot happen: sized at creation)
     if (s->resw_sync && wp.sync_bytes > s->resw.sync_bytes) { (void)hipFree(s->resw_sync); s->resw_sync = nullptr; }
@@ -209,12 +211,6 @@ static int setup_resident_wide_plan(cgamd_solver *s) {
     s->resw = wp;
     s->rm_ok = false;       // the chip-wide resident groups keep the caller's RHS-major layout (and beat the row-major loop: 1M x 32 fp64)
     return CGAMD_OK;
-}
-static int setup_resident_wide(cgamd_solver *s) {
-    const int rc = setup_resident_wide_plan(s);
-    s->res_ok = false;
-    apply_wide_order(s);
-    return rc;
 }
 
 // (re)build the one-byte column codes for the matrix now in s->cols; dropped when they do not apply
@@ -245,9 +241,16 @@ static int setup_resident(cgamd_solver *s) {
     apply_wide_order(s);
     return rc;
 }
+// the one-XCD loop where it applies (bit-identical to the two-launch loop as it is); else the chip-wide groups
+static int setup_resident_one_xcd(cgamd_solver *s);
 static int setup_resident_local(cgamd_solver *s) {
     s->res_ok = false;
-    if (int rc = setup_resident_wide(s)) return rc;
+    s->resw.ok = false;
+    if (int rc = setup_resident_one_xcd(s)) return rc;
+    if (s->res_ok) return CGAMD_OK;
+    return setup_resident_wide_plan(s);
+}
+static int setup_resident_one_xcd(cgamd_solver *s) {
     if (!s->fused2 || tune().resident == 0 || s->n > 65536) return CGAMD_OK;
     std::vector<int> tmp;
     const int *ph = s->ptr_host.size() == (size_t)s->n + 1 ? s->ptr_host.data() : nullptr;
@@ -263,7 +266,8 @@ static int setup_resident_local(cgamd_solver *s) {
     int max_window = 0;
     if (s->n % (int)(16 / dtype_size(s->dtype)) == 0)
         if (int rc = resident_max_window(s->dtype, s->n, s->ptr, s->cols, s->sc.iter, s->ctx->stream, &max_window)) return rc;
-    if (!resident_plan(s->dtype, s->n, s->vgrid, s->plan.n_partials, s->n_cus, ph, max_window, &rp)) return CGAMD_OK;
+    // (checked against the plain launched configuration: the vector grid of a handle no chip-wide loop takes over)
+    if (!resident_plan(s->dtype, s->n, vec_grid(s->n, s->dtype, s->nrhs), s->plan.n_partials, s->n_cus, ph, max_window, &rp)) return CGAMD_OK;
     if (s->res_sync && rp.sync_bytes > s->res.sync_bytes) { (void)hipFree(s->res_sync); s->res_sync = nullptr; }
     if (!s->res_sync)
         if (int rc = dmalloc(&s->res_sync, rp.sync_bytes, "resident sync words")) return rc;
@@ -328,7 +332,7 @@ int cgamd_solver_create(cgamd_ctx *ctx, int dtype, int size, long long nnz, cons
     // 1 %, complex64 x 16 slower).  spmm_rowmajor = 2 takes it for every supported type, 0 never.
     const int rm_knob = tune().spmm_rowmajor;
     // (up to 32768 rows the resident loop is several times faster than any launched loop; between that and ~1M rows the chip-wide
-    // resident groups take over when they apply, setup_resident_wide)
+    // resident groups take over when they apply, setup_resident_wide_plan)
     const bool rm_wins = dtype == CGAMD_F64 && nRHS == 32 && size > 32768;
     s->rm_ok = nRHS > 1 && (rm_knob >= 2 || (rm_knob == 1 && rm_wins)) && !(flags & CGAMD_UNFUSED) && spmm_rm_supported(dtype, nRHS, size);
     if (s->rm_ok) s->rm_vgrid = rm_vec_grid((long long)size * nRHS, dtype);

@@ -136,6 +136,42 @@ def test_bits_do_not_depend_on_the_call_lengths(pkg, gpu, dtype, kind, nrhs):
     assert np.all(np.isfinite(whole[1]))
 
 
+@pytest.mark.parametrize("N,nrhs", [(128, 1), (128, 9), (100, 2)])
+def test_small_complex128_fe_systems_run_the_chip_wide_groups(pkg, gpu, N, nrhs):
+    """helmFE_var(128) in complex128 (16 384 rows x 7 entries: 1024 rows x 20 bytes per entry do not fit the one-XCD loop's LDS) ran
+    two launches per iteration until round 3.  The chip-wide groups take such handles over now: same bits as the
+    handle's launched loops, oracle tolerance, one launch per call."""
+    ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
+    ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    n = len(ip) - 1
+    rng = np.random.default_rng(N + nrhs)
+    b = np.concatenate([(1.0 + r + rand_vec(rng, n, np.complex128)) for r in range(nrhs)])
+
+    def run(calls, wide_min=16):
+        pkg._lib.check(lib.cgamd_tune(b"resident_wide_min", wide_min))
+        try:
+            s = pkg.Solver(ctx, n, len(ix), da.astype(np.complex128), ip, ix, nrhs)
+            s.set_rhs(b, None)
+            kind = lib.cgamd_solver_loop_launches(s.handle)
+            for c in calls:
+                s.iterate(c)
+            out = (s.x(), s.history(), kind)
+            s.close()
+            return out
+        finally:
+            pkg._lib.check(lib.cgamd_tune(b"resident_wide_min", 16))
+
+    x, h, kind = run([40])
+    assert kind == 1
+    for calls, wm in (([20, 20], 16), ([40], 1 << 20), ([10, 30], 16)):
+        x2, h2, _ = run(calls, wm)
+        assert np.array_equal(h, h2) and np.array_equal(x, x2), (calls, wm)
+    xo, ho = cg_oracle.cg(ip, ix, da, b, nrhs=nrhs, n_iterations=40, mode=cg_oracle.MODE_SEQUENTIAL)
+    live = np.abs(ho) > 1e-6 * np.abs(ho[0])
+    assert np.max((np.abs(h - ho) / np.abs(ho))[live]) < 1e-10
+
+
 @pytest.mark.parametrize("n_side,nrhs,want_kind", [(128, 3, 0), (300, 1, 1)])
 def test_resident_launch_that_cannot_form_its_group_falls_back_untouched(pkg, gpu, n_side, nrhs, want_kind):
     """CUs held by other work: a resident launch whose group never fills gives up before touching anything (bounded wait), and
