@@ -59,6 +59,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "dev.generic_spmv") g_tune.dev_generic_spmv = value;
     else if (k == "dev.resident_lock") g_tune.resident_lock = value;
     else if (k == "dev.slab_cus") g_tune.slab_cus = value;
+    else if (k == "dev.slab_trim") g_tune.slab_trim = value;
     else if (k == "dev.resident_test_short_grid") g_tune.resident_test_short_grid = value;
     else if (k == "dev.resident_wide_rpt") g_tune.resident_wide_rpt = value;
     else if (k == "dev.resident_window") g_tune.resident_window = value;

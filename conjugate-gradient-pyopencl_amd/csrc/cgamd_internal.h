@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../../include/cgamd.h"
 
@@ -102,6 +103,7 @@ struct Tuning {
     int dev_no_fold_alpha = 0;      // 1: small systems keep the separate cg_alpha launch (the four-launch family at sizes that would fold it)
     int dev_generic_spmv = 0;       // 1: the generic chunked CSR stream for every matrix (the row-block kernels' fallback, tested against them)
     int resident_lock = 1;          // 0: no per-GPU serialisation of resident launches (ranks of ONE job sharing a GPU in a rehearsal)
+    int slab_trim = -1;             // slab loop: 1024-row granules a member that pushes to a peer owns fewer than the others (-1 = 2, 0 = equal members)
     int slab_cus = 0;               // slab loop: CUs (= members at most) a handle may use; 0 = all (ranks that share a GPU must fit side by side)
     int resident_test_short_grid = 0; // launch one work-group too few, so that no group can fill (the untouched-fallback tests)
     int resident_wide_rpt = 0;      // rows per thread of the chip-wide loop: 0 = the smallest that fits (4, then 8), or 4 / 8
@@ -285,10 +287,14 @@ int run_cg_resident_wide(int dtype, const ResidentWidePlan &wp, int n, int nrhs,
 // slab loop (slab.hip): every iteration of a call in one launch, vectors in registers, matrix streamed; systems of up to ~3M rows
 struct SlabPlan {
     bool ok = false;
-    int rows_m = 0, G = 0, nsteps = 0, cap = 0, ccap = 0, unroll = 8;
+    int rows_m = 0, G = 0, nsteps = 0, cap = 0, ccap = 0, unroll = 8;      // rows_m / nsteps: of the largest member
     size_t lds_bytes = 0, sync_bytes = 0;
+    const int *mstart = nullptr, *gmember = nullptr;      // device arrays of a non-uniform partition (slab_partition), owned by the caller
 };
 bool slab_plan(int dtype, int n, int n_cus, const SpmvPlan &plan, bool coded, SlabPlan *out);
+int slab_partition(const SlabPlan &sp, int n, const std::vector<char> &boundary, int trim, int max_members, std::vector<int> *mstart,
+                   std::vector<int> *gmember);
+size_t slab_sync_bytes(int G);
 // row-partitioned run of the slab loop: the peer-to-peer mailboxes of the handle (device arrays as in P2pExchange) and, per peer and
 // buffer parity, where this rank's boundary entries land in the PEER's published-d buffer
 struct SlabComm {

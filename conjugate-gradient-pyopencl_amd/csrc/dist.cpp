@@ -132,6 +132,7 @@ struct cgamd_dist {
     void *s2 = nullptr, *cg1_state = nullptr, *part_cg1 = nullptr;
     // slab loop (CGAMD_DIST_RESIDENT, slab.hip): every iteration of an iterate() call in one launch, vectors in registers
     SlabPlan slab, slab_plan_;         // slab: in use (ok); slab_plan_: what create found, waiting for its buffers (peer-to-peer handles)
+    int *slab_map = nullptr;            // member starts [G + 1] and granule owners of a non-uniform slab partition
     void *slab_sync = nullptr, *ds_own[2] = {nullptr, nullptr};     // ds_own: plain buffers of a handle without peers
     void *ds[2] = {nullptr, nullptr};  // where the slab loop publishes d: ds_own, or inside the rank's mailbox allocation
     void **push_dst_dev = nullptr;     // device [2][n_peers]
@@ -496,7 +497,7 @@ int cgamd_dist_destroy(cgamd_dist *d) {
     if (d->codes) (void)hipFree(d->codes);
     if (d->dict) (void)hipFree(d->dict);
     void *bufs[] = {d->x, d->r, d->q, d->b, d->d_ext, d->sendbuf, d->part_dq, d->part_rr, d->red, d->sc.alpha,
-                    d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter, d->s2, d->cg1_state, d->part_cg1, d->slab_sync, d->ds_own[0], d->ds_own[1],
+                    d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter, d->s2, d->cg1_state, d->part_cg1, d->slab_sync, d->slab_map, d->ds_own[0], d->ds_own[1],
                     d->push_dst_dev};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -726,7 +727,39 @@ int cgamd_dist_enable_resident(cgamd_dist *d, long long mailbox_values, const in
     c.send_index = d->send_index;
     c.push_dst = d->push_dst_dev;
     c.halo_epoch = d->epochs; c.red_seq = d->epochs + 3;
-    d->slab = d->slab_plan_;
+    SlabPlan sp = d->slab_plan_;
+    if (np > 0 && d->total_send > 0 && d->tune.slab_trim != 0) {
+        // members that push to a peer own fewer rows (slab_partition): try two granules fewer, then one
+        std::vector<int> send((size_t)d->total_send);
+        CG_HIP(hipMemcpy(send.data(), d->send_index, send.size() * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<char> boundary((size_t)(d->n_local + 1023) / 1024, 0);
+        for (int row : send)
+            if (row >= 0 && row < d->n_local) boundary[(size_t)row >> 10] = 1;
+        {   // ... and the rows that read a peer's entries (they wait for its flag)
+            std::vector<int> inner, outer;
+            if ((rc = classify_row_blocks(d, &inner, &outer))) return rc;
+            for (int rb : outer) boundary[(size_t)rb >> 2] = 1;
+        }
+        std::vector<int> mstart, gmember;
+        const int want = d->tune.slab_trim > 0 ? d->tune.slab_trim : 2;
+        for (int trim = std::min(want, sp.rows_m / 1024 - 1); trim >= 1; --trim) {
+            const int members = slab_partition(sp, d->n_local, boundary, trim, std::min(d->n_cus, 256), &mstart, &gmember);
+            if (members < 2) continue;
+            const size_t bytes = (mstart.size() + gmember.size()) * sizeof(int);
+            if (d->slab_map) { (void)hipFree(d->slab_map); d->slab_map = nullptr; }
+            if ((rc = dalloc((void **)&d->slab_map, bytes, "slab member map"))) return rc;
+            CG_HIP(hipMemcpy(d->slab_map, mstart.data(), mstart.size() * sizeof(int), hipMemcpyHostToDevice));
+            CG_HIP(hipMemcpy(d->slab_map + mstart.size(), gmember.data(), gmember.size() * sizeof(int), hipMemcpyHostToDevice));
+            sp.mstart = d->slab_map; sp.gmember = d->slab_map + mstart.size(); sp.G = members;
+            if (slab_sync_bytes(members) > sp.sync_bytes) {
+                if (d->slab_sync) { (void)hipFree(d->slab_sync); d->slab_sync = nullptr; }
+                sp.sync_bytes = slab_sync_bytes(members);
+                if ((rc = dalloc(&d->slab_sync, sp.sync_bytes, "slab sync words"))) return rc;
+            }
+            break;
+        }
+    }
+    d->slab = sp;
     return CGAMD_OK;
 }
 

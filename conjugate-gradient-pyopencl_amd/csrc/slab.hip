@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -44,7 +45,9 @@ constexpr int kSlabStep = kResThreads;      // rows per step: one per thread
 constexpr int kSlabRpt = 12;                // steps at most: 6144 rows per member
 
 template <typename T> struct SlabArgs {
-    int n, G, rows_m, nsteps, it0, K, history_cap;
+    int n, G, rows_m, nsteps, it0, K, history_cap;     // rows_m / nsteps: of the LARGEST member (LDS layout); uniform members when mstart is null
+    const int *mstart;              // [G + 1] first row of every member (multiples of 1024), or null = m rows_m
+    const int *gmember;             // [ceil(n / 1024)] member that owns a 1024-row granule (with mstart)
     int vcap;                       // LDS entries of one value slice (multiple of 4)
     int ccap;                       // LDS bytes of the member's column codes
     long long nnz;
@@ -269,7 +272,10 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     u64 *xs_rr = a.xres + (size_t)(__builtin_amdgcn_readfirstlane(sh.ctl[0]) & 7) * 16, *xs_dq = xs_rr + 8;
 
     // ---- my rows: the codes of all of them into LDS, slice bounds per step, the members that own a far column of mine
-    const int R0 = m * a.rows_m, R1 = min(R0 + a.rows_m, a.n);
+    // members of unequal size (slab_partition): the ones that push to / wait for a peer rank own fewer rows, so that their SpMV ends
+    // with the others' although it starts a push later
+    const int R0 = a.mstart ? a.mstart[m] : m * a.rows_m, R1 = min(a.mstart ? a.mstart[m + 1] : R0 + a.rows_m, a.n);
+    const int nsteps = a.mstart ? (a.mstart[m + 1] - a.mstart[m]) / kSlabStep : a.nsteps;      // even (members start at multiples of 1024)
     const int c0 = a.ptr[R0] & ~3, cend = a.ptr[R1];            // my entries are [c0, cend)
     for (int o = 4 * t; o < cend - c0; o += 4 * kResThreads)
         *reinterpret_cast<unsigned *>(scode + o) = *reinterpret_cast<const unsigned *>(a.codes + c0 + o);
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     for (int h = 0; h < RPT; ++h) {
         const int row = R0 + h * kSlabStep + t;
         unsigned info = 0;
-        if (h < a.nsteps && row < R1) {
+        if (h < nsteps && row < R1) {
             const int ps = a.ptr[row], pe = a.ptr[row + 1];
             info = ((unsigned)(ps - c0) << 5) | (unsigned)(pe - ps);
             for (int j = ps; j < pe; ++j) {
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
                     if (c >= a.n) {
                         has_halo = 1;                        // a column another RANK owns: it arrives in the tail of ds0 / ds1
                     } else {
-                        const int owner = c / a.rows_m;
+                        const int owner = a.gmember ? a.gmember[c >> 10] : c / a.rows_m;
                         atomicOr(&depmask[owner >> 5], 1u << (owner & 31));
                     }
                 }
@@ -347,11 +353,11 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
 #pragma unroll
     for (int h = 0; h < RPT; ++h) {
         const int row = R0 + h * kSlabStep + t;
-        const bool lv = h < a.nsteps && row < R1;
+        const bool lv = h < nsteps && row < R1;
         px[h] = lv ? a.x[row] : vzero<T>();
         pr[h] = lv ? a.r[row] : vzero<T>();
         pq[h] = vzero<T>();
-        if (h < a.nsteps) dl[h * kSlabStep + t] = lv ? a.din[row] : vzero<T>();
+        if (h < nsteps) dl[h * kSlabStep + t] = lv ? a.din[row] : vzero<T>();
     }
     u64 *g_dq = a.gran, *g_rr = a.gran + (size_t)a.G * W;
     T dlt = a.delta[0];
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     slab_stage_load<T>(rv, sbound[0], sbound[1], slB);
     slab_stage_store<T>(slB, sval);
     slab_stage_load<T>(rv, sbound[2], sbound[3], slA);                                     // step 1
-    slab_stage_load<T>(rv, sbound[2 * (2 % a.nsteps)], sbound[2 * (2 % a.nsteps) + 1], slB);   // step 2
+    slab_stage_load<T>(rv, sbound[2 * (2 % nsteps)], sbound[2 * (2 % nsteps) + 1], slB);   // step 2
     __syncthreads();
 
     long long stamp = clock64();
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
 #pragma unroll
         for (int h = 0; h < RPT; ++h) {
             const int li = h * kSlabStep + t;
-            if (h < a.nsteps && R0 + li < R1) {
+            if (h < nsteps && R0 + li < R1) {
                 const T dn = k > 0 ? vaypx(bt, dl[li], pr[h]) : dl[li];
                 dl[li] = dn;
                 st_coh(dpub + (R0 + li), dn);
@@ -475,9 +481,9 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
             }
             const int s = (int)(info >> 5), e = s + (int)(info & 31u);
             const int s2 = (int)(info2 >> 5), e2 = s2 + (int)(info2 & 31u);
-            slab_far_issue<T, UNROLL>(scode, sdict, s2, e2, R0 + (h + 1) * kSlabStep + t, R0, R1 - R0, rd, h + 1 < a.nsteps, fnext);
+            slab_far_issue<T, UNROLL>(scode, sdict, s2, e2, R0 + (h + 1) * kSlabStep + t, R0, R1 - R0, rd, h + 1 < nsteps, fnext);
             slab_stage_store<T>(sl, sval + (size_t)(bcur ^ 1) * a.vcap);
-            const int j3 = (h + 3) % a.nsteps;           // (past the last iteration: a redundant load, never stored)
+            const int j3 = (h + 3) % nsteps;           // (past the last iteration: a redundant load, never stored)
             slab_stage_load<T>(rv, sbound[2 * j3], sbound[2 * j3 + 1], sl);
             const T qv = slab_row<T, UNROLL>(sval + (size_t)bcur * a.vcap + (e > s ? (c0 + s) - sbound[2 * h] : 0), scode, sdict, s, e,
                                              R0 + h * kSlabStep + t, R0, R1 - R0, dl, fcur);
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
             __syncthreads();                         // slice h is done with; slice h + 1 is complete in the other buffer
         };
 #pragma unroll 1
-        for (int h = 0; h < a.nsteps; h += 2) {
+        for (int h = 0; h < nsteps; h += 2) {
             one_step(h, 0, slA, fA, fB);
             one_step(h + 1, 1, slB, fB, fA);
         }
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
         A dot = vzero<A>();
 #pragma unroll
         for (int h = 0; h < RPT; ++h)
-            if (h < a.nsteps) dot = vadd(dot, to_acc(vmul(dl[h * kSlabStep + t], pq[h])));
+            if (h < nsteps) dot = vadd(dot, to_acc(vmul(dl[h * kSlabStep + t], pq[h])));
         A tot = wg_sum(dot, sh);
         if (t == 0) put_granule<false>(g_dq + (size_t)m * W, 2u * k + 1, tot);
         SLAB_STAMP(5)
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
         A acc = vzero<A>();
 #pragma unroll
         for (int h = 0; h < RPT; ++h)
-            if (h < a.nsteps) {
+            if (h < nsteps) {
                 px[h] = vadd(px[h], vmul(al, dl[h * kSlabStep + t]));
                 pr[h] = vsub(pr[h], vmul(al, pq[h]));
                 acc = vadd(acc, to_acc(vmul(pr[h], pr[h])));
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
 #pragma unroll
         for (int h = 0; h < RPT; ++h) {
             const int row = R0 + h * kSlabStep + t;
-            if (h < a.nsteps && row < R1) {
+            if (h < nsteps && row < R1) {
                 a.x[row] = px[h];
                 a.r[row] = pr[h];
                 a.din[row] = vaypx(bt, dl[h * kSlabStep + t], pr[h]);
@@ -587,9 +593,42 @@ bool slab_plan(int dtype, int n, int n_cus, const SpmvPlan &plan, bool coded, Sl
     out->ok = true; out->rows_m = (int)rows_m; out->G = G; out->cap = (int)vcap; out->ccap = (int)ccap; out->lds_bytes = (lds + 15) & ~(size_t)15;
     out->nsteps = (int)(rows_m / kSlabStep);
     out->unroll = plan.max_row <= 5 ? 5 : plan.max_row <= 7 ? 7 : 8;
-    constexpr int W4 = 4;       // granule words per partial (complex: 4, real: 2): sized for the larger
-    out->sync_bytes = (size_t)kHdrWords * 4 + (size_t)2 * G * W4 * 8 + 16 * 16 * 8 + 8 * 4 + 16 + (size_t)G * 8 + 2 * 64 * 4 + 256;
+    out->sync_bytes = slab_sync_bytes(G);
     return true;
+}
+size_t slab_sync_bytes(int G) {
+    constexpr int W4 = 4;       // granule words per partial (complex: 4, real: 2): sized for the larger
+    return (size_t)kHdrWords * 4 + (size_t)2 * G * W4 * 8 + 16 * 16 * 8 + 8 * 4 + 16 + (size_t)G * 8 + 2 * 64 * 4 + 256;
+}
+
+// Members of unequal size for a rank with peers.  boundary[g] != 0: the 1024-row granule g holds a row that is pushed to a peer (for
+// the symmetric patterns of CG also the rows that read the peer's entries).  Such members publish, push ~rows x 8 bytes with
+// system-scope stores and wait for the peer's flag before their SpMV can start (~6 us on the 1/8 slab of the headline system, where
+// they were the critical path of every iteration): they get `trim` granules fewer than the others.  Fills mstart [G + 1] / gmember
+// [granules]; returns the number of members, 0 when more than max_members would be needed.
+int slab_partition(const SlabPlan &sp, int n, const std::vector<char> &boundary, int trim, int max_members, std::vector<int> *mstart,
+                   std::vector<int> *gmember) {
+    const int granules = (n + 1023) / 1024, cap_i = sp.rows_m / 1024, cap_b = std::max(1, cap_i - trim);
+    mstart->clear();
+    gmember->assign((size_t)granules, 0);
+    int g = 0, members = 0;
+    while (g < granules) {
+        int take = std::min(cap_i, granules - g);
+        bool touches = false;
+        for (int k = 0; k < take; ++k) touches = touches || boundary[(size_t)(g + k)] != 0;
+        if (touches) {
+            // up to cap_b granules; a member that starts in the interior stops short of the boundary instead of swallowing it
+            int first_b = 0;
+            while (!boundary[(size_t)(g + first_b)]) ++first_b;
+            take = first_b > 0 ? first_b : std::min(cap_b, granules - g);
+        }
+        mstart->push_back(g * 1024);
+        for (int k = 0; k < take; ++k) (*gmember)[(size_t)(g + k)] = members;
+        g += take;
+        if (++members > max_members) return 0;
+    }
+    mstart->push_back(granules * 1024);
+    return members;
 }
 
 static long long *g_slab_prof = nullptr;     // diagnostics only (CGAMD_RESIDENT_PROF=<member>; single device, single thread)
@@ -600,6 +639,7 @@ static int slab_impl(const SlabPlan &sp, int n, long long nnz, const void *vals,
     using A = typename VT<T>::acc;
     SlabArgs<T> a;
     a.n = n; a.G = sp.G; a.rows_m = sp.rows_m; a.nsteps = sp.nsteps; a.it0 = it0; a.K = K; a.history_cap = sc.history_cap;
+    a.mstart = sp.mstart; a.gmember = sp.gmember;
     a.vcap = sp.cap; a.ccap = sp.ccap;
     a.nnz = nnz;
     a.claim_ticks = (long long)std::max(1, tune().resident_claim_ms) * 100000;

@@ -33,6 +33,9 @@ def main():
     dmod = importlib.import_module("conjugate-gradient-pyopencl_amd.dist")
     L = pkg._lib
     lib = L.load()
+    for kv in filter(None, os.environ.get("CG_TUNE", "").split(",")):      # CG_TUNE=key=value,... like bench.py and the tests
+        k, v = kv.split("=")
+        L.check(lib.cgamd_tune(k.encode(), int(v)))
     nx, ny, nz = (int(v) for v in args.grid.split("x"))
     n, h = nx * ny * nz, nx * ny
     ctx = pkg.Context(0)
