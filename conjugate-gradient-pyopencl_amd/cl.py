@@ -325,6 +325,11 @@ class Solver:
         """distinct (column - row) offsets when the SpMV reads one-byte column codes instead of aCols, else 0"""
         return self._lib.cgamd_solver_index_codes(self.handle)
 
+    @property
+    def value_codes(self):
+        """distinct matrix entries behind the one-byte value codes of the SpMV (0 = the kernel reads aValues)"""
+        return self._lib.cgamd_solver_value_codes(self.handle)
+
     def iter_bytes(self, fused=False):
         return self._lib.cgamd_solver_iter_bytes(self.handle, int(fused))
 

@@ -41,6 +41,7 @@ int cgamd_tune(const char *key, int value) {
     // public keys (include/cgamd.h)
     if (k == "index_codes") g_tune.index_codes = value;
     else if (k == "index_codes16") g_tune.index_codes16 = value;
+    else if (k == "value_codes") g_tune.value_codes = value;
     else if (k == "index_codes_min_mb") g_tune.index_codes_min_mb = value;
     else if (k == "resident") g_tune.resident = value;
     else if (k == "resident_min") g_tune.resident_min = value;

@@ -51,6 +51,10 @@ struct SpmvPlan {
     const int *dict = nullptr;              // [256] distinct (column - row) offsets of the matrix
     const int *codes_for = nullptr;         // the aCols array the codes were made from
     bool codes16 = false;                   // the codes are 16-bit columns relative to the row block's first column (build_index_codes16)
+    // one-byte VALUE codes (build_value_codes; with the one-byte column codes only): aValues[j] == vdict[vcodes[j]]
+    const unsigned char *vcodes = nullptr;  // [nnz + pad]
+    const void *vdict = nullptr;            // [256] values
+    const void *vcodes_for = nullptr;       // the aValues array the codes were made from
 };
 SpmvPlan make_spmv_plan(int n);
 // fills plan->max_span / chunk_span from the matrix structure; synchronises `st`; scratch_dev: >= 32 bytes
@@ -68,6 +72,7 @@ int build_index_codes(int n, long long nnz, const int *ptr_dev, const int *cols_
                       int **dict_out, int *distinct_out);
 // 16-bit columns relative to the first column of every 256-row block, for matrices with more offsets than the dictionary holds
 // whose row blocks span fewer than 65 536 columns: *codes_out 2 nnz + 64 bytes, *base_out one int per row block; null when not codable
+int build_value_codes(int dtype, long long nnz, const void *vals_dev, hipStream_t st, unsigned char **vcodes_out, void **vdict_out, int *n_values);
 int build_index_codes16(int n, long long nnz, const int *ptr_dev, const int *cols_dev, hipStream_t st, unsigned char **codes_out, int **base_out);
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols);
 constexpr int kChunkBytes = 32 * 1024;      // kind 7: preferred LDS chunk slice (4-5 work-groups per CU)
@@ -83,6 +88,7 @@ struct Tuning {
     // ---- public
     int index_codes = 1;    // single-RHS row-block SpMV on one-byte column codes (0 = always aCols)
     int index_codes16 = 1;  // ... and, where the matrix has more than 256 offsets, on 16-bit block-relative columns (0 = aCols then)
+    int value_codes = 1;    // ... and, where the matrix has at most 256 distinct values, one-byte value codes on top of the one-byte column codes
     int index_codes_min_mb = 32;    // ... for matrices above this size (smaller systems run the resident / two-launch loops, which read aCols)
     int resident = 1;       // systems of at most 32768 rows whose matrix slices fit LDS: all iterations of an iterate() call in ONE launch
                             // (resident.hip); 0 = never, 2 = always in the cross-XCD form (up to 65536 rows; for the any-placement tests)

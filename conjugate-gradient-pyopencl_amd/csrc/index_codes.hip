@@ -182,4 +182,139 @@ int build_index_codes16(int n, long long nnz, const int *ptr_dev, const int *col
     return CGAMD_OK;
 }
 
+// -------------------------------------------------------------------------------------------------
+// VALUE codes: matrices with at most 256 distinct entries (constant-coefficient stencils, graph Laplacians, lattice operators: the
+// headline system has 2) keep `vcodes[nnz]` (one byte each) and `vdict[256]` with aValues[j] == vdict[vcodes[j]] -- the same bits, so
+// every product, sum and history is bit-identical to the kernels that read aValues.  With the column codes the SpMV then streams 2
+// bytes per non-zero instead of sizeof(T) + 1 (fp64: 9).  Built with an open-addressing table of the value bits (4096 slots): a pass
+// that inserts (it stops as soon as a 257th value shows up), a one-work-group pass that numbers the occupied slots, a pass that
+// encodes.  Which code a value gets may differ from run to run (insertion races); the value it stands for does not.
+// -------------------------------------------------------------------------------------------------
+constexpr int kVSlots = 4096;
+constexpr unsigned long long kVEmpty = ~0ULL;      // (a NaN pattern: a matrix that holds it is not coded)
+template <typename T> CG_DEV unsigned long long value_key(const T &v) {
+    if constexpr (sizeof(T) == 4) { unsigned b; __builtin_memcpy(&b, &v, 4); return b; }
+    else { unsigned long long b; __builtin_memcpy(&b, &v, 8); return b; }
+}
+CG_DEV unsigned vhash(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 29;
+    return (unsigned)k & (kVSlots - 1);
+}
+// state: [0] number of distinct values, [1] failure flag
+template <typename T>
+__global__ __launch_bounds__(256) void value_insert_kernel(long long nnz, const T *__restrict__ vals, unsigned long long *table, int *state) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < nnz; j += stride) {
+        if (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const unsigned long long key = value_key(vals[j]);
+        if (key == kVEmpty) { atomicExch(state + 1, 1); return; }
+        unsigned s = vhash(key);
+        for (int probe = 0; probe < kVSlots; ++probe, s = (s + 1) & (kVSlots - 1)) {
+            unsigned long long cur = __hip_atomic_load(table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == key) break;
+            if (cur == kVEmpty) {
+                cur = atomicCAS(table + s, kVEmpty, key);
+                if (cur == kVEmpty) {                       // a new value
+                    if (atomicAdd(state, 1) >= 256) atomicExch(state + 1, 1);
+                    break;
+                }
+                if (cur == key) break;
+            }
+        }
+    }
+}
+// one work-group: occupied slot -> code (slot order), dictionary entries
+template <typename T>
+__global__ __launch_bounds__(1024) void value_number_kernel(const unsigned long long *table, unsigned short *slot_code, T *vdict) {
+    __shared__ int wsum[16];
+    const int t = threadIdx.x;
+    int mine = 0;
+    for (int k = 0; k < kVSlots / 1024; ++k) mine += table[t * (kVSlots / 1024) + k] != kVEmpty;
+    int incl = mine;                                        // inclusive scan over the wave, then over the waves
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if ((t & 63) >= off) incl += o; }
+    if ((t & 63) == 63) wsum[t >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += wsum[w];
+    int code = base + incl - mine;
+    for (int k = 0; k < kVSlots / 1024; ++k) {
+        const int s = t * (kVSlots / 1024) + k;
+        const unsigned long long key = table[s];
+        if (key != kVEmpty) {
+            slot_code[s] = (unsigned short)code;
+            if (code < 256) {
+                T v;
+                if constexpr (sizeof(T) == 4) { const unsigned b = (unsigned)key; __builtin_memcpy(&v, &b, 4); }
+                else __builtin_memcpy(&v, &key, 8);
+                vdict[code] = v;
+            }
+            ++code;
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void value_encode_kernel(long long nnz, const T *__restrict__ vals, const unsigned long long *__restrict__ table,
+                                                           const unsigned short *__restrict__ slot_code, unsigned char *__restrict__ vcodes) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < nnz; j += stride) {
+        const unsigned long long key = value_key(vals[j]);
+        unsigned s = vhash(key);
+        while (table[s] != key) s = (s + 1) & (kVSlots - 1);     // present: the insert pass put it there
+        vcodes[j] = (unsigned char)slot_code[s];
+    }
+}
+
+template <typename T>
+static int build_value_codes_impl(long long nnz, const void *vals_dev, hipStream_t st, unsigned char **vcodes_out, void **vdict_out, int *n_values) {
+    // scratch: table | slot codes | state
+    char *scratch = nullptr;
+    const size_t tb = sizeof(unsigned long long) * kVSlots, sb = sizeof(unsigned short) * kVSlots;
+    CG_HIP(hipMalloc((void **)&scratch, tb + sb + 16));
+    auto *table = reinterpret_cast<unsigned long long *>(scratch);
+    auto *slot_code = reinterpret_cast<unsigned short *>(scratch + tb);
+    int *state = reinterpret_cast<int *>(scratch + tb + sb);
+    int h[2] = {0, 1};
+    hipError_t e = hipMemsetAsync(table, 0xff, tb, st);
+    if (e == hipSuccess) e = hipMemsetAsync(state, 0, 8, st);
+    const int grid = (int)std::min<long long>((nnz + 255) / 256, 4096);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((value_insert_kernel<T>), dim3(grid), dim3(256), 0, st, nnz, static_cast<const T *>(vals_dev), table, state);
+        e = hipMemcpyAsync(h, state, 8, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess || h[1] != 0 || h[0] < 1 || h[0] > 256) {
+        (void)hipFree(scratch);
+        return e == hipSuccess ? CGAMD_OK : fail(CGAMD_ERR_HIP, std::string("build_value_codes: ") + hipGetErrorString(e));
+    }
+    unsigned char *vcodes = nullptr;
+    void *vdict = nullptr;
+    e = hipMalloc((void **)&vcodes, (size_t)nnz + 64);
+    if (e == hipSuccess) e = hipMalloc(&vdict, 256 * sizeof(T));
+    if (e == hipSuccess) e = hipMemsetAsync(vcodes + (size_t)nnz, 0, 64, st);
+    if (e == hipSuccess) e = hipMemsetAsync(vdict, 0, 256 * sizeof(T), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((value_number_kernel<T>), dim3(1), dim3(1024), 0, st, table, slot_code, static_cast<T *>(vdict));
+        hipLaunchKernelGGL((value_encode_kernel<T>), dim3(grid), dim3(256), 0, st, nnz, static_cast<const T *>(vals_dev), table, slot_code, vcodes);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(scratch);
+    if (e != hipSuccess) {
+        if (vcodes) (void)hipFree(vcodes);
+        if (vdict) (void)hipFree(vdict);
+        return fail(CGAMD_ERR_HIP, std::string("build_value_codes: ") + hipGetErrorString(e));
+    }
+    *vcodes_out = vcodes; *vdict_out = vdict; *n_values = h[0];
+    return CGAMD_OK;
+}
+// *vcodes_out (nnz + 64 bytes) and *vdict_out (256 values) are device allocations the caller frees; both null when the matrix has more
+// than 256 distinct values (or is complex128).  Synchronises `st`.
+int build_value_codes(int dtype, long long nnz, const void *vals_dev, hipStream_t st, unsigned char **vcodes_out, void **vdict_out, int *n_values) {
+    *vcodes_out = nullptr; *vdict_out = nullptr; *n_values = 0;
+    if (nnz <= 0 || dtype == CGAMD_C128) return CGAMD_OK;
+    if (dtype == CGAMD_F32) return build_value_codes_impl<float>(nnz, vals_dev, st, vcodes_out, vdict_out, n_values);
+    if (dtype == CGAMD_F64) return build_value_codes_impl<double>(nnz, vals_dev, st, vcodes_out, vdict_out, n_values);
+    return build_value_codes_impl<float2>(nnz, vals_dev, st, vcodes_out, vdict_out, n_values);
+}
+
 }  // namespace cgamd

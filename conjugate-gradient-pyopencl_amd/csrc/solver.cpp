@@ -71,6 +71,9 @@ struct cgamd_solver {
     unsigned char *codes = nullptr;   // one-byte column codes of the single-RHS SpMV (build_index_codes), with their dictionary
     int *dict = nullptr;
     int n_offsets = 0;                // distinct (column - row) offsets behind the codes; 0 = the SpMV reads aCols
+    unsigned char *vcodes = nullptr;  // one-byte value codes on top of the one-byte column codes (build_value_codes), with their dictionary
+    void *vdict = nullptr;
+    int n_values = 0;                 // distinct matrix entries behind the value codes; 0 = the SpMV reads aValues
     // cgamd_solver_iterate_tol: tolerance of the device-side stop for the call in progress (0 = none), and what it reported
     double tol_req = 0.;
     bool tol_served = false, tol_stopped = false;
@@ -219,6 +222,10 @@ static int setup_index_codes(cgamd_solver *s) {
     if (s->dict) { (void)hipFree(s->dict); s->dict = nullptr; }
     s->plan.codes = nullptr; s->plan.dict = nullptr; s->plan.codes_for = nullptr; s->plan.codes16 = false;
     s->n_offsets = 0;
+    if (s->vcodes) { (void)hipFree(s->vcodes); s->vcodes = nullptr; }
+    if (s->vdict) { (void)hipFree(s->vdict); s->vdict = nullptr; }
+    s->plan.vcodes = nullptr; s->plan.vdict = nullptr; s->plan.vcodes_for = nullptr;
+    s->n_values = 0;
     const size_t matrix_bytes = (size_t)s->nnz * (dtype_size(s->dtype) + 4);
     // a handle whose iterations run in the chip-wide resident loop (matrix in registers) would pay the two coding passes at every
     // create / reload (the stateless cg() reloads per call) for the few launched SpMVs around it
@@ -227,7 +234,15 @@ static int setup_index_codes(cgamd_solver *s) {
         matrix_bytes <= ((size_t)s->tune.index_codes_min_mb << 20))
         return CGAMD_OK;
     if (int rc = build_index_codes(s->n, s->nnz, s->ptr, s->cols, s->ctx->stream, &s->codes, &s->dict, &s->n_offsets)) return rc;
-    if (s->codes) { s->plan.codes = s->codes; s->plan.dict = s->dict; s->plan.codes_for = s->cols; s->plan.codes16 = false; return CGAMD_OK; }
+    if (s->codes) {
+        s->plan.codes = s->codes; s->plan.dict = s->dict; s->plan.codes_for = s->cols; s->plan.codes16 = false;
+        // matrices of at most 256 distinct entries (constant-coefficient stencils): one-byte value codes as well, 2 bytes per non-zero
+        if (s->tune.value_codes && s->plan.kind == 5) {
+            if (int rc = build_value_codes(s->dtype, s->nnz, s->vals, s->ctx->stream, &s->vcodes, &s->vdict, &s->n_values)) return rc;
+            if (s->vcodes) { s->plan.vcodes = s->vcodes; s->plan.vdict = s->vdict; s->plan.vcodes_for = s->vals; }
+        }
+        return CGAMD_OK;
+    }
     // more than 256 distinct offsets (unstructured patterns, Matrix-Market inputs): 16-bit columns relative to the row block's first
     if (s->tune.index_codes16 == 0) return CGAMD_OK;
     if (int rc = build_index_codes16(s->n, s->nnz, s->ptr, s->cols, s->ctx->stream, &s->codes, &s->dict)) return rc;
@@ -486,7 +501,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
         if (s->cols) (void)hipFree(s->cols);
     }
     void *bufs[] = {s->slab, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
-                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync, s->resw_sync, s->codes, s->dict, s->rm_pace};
+                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync, s->resw_sync, s->codes, s->dict, s->rm_pace, s->vcodes, s->vdict};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;
@@ -865,13 +880,16 @@ static long long index_bytes_per_nnz(const cgamd_solver *s) { return s->plan.cod
 long long cgamd_solver_spmv_moved_bytes(cgamd_solver *s) {
     if (!s) return 0;
     const long long V = (long long)dtype_size(s->dtype);
-    return s->nnz * (V + index_bytes_per_nnz(s)) + ((long long)s->n_user + 1) * 4 + 2LL * s->n_user * V * s->nrhs;
+    const long long value_bytes = s->plan.vcodes ? 1 : V;      // value codes: one byte per entry instead of the value
+    return s->nnz * (value_bytes + index_bytes_per_nnz(s)) + ((long long)s->n_user + 1) * 4 + 2LL * s->n_user * V * s->nrhs;
 }
+int cgamd_solver_value_codes(cgamd_solver *s) { return s ? s->n_values : -CGAMD_ERR_INVALID; }
 long long cgamd_solver_iter_moved_bytes(cgamd_solver *s) {
     if (!s) return 0;
     const long long V = (long long)dtype_size(s->dtype);
     const long long passes = (s->flags & CGAMD_UNFUSED) ? 14 : s->mdiag ? 12 : 10;
-    return s->nnz * (V + index_bytes_per_nnz(s)) + ((long long)s->n_user + 1) * 4 + passes * s->n_user * V * s->nrhs;
+    const long long value_bytes = s->plan.vcodes ? 1 : V;
+    return s->nnz * (value_bytes + index_bytes_per_nnz(s)) + ((long long)s->n_user + 1) * 4 + passes * s->n_user * V * s->nrhs;
 }
 
 }  // extern "C"

@@ -234,6 +234,183 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_kernel(SpmvArgs<T> a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// The FULLY CODED form of the row-block kernel: one-byte column codes AND one-byte value codes (matrices with at most 256 distinct
+// entries, build_value_codes) -- 2 bytes per non-zero from HBM instead of sizeof(T) + 1.  The value dictionary sits in LDS beside
+// the offset dictionary; a slot is code byte -> ds_read of the value, code byte -> ds_read of the offset.  Same row walk, same
+// order of fused multiply-adds on the same bits as every other form of the kernel: bit-identical results.
+// -------------------------------------------------------------------------------------------------
+// With 2 bytes per non-zero a 256-row block is ~4 KB of matrix: a work-group that owned ONE block would live for a single chain
+// of round trips (row pointers -> codes -> gathers) and the kernel is bound by the latency of the gathers.  So a work-group walks
+// kVcBlocks consecutive row blocks, TWO at a time: every thread walks one row of each block of the pair (twice the gathers in flight
+// per thread: 92.9 -> see DESIGN.md), and the next pair's code dwords travel (registers) while the current pair is multiplied out of
+// LDS (two LDS buffers; the row pointers of the pair after that are loaded a step earlier still).  One d.q partial per 256-row
+// block, formed exactly as block_sum<256> forms it, as everywhere.
+constexpr int kVcBlocks = 4;      // row blocks per work-group
+constexpr int kVcRows = 1;        // of which a thread walks this many at a time (one row of each): 2 were measured slower (108 VGPRs)
+template <typename T> CG_DEV T buf_gather(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    if constexpr (sizeof(T) == 4) {
+        const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0);
+        T v; __builtin_memcpy(&v, &w, 4); return v;
+    } else {
+        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0);
+        T v; __builtin_memcpy(&v, &w, 8); return v;
+    }
+}
+template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void spmv_rowblock_vc_kernel(SpmvArgs<T> a) {
+    using A = typename VT<T>::acc;
+    constexpr int PR = kVcRows;          // rows per thread = row blocks walked at a time
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    // [2 buffers][PR blocks][column codes cap | value codes cap]
+    __shared__ A red[PR][BLOCK / kWave];
+    __shared__ int sdict[BLOCK];
+    __shared__ T sdictv[BLOCK];
+    static_assert(BLOCK == 256 && kVcBlocks % PR == 0, "one dictionary entry per thread; whole groups of row blocks");
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    sdict[t] = a.dict[t] * (int)sizeof(T);     // byte offsets into x; visible after the first staging barrier
+    sdictv[t] = a.vdict[t];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(a.x), 0, (int)((unsigned)a.n * (unsigned)sizeof(T)), 0x00020000);
+    const int supers = (a.row_blocks + kVcBlocks - 1) / kVcBlocks;
+    const int srb = rowblock_of(blockIdx.x, supers, a.cycle);
+    if (srb < 0) return;
+    const int rb0 = srb * kVcBlocks, nb = min(kVcBlocks, a.row_blocks - rb0);
+
+    struct Bounds { int s_raw, e_raw, p0, p1; };
+    auto bounds_of = [&](int rb) -> Bounds {          // branch-free: clamped rows (a block past the matrix: empty)
+        const int r0 = min(rb, a.row_blocks) * BLOCK, rclamp = min(r0 + t, a.n - 1);
+        Bounds b;
+        b.s_raw = a.ptr[rclamp]; b.e_raw = a.ptr[rclamp + 1];
+        b.p0 = a.ptr[min(r0, a.n)]; b.p1 = a.ptr[min(r0 + BLOCK, a.n)];
+        return b;
+    };
+    // the code dwords of a block: two rounds of 4 BLOCK entries cover the 8 BLOCK entries a slice may have (the host checked cap)
+    struct Codes { unsigned cw[2], vw[2]; };
+    auto load_codes = [&](const Bounds &b) -> Codes {
+        Codes c;
+        const int cfirst = b.p0 & ~3;
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            const long long q = (long long)cfirst + rg * 4 * BLOCK + 4 * t;
+            const long long qq = q < b.p1 ? q : cfirst;         // (a valid address either way: unconditional loads)
+            const unsigned *cp = reinterpret_cast<const unsigned *>(a.codes + qq), *vp = reinterpret_cast<const unsigned *>(a.vcodes + qq);
+            c.cw[rg] = NT ? __builtin_nontemporal_load(cp) : *cp;
+            c.vw[rg] = NT ? __builtin_nontemporal_load(vp) : *vp;
+        }
+        return c;
+    };
+    Bounds bc[PR], bn[PR];
+    Codes cc[PR];
+#pragma unroll
+    for (int h = 0; h < PR; ++h) { bc[h] = bounds_of(rb0 + h); bn[h] = bounds_of(rb0 + PR + h); }
+#pragma unroll
+    for (int h = 0; h < PR; ++h) cc[h] = load_codes(bc[h]);
+    for (int i = 0; i < nb; i += PR) {
+        unsigned char *buf = reinterpret_cast<unsigned char *>(dyn_smem) + (size_t)((i / PR) & 1) * 2 * PR * a.cap;
+        int cfirst[PR];
+#pragma unroll
+        for (int h = 0; h < PR; ++h) {
+            cfirst[h] = bc[h].p0 & ~3;
+            unsigned char *scc = buf + (size_t)h * 2 * a.cap, *svc = scc + a.cap;
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+                const int o = rg * 4 * BLOCK + 4 * t;
+                if (cfirst[h] + o < bc[h].p1) {
+                    *reinterpret_cast<unsigned *>(scc + o) = cc[h].cw[rg];
+                    *reinterpret_cast<unsigned *>(svc + o) = cc[h].vw[rg];
+                }
+            }
+        }
+        __syncthreads();
+        // the next pair's codes and the row pointers of the pair after it: in flight behind this pair's gathers
+        Bounds bcur[PR];
+#pragma unroll
+        for (int h = 0; h < PR; ++h) bcur[h] = bc[h];
+        if (i + PR < nb) {
+#pragma unroll
+            for (int h = 0; h < PR; ++h) { cc[h] = load_codes(bn[h]); bc[h] = bn[h]; bn[h] = bounds_of(rb0 + i + 2 * PR + h); }
+        }
+        int row[PR], s[PR], e[PR];
+        T dv[PR];
+#pragma unroll
+        for (int h = 0; h < PR; ++h) {
+            row[h] = (rb0 + i + h) * BLOCK + t;
+            const bool live = row[h] < a.n && i + h < nb;
+            s[h] = bcur[h].s_raw - cfirst[h];
+            e[h] = live ? bcur[h].e_raw - cfirst[h] : s[h];
+            if (FUSE_DOT) dv[h] = a.dvec[min(row[h], a.n - 1)];      // early: it need not wait for the gathers
+        }
+        // Row walk with as few instructions as the form allows (the kernel is bound by instruction issue at 7 waves per SIMD, not by
+        // bytes): code bytes at immediate LDS offsets from the row's first entry (unclamped: slots past the row's end read the next
+        // row's codes -- valid LDS -- and are masked), byte offsets of x from a pre-multiplied dictionary, gathers as buffer loads
+        // (base in scalar registers + 32-bit offset: no 64-bit address arithmetic); a masked slot gathers x[row] and its term is
+        // dropped by the same select as in every other form of the kernel.
+        T sum[PR];
+        int len[PR], kmax = 0;
+        unsigned row8[PR];
+#pragma unroll
+        for (int h = 0; h < PR; ++h) {
+            sum[h] = vzero<T>();
+            len[h] = e[h] - s[h];
+            kmax = max(kmax, len[h]);
+            row8[h] = (unsigned)min(row[h], a.n - 1) * (unsigned)sizeof(T);
+        }
+        for (int k = 0; k < kmax; k += UNROLL) {
+            T xv[PR][UNROLL], av[PR][UNROLL];
+            unsigned off[PR][UNROLL];
+#pragma unroll
+            for (int h = 0; h < PR; ++h) {
+                const unsigned char *pc = buf + (size_t)h * 2 * a.cap + s[h] + k, *pv = pc + a.cap;
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j) {
+                    off[h][j] = pc[j];
+                    av[h][j] = sdictv[pv[j]];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < PR; ++h)
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j) off[h][j] = k + j < len[h] ? row8[h] + (unsigned)sdict[off[h][j]] : row8[h];
+#pragma unroll
+            for (int h = 0; h < PR; ++h)
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j) xv[h][j] = buf_gather<T>(xrs, off[h][j]);
+#pragma unroll
+            for (int h = 0; h < PR; ++h)
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j) {
+                    const T nxt = vfma(av[h][j], xv[h][j], sum[h]);
+                    sum[h] = vsel(k + j < len[h], nxt, sum[h]);
+                }
+        }
+        A dot1[PR];
+#pragma unroll
+        for (int h = 0; h < PR; ++h) dot1[h] = vzero<A>();
+#pragma unroll
+        for (int h = 0; h < PR; ++h)
+            if (row[h] < a.n && i + h < nb) {
+                a.y[row[h]] = sum[h];
+                if (FUSE_DOT) dot1[h] = to_acc(vmul(dv[h], sum[h]));
+            }
+        if (FUSE_DOT) {                     // block_sum<256> of both blocks behind one pair of barriers (same tree, same order)
+#pragma unroll
+            for (int h = 0; h < PR; ++h) dot1[h] = wave_sum(dot1[h]);
+            __syncthreads();
+            if (lane == 0) {
+#pragma unroll
+                for (int h = 0; h < PR; ++h) red[h][wave] = dot1[h];
+            }
+            __syncthreads();
+            if (t < PR && i + t < nb) {
+                A v = red[t][0];
+#pragma unroll
+                for (int w = 1; w < BLOCK / kWave; ++w) v = vadd(v, red[t][w]);
+                a.partials[rb0 + i + t] = v;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // The same kernel for DENSER rows (a 256-row slice no longer fits LDS: > ~21 non-zeros per row in fp64).  The work-group
 // still owns 256 rows and writes one d.q partial, but stages and walks them in LPR chunks of 256/LPR rows, LPR = 2, 4 or
 // 8 lanes per row: lane l of a row takes entries s+l, s+l+LPR, ... (consecutive lanes -> consecutive entries -> for
@@ -615,7 +792,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
     a.partials = static_cast<typename VT<T>::acc *>(partials);
     a.row_blocks = plan.row_blocks;
     a.rb_list = rb_list; a.rb_count = rb_count;
-    a.codes = nullptr; a.dict = nullptr;
+    a.codes = nullptr; a.dict = nullptr; a.vcodes = nullptr; a.vdict = nullptr;
     const bool vec = aligned16(vals) && aligned16(cols);
     const bool fuse = partials != nullptr;
     const size_t dyn = (fuse && nrhs > 1) ? sizeof(typename VT<T>::acc) * nrhs * (kBlock / kWave) : 0;
@@ -632,6 +809,9 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         // one-byte column codes instead of aCols (build_index_codes; the codes belong to THIS cols array)
         const bool coded_any = nrhs == 1 && plan.codes && plan.codes_for == cols && tune().index_codes != 0;
         const bool coded = coded_any && !plan.codes16, coded16 = coded_any && plan.codes16;
+        // ... and one-byte value codes on top (matrices of at most 256 distinct entries; complex128 has none)
+        // (its staging covers slices of at most 8 x 256 entries: rows of 8 entries on average)
+        const bool vcoded = coded && !rb_list && plan.vcodes && plan.vcodes_for == vals && tune().value_codes != 0 && a.cap <= 8 * kBlock && (unsigned long long)n * sizeof(T) < (1ULL << 31);
         a.codes = coded_any ? plan.codes : nullptr;
         a.dict = coded_any ? plan.dict : nullptr;      // (16-bit form: the first column of every row block)
         const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15)
@@ -655,6 +835,26 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         // row and no idle slot (N = 10M 7-point fp64: SpMV 134.7 -> 131.2 us, CG 4 215 -> 4 292 it/s; same sums, same bits)
         const int fit = plan.max_row <= 0 ? 8 : plan.max_row <= 4 ? 4 : plan.max_row == 5 ? 5 : plan.max_row <= 7 ? 7 : 8;
         const int unroll = tune().spmv_unroll ? tune().spmv_unroll : (sizeof(T) > 8 ? 4 : fit);
+        if constexpr (sizeof(T) <= 8) {
+            if (vcoded) {
+                a.vcodes = plan.vcodes; a.vdict = static_cast<const T *>(plan.vdict);
+                const size_t lds2 = (((size_t)a.cap * 4 * kVcRows + 15) & ~(size_t)15) + 16;      // two buffers x kVcRows blocks x two code streams (+ the unclamped reads' slack)
+                const int supers = (plan.row_blocks + kVcBlocks - 1) / kVcBlocks, cyc = std::max(1, a.cycle / kVcBlocks);
+                a.cycle = cyc;
+                const dim3 gvc(rowblock_grid(supers, cyc));
+#define CG_VC(NT, UNR)                                                                                                  \
+    do {                                                                                                                \
+        if (fuse) CG_LAUNCH_EV((spmv_rowblock_vc_kernel<T, kBlock, NT, true, UNR>), gvc, block, lds2, st, a);            \
+        else CG_LAUNCH_EV((spmv_rowblock_vc_kernel<T, kBlock, NT, false, UNR>), gvc, block, lds2, st, a);                \
+    } while (0)
+                if (unroll == 4) { if (nt) CG_VC(true, 4); else CG_VC(false, 4); }
+                else if (unroll == 5) { if (nt) CG_VC(true, 5); else CG_VC(false, 5); }
+                else if (unroll == 7) { if (nt) CG_VC(true, 7); else CG_VC(false, 7); }
+                else { if (nt) CG_VC(true, 8); else CG_VC(false, 8); }
+#undef CG_VC
+                return check_launch("spmv_rowblock_vc");
+            }
+        }
         if (unroll == 4) { if (nt) CG_RB(true, 4); else CG_RB(false, 4); }
         else if (unroll == 5) { if (nt) CG_RB(true, 5); else CG_RB(false, 5); }
         else if (unroll == 7) { if (nt) CG_RB(true, 7); else CG_RB(false, 7); }
@@ -668,6 +868,9 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
         const bool coded_any = plan.codes && plan.codes_for == cols && tune().index_codes != 0;
         const bool coded = coded_any && !plan.codes16, coded16 = coded_any && plan.codes16;
+        // ... and one-byte value codes on top (matrices of at most 256 distinct entries; complex128 has none)
+        // (its staging covers slices of at most 8 x 256 entries: rows of 8 entries on average)
+        const bool vcoded = coded && !rb_list && plan.vcodes && plan.vcodes_for == vals && tune().value_codes != 0 && a.cap <= 8 * kBlock && (unsigned long long)n * sizeof(T) < (1ULL << 31);
         a.codes = coded_any ? plan.codes : nullptr;
         a.dict = coded_any ? plan.dict : nullptr;
         const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15)

@@ -38,6 +38,8 @@ template <typename T> struct SpmvArgs {
     int cycle; // row-block kernel: block-cyclic schedule over the XCDs, cycle length in row blocks (1 = one contiguous eighth per XCD)
     const unsigned char *codes;   // coded row-block kernel: one byte per non-zero, aCols[j] = row + dict[codes[j]] (build_index_codes)
     const int *dict;              // [256]
+    const unsigned char *vcodes;  // value-coded row-block kernel: one byte per non-zero, aValues[j] == vdict[vcodes[j]] (build_value_codes)
+    const T *vdict;               // [256]
 };
 
 // Row-block schedule shared by the row-block kernels: work-group b runs on XCD b%8 as that XCD's (b/8)-th block.
@@ -149,6 +151,35 @@ CG_DEV void stage_slice(const T *__restrict__ vals, const int *__restrict__ cols
     constexpr int C = POL == -3 ? 1 : POL == -4 ? 2 : 0;
     if (((long long)(p1 + 3) & ~3LL) <= nnz) stage_slice_ilv<T, BLOCK, NT, true, C>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
     else stage_slice_ilv<T, BLOCK, NT, false, C>(vals, cols, nnz, cfirst, p1, sv, sc, codes);
+}
+
+// Both code streams of the fully coded row-block kernel (column codes + value codes, one byte each per non-zero) for the slice
+// [cfirst, p1): a dword of each per lane and round of 4 BLOCK entries, two rounds in flight.  The arrays are padded by 64 bytes:
+// no tail handling.
+template <int BLOCK, bool NT>
+CG_DEV void stage_codes2(const unsigned char *__restrict__ codes, const unsigned char *__restrict__ vcodes, int cfirst, int p1,
+                         unsigned char *sc, unsigned char *sv) {
+    const int t = threadIdx.x;
+    for (long long base = cfirst; base < p1; base += 8 * BLOCK) {
+        unsigned cw[2], vw[2];
+        long long q[2];
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            q[rg] = base + (long long)rg * 4 * BLOCK + 4 * t;
+            if (q[rg] < p1) {
+                const unsigned *cp = reinterpret_cast<const unsigned *>(codes + q[rg]), *vp = reinterpret_cast<const unsigned *>(vcodes + q[rg]);
+                cw[rg] = NT ? __builtin_nontemporal_load(cp) : *cp;
+                vw[rg] = NT ? __builtin_nontemporal_load(vp) : *vp;
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+            if (q[rg] < p1) {
+                const int o = (int)(q[rg] - cfirst);
+                *reinterpret_cast<unsigned *>(sc + o) = cw[rg];
+                *reinterpret_cast<unsigned *>(sv + o) = vw[rg];
+            }
+    }
 }
 
 }  // namespace cgamd

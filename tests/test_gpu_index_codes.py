@@ -18,6 +18,7 @@ def tuned(pkg):
     yield lambda **kv: [pkg._lib.check(lib.cgamd_tune(k.encode(), v)) for k, v in kv.items()]
     lib.cgamd_tune(b"index_codes", 1)
     lib.cgamd_tune(b"index_codes16", 1)
+    lib.cgamd_tune(b"value_codes", 1)
     lib.cgamd_tune(b"index_codes_min_mb", 32)
     lib.cgamd_tune(b"resident", 1)
 
@@ -298,3 +299,82 @@ def test_matrix_market_input_reaches_the_coded_kernel(pkg, gpu, tuned, tmp_path)
     xo, ho = cg_oracle.cg(ip, ix, da, b, n_iterations=20, mode=cg_oracle.MODE_SEQUENTIAL)
     keep = np.abs(ho[:, 0]) / np.abs(ho[0, 0]) > 1e-8
     assert keep.sum() >= 10 and np.max(np.abs(h[keep, 0] - ho[keep, 0]) / np.abs(ho[keep, 0])) < 1e-10
+
+
+def _run_values(pkg, ctx, ip, ix, da, dtype, b, iters):
+    import torch
+    dev = torch.device("cuda", 0)
+    s = _solver(pkg, ctx, ip, ix, da, dtype)
+    n = len(ip) - 1
+    x = torch.from_numpy((np.linspace(-1, 1, n) + (0.3j * np.cos(np.arange(n)) if np.dtype(dtype).kind == "c" else 0)).astype(dtype)).to(dev)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    s.spmv(x, y, fused_dot=True)
+    s.spmv(x, y, fused_dot=False)
+    bd = torch.from_numpy(b.astype(dtype)).to(dev)
+    torch.cuda.synchronize()
+    s.set_rhs(bd, None, on_device=True)
+    s.iterate(iters)
+    ctx.synchronize()
+    out = (s.value_codes, s.index_codes, y.cpu().numpy(), s.history().copy(), s.x().copy(), s.spmv_moved_bytes)
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("dt,kind", [("f64", "lap3d"), ("f32", "lap3d"), ("c64", "lap3d"), ("f64", "lap2d"), ("f64", "v256"), ("f64", "v257"),
+                                      ("c64", "helm"), ("c128", "lap3d")])
+def test_value_codes_change_no_bit(pkg, tuned, dt, kind):
+    """One-byte VALUE codes (matrices of at most 256 distinct entries: the constant-coefficient stencils of the reference's test
+    systems, clcg.c / helmFE_var.Poisson) on top of the one-byte column codes: the kernel multiplies vdict[vcode[j]] -- the same bits
+    as aValues[j] -- so SpMV, fused d.q, residual history and x are bit-identical to the kernel that streams aValues.  Exactly 256
+    distinct values are coded, 257 are not; the variable-coefficient FE matrix and complex128 keep aValues."""
+    import cg_numpy
+    import cg_oracle
+    dtype = DT[dt]
+    ctx = pkg.Context(0)
+    rng = np.random.default_rng(5)
+    if kind == "helm":
+        N = 96
+        rho = 1.0 + 0.3 * rng.random((N - 1, N - 1))
+        ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, rho, 0.15, N, N)
+    elif kind == "lap2d":
+        ip, ix, da = cg_numpy.poisson2d(150)
+    else:
+        ip, ix, da = cg_numpy.laplace3d(23, 19, 31)
+    n, nnz = len(ip) - 1, len(ix)
+    if kind in ("v256", "v257"):
+        # the same pattern with 256 / 257 distinct entries: symmetric, diagonally dominant
+        import scipy.sparse as sp
+        nv = int(kind[1:])
+        A = sp.csr_matrix((da, ix, ip), shape=(n, n)).tocoo()
+        lo = A.row > A.col
+        pool = -(1.0 + np.arange(nv - 1) / 1024.0)              # nv - 1 off-diagonal values + one diagonal value
+        w = pool[rng.integers(0, nv - 1, int(lo.sum()))]
+        w[: nv - 1] = pool                                       # every one of them occurs
+        L = sp.coo_matrix((w, (A.row[lo], A.col[lo])), shape=(n, n))
+        M = (L + L.T + sp.identity(n) * 16.0).tocsr()
+        M.sort_indices()
+        ip, ix, da = M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.copy()
+        assert len(np.unique(da)) == nv
+    if dt[0] == "c" and kind != "helm":
+        da = da * (1.0 + 0.25j)                                  # complex symmetric, still few distinct entries
+    b = np.linspace(1.0, 2.0, n) * (1 + (0.5j if dt[0] == "c" else 0))
+    iters = 25
+    tuned(resident=0, resident_wide=0, index_codes=1, index_codes_min_mb=0, value_codes=1)
+    v1, k1, y1, h1, x1, mb1 = _run_values(pkg, ctx, ip, ix, da, dtype, b, iters)
+    tuned(value_codes=0)
+    v0, k0, y0, h0, x0, mb0 = _run_values(pkg, ctx, ip, ix, da, dtype, b, iters)
+    pkg._lib.check(pkg._lib.load().cgamd_tune(b"resident_wide", 1))
+    assert v0 == 0 and k0 == k1 and k1 in (5, 7)
+    want = {"lap3d": 2, "lap2d": 2, "v256": 256, "v257": 0, "helm": 0}[kind] if dt != "c128" else 0
+    assert v1 == want, (v1, want)
+    V = np.dtype(dtype).itemsize
+    assert mb0 - mb1 == (len(ix) * (V - 1) if want else 0)       # the moved-byte model follows the form that runs
+    assert np.array_equal(y1, y0) and np.array_equal(h1, h0) and np.array_equal(x1, x0)
+    if kind != "helm":
+        wide = np.complex128 if dt[0] == "c" else np.float64
+        xo, ho = cg_oracle.cg(ip, ix, da.astype(wide), b.astype(wide), n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
+        live = np.abs(ho[:, 0]) > 1e-6 * np.abs(ho[0, 0])
+        rel = (np.abs(h1[:, 0] - ho[:, 0]) / np.abs(ho[:, 0]))[live]
+        assert rel.max() < (1e-10 if dt in ("f64", "c128") else 5e-4), rel.max()
+    ctx.close()
