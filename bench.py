@@ -58,20 +58,22 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("CG_BASELINE_THREADS", "16"))))
 
 
-def pmc_traffic():
+def pmc_traffic(kernel="spmv_rowblock_kernel"):
     """(HBM bytes per launch of the dominant kernel, where that number comes from).  PMC counters need rocprofv3 around
     the process, so the figure is read from the committed counter passes of the same command (scripts/pmc_traffic.py);
-    the newest round's file wins.  (None, reason) when absent."""
+    the newest round's file FOR THE KERNEL FORM THAT RUNS wins.  (None, reason) when absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     for f in reversed(files):
         try:
             j = json.load(open(f))
+            if j.get("kernel") != kernel:
+                continue
             return j["hbm_bytes_per_launch"], (f"profiles/{os.path.basename(f)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                                f"over bench.py, {j.get('launches_averaged', '?')} launches averaged; not measured in this run)")
         except Exception:
             continue
-    return None, "no committed PMC pass found"
+    return None, "no committed PMC pass of " + kernel + " found"
 
 
 def cpu_baseline(nx, ny, nz, dtype, budget_s=10.0, batch=50):
@@ -232,7 +234,7 @@ def small_system_extra(pkg, ctx, torch, dev):
             "finite_history": bool(np.all(np.isfinite(h[: iters + 65])))}
 
 
-def rate_fields(spmv_moved, spmv_csr, spmv_ms, spmv_alone_ms, iter_moved, iter_csr, it_s, traffic, traffic_source, n_offsets):
+def rate_fields(spmv_moved, spmv_csr, spmv_ms, spmv_alone_ms, iter_moved, iter_csr, it_s, traffic, traffic_source, n_offsets, n_values=0):
     """The rate / roofline part of the single-GPU line (pure arithmetic: tests/test_bench_launch.py checks it without a GPU).
 
     `moved`: what the kernels that ran really move -- index bytes per non-zero as the SpMV reads them (1 with the one-byte
@@ -251,13 +253,16 @@ def rate_fields(spmv_moved, spmv_csr, spmv_ms, spmv_alone_ms, iter_moved, iter_c
                           "spmv_bytes": spmv_csr, "spmv_gbs": spmv_csr / (spmv_ms * 1e-3) / 1e9,
                           "cg_iter_bytes": iter_csr, "cg_iter_gbs": iter_csr * it_s / 1e9},
         "roofline": {"bound": "hbm",
-                     "kernel": "spmv_rowblock_kernel (CSR SpMV fused with d.q partials" + (", column indices read as one-byte codes" if n_offsets > 0 else "")
+                     "kernel": ("spmv_rowblock_vc_kernel" if n_values > 0 else "spmv_rowblock_kernel") + " (CSR SpMV fused with d.q partials"
+                               + (", column indices read as one-byte codes" if n_offsets > 0 else "")
+                               + (", values as one-byte codes into the matrix's %d distinct entries: no longer bound by bytes, see DESIGN.md" % n_values if n_values > 0 else "")
                                + "), in-loop average over the instrumented pass (HIP events on each dispatch)",
                      "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_ratio": (traffic / spmv_moved) if traffic else None,
                      "moved_bytes_per_launch": spmv_moved, "avg_launch_ms": spmv_ms,
                      "index_codes": {"distinct_offsets": n_offsets, "index_bytes_per_nonzero": 2 if n_offsets == 65536 else 1 if n_offsets > 0 else 4},
+                     "value_codes": {"distinct_values": n_values, "value_bytes_per_nonzero": 1 if n_values > 0 else None},
                      "effective_csr_bytes_per_launch": spmv_csr, "effective_csr_gbs": spmv_csr / (spmv_ms * 1e-3) / 1e9},
     }
 
@@ -310,7 +315,7 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
     spmv_alone_ms = e0.elapsed_time(e1) / args.spmv_reps
     if spmv_ms is None:
         spmv_ms = spmv_alone_ms
-    traffic, traffic_source = pmc_traffic()
+    traffic, traffic_source = pmc_traffic("spmv_rowblock_vc_kernel" if solver.value_codes > 0 else "spmv_rowblock_kernel")
     delta0, deltak = abs(hist[0, 0]), abs(hist[-1, 0])
     res = {
         "metric": "CG iterations/sec + SpMV effective HBM GB/s (% of 8 TB/s peak), N=10M CSR",
@@ -324,8 +329,31 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
     }
     res.update(rate_fields(spmv_moved=solver.spmv_moved_bytes, spmv_csr=spmv_bytes, spmv_ms=spmv_ms, spmv_alone_ms=spmv_alone_ms,
                            iter_moved=solver.iter_moved_bytes, iter_csr=iter_bytes, it_s=it_s, traffic=traffic,
-                           traffic_source=traffic_source, n_offsets=solver.index_codes))
+                           traffic_source=traffic_source, n_offsets=solver.index_codes, n_values=solver.value_codes))
+    n_values = solver.value_codes
     solver.close()
+    if n_values > 0 and not args.unfused:
+        # For the record, in the same process: the same system with the value stream as passed (the HBM-bound form of the kernel; the
+        # constant-coefficient stencil of this workload has 2 distinct entries, a variable-coefficient matrix runs this form).
+        lib.check(lib.load().cgamd_tune(b"dev.value_codes", 0))
+        try:
+            s2 = pkg.Solver(ctx, n, nnz, data, indptr, indices, 1, flags=flags, dtype=dtype)
+        finally:
+            lib.check(lib.load().cgamd_tune(b"dev.value_codes", 1))
+        s2.set_rhs(b, None, on_device=True)
+        s2.iterate(args.warmup)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        s2.iterate(args.steps)
+        ctx.synchronize()
+        dt2 = time.perf_counter() - t0
+        ms2, _ = s2.iterate_timed(args.steps)
+        moved2 = s2.spmv_moved_bytes
+        res["values_as_passed"] = {"note": "same run, value codes off (dev.value_codes=0): the kernel that streams aValues",
+                                   "value": args.steps / dt2, "spmv_avg_launch_ms": ms2, "moved_bytes_per_launch": moved2,
+                                   "spmv_gbs": moved2 / (ms2 * 1e-3) / 1e9, "frac": moved2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "history_bit_identical": bool(np.array_equal(s2.history()[: args.warmup + args.steps + 1], hist[: args.warmup + args.steps + 1]))}
+        s2.close()
     return res
 
 

@@ -41,7 +41,6 @@ int cgamd_tune(const char *key, int value) {
     // public keys (include/cgamd.h)
     if (k == "index_codes") g_tune.index_codes = value;
     else if (k == "index_codes16") g_tune.index_codes16 = value;
-    else if (k == "value_codes") g_tune.value_codes = value;
     else if (k == "index_codes_min_mb") g_tune.index_codes_min_mb = value;
     else if (k == "resident") g_tune.resident = value;
     else if (k == "resident_min") g_tune.resident_min = value;
@@ -58,6 +57,7 @@ int cgamd_tune(const char *key, int value) {
     // development hooks: tests, rehearsals, profiling (not part of the documented interface)
     else if (k == "dev.no_fold_alpha") g_tune.dev_no_fold_alpha = value;
     else if (k == "dev.generic_spmv") g_tune.dev_generic_spmv = value;
+    else if (k == "dev.value_codes") g_tune.value_codes = value;
     else if (k == "dev.resident_lock") g_tune.resident_lock = value;
     else if (k == "dev.slab_cus") g_tune.slab_cus = value;
     else if (k == "dev.slab_trim") g_tune.slab_trim = value;

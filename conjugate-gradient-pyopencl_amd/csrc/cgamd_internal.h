@@ -88,7 +88,6 @@ struct Tuning {
     // ---- public
     int index_codes = 1;    // single-RHS row-block SpMV on one-byte column codes (0 = always aCols)
     int index_codes16 = 1;  // ... and, where the matrix has more than 256 offsets, on 16-bit block-relative columns (0 = aCols then)
-    int value_codes = 1;    // ... and, where the matrix has at most 256 distinct values, one-byte value codes on top of the one-byte column codes
     int index_codes_min_mb = 32;    // ... for matrices above this size (smaller systems run the resident / two-launch loops, which read aCols)
     int resident = 1;       // systems of at most 32768 rows whose matrix slices fit LDS: all iterations of an iterate() call in ONE launch
                             // (resident.hip); 0 = never, 2 = always in the cross-XCD form (up to 65536 rows; for the any-placement tests)
@@ -107,6 +106,7 @@ struct Tuning {
     int vec_grid = 0;       // vector kernels: work-groups, 0 = auto
     // ---- development hooks ("dev." keys): tests, rehearsals, profiling
     int dev_no_fold_alpha = 0;      // 1: small systems keep the separate cg_alpha launch (the four-launch family at sizes that would fold it)
+    int value_codes = 1;            // one-byte value codes on top of the one-byte column codes where the matrix has at most 256 distinct entries (0 = off: A/B, tests)
     int dev_generic_spmv = 0;       // 1: the generic chunked CSR stream for every matrix (the row-block kernels' fallback, tested against them)
     int resident_lock = 1;          // 0: no per-GPU serialisation of resident launches (ranks of ONE job sharing a GPU in a rehearsal)
     int slab_trim = -1;             // slab loop: 1024-row granules a member that pushes to a peer owns fewer than the others (-1 = 2, 0 = equal members)

@@ -188,7 +188,7 @@ int cgamd_solver_loop_launches(cgamd_solver *s);
 int cgamd_solver_index_codes(cgamd_solver *s);
 /* distinct matrix entries behind the one-byte VALUE codes of the handle's single-RHS SpMV (matrices of at most 256 distinct entries
  * that also run on one-byte column codes: 2 bytes per non-zero from memory, same bits); 0 = the SpMV reads aValues.
- * cgamd_tune("value_codes", 0) turns the form off. */
+ * (cgamd_tune("dev.value_codes", 0) turns the form off for A/B runs.) */
 int cgamd_solver_value_codes(cgamd_solver *s);
 int cgamd_transpose(cgamd_ctx *ctx, int dtype, int rows, int cols, const void *in, void *out);
 /* algorithmic HBM bytes of one SpMV / one CG iteration of this solver (SURVEY §8d formulae: 14 vector passes for the

@@ -18,7 +18,7 @@ def tuned(pkg):
     yield lambda **kv: [pkg._lib.check(lib.cgamd_tune(k.encode(), v)) for k, v in kv.items()]
     lib.cgamd_tune(b"index_codes", 1)
     lib.cgamd_tune(b"index_codes16", 1)
-    lib.cgamd_tune(b"value_codes", 1)
+    lib.cgamd_tune(b"dev.value_codes", 1)
     lib.cgamd_tune(b"index_codes_min_mb", 32)
     lib.cgamd_tune(b"resident", 1)
 
@@ -360,9 +360,9 @@ def test_value_codes_change_no_bit(pkg, tuned, dt, kind):
         da = da * (1.0 + 0.25j)                                  # complex symmetric, still few distinct entries
     b = np.linspace(1.0, 2.0, n) * (1 + (0.5j if dt[0] == "c" else 0))
     iters = 25
-    tuned(resident=0, resident_wide=0, index_codes=1, index_codes_min_mb=0, value_codes=1)
+    tuned(resident=0, resident_wide=0, index_codes=1, index_codes_min_mb=0, **{"dev.value_codes": 1})
     v1, k1, y1, h1, x1, mb1 = _run_values(pkg, ctx, ip, ix, da, dtype, b, iters)
-    tuned(value_codes=0)
+    tuned(**{"dev.value_codes": 0})
     v0, k0, y0, h0, x0, mb0 = _run_values(pkg, ctx, ip, ix, da, dtype, b, iters)
     pkg._lib.check(pkg._lib.load().cgamd_tune(b"resident_wide", 1))
     assert v0 == 0 and k0 == k1 and k1 in (5, 7)
