@@ -296,6 +296,8 @@ struct SlabPlan {
     int rows_m = 0, G = 0, nsteps = 0, cap = 0, ccap = 0, unroll = 8;      // rows_m / nsteps: of the largest member
     size_t lds_bytes = 0, sync_bytes = 0;
     const int *mstart = nullptr, *gmember = nullptr;      // device arrays of a non-uniform partition (slab_partition), owned by the caller
+    const unsigned char *vcodes = nullptr;                // one-byte value codes of the matrix and their dictionary (build_value_codes), owned by
+    const void *vdict = nullptr;                          // the caller; null = the members stream the values
 };
 bool slab_plan(int dtype, int n, int n_cus, const SpmvPlan &plan, bool coded, SlabPlan *out);
 int slab_partition(const SlabPlan &sp, int n, const std::vector<char> &boundary, int trim, int max_members, std::vector<int> *mstart,

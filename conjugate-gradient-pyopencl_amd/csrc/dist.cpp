@@ -126,6 +126,9 @@ struct cgamd_dist {
     unsigned char *codes = nullptr;
     int *dict = nullptr;
     int n_offsets = 0;
+    unsigned char *vcodes = nullptr;    // one-byte value codes on top (build_value_codes), with their dictionary
+    void *vdict = nullptr;
+    int n_values = 0;
     // single-reduction loop (CGAMD_DIST_SINGLE_REDUCTION, cg1.hip).  Roles of the buffers there: d_ext = r (the residual is what the
     // SpMV gathers, so it carries the halo), r = p, q = w = A r, s2 = s = A p
     bool cg1 = false;
@@ -424,6 +427,10 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
         (size_t)nnz_local * (dtype_size(dtype) + 4) > ((size_t)d->tune.index_codes_min_mb << 20)) {
         rc = build_index_codes(n_local, nnz_local, d->ptr, d->cols, ctx->stream, &d->codes, &d->dict, &d->n_offsets);
         if (!rc && d->codes) { d->plan.codes = d->codes; d->plan.dict = d->dict; d->plan.codes_for = d->cols; }
+        if (!rc && d->codes && d->tune.value_codes && d->plan.kind == 5) {
+            rc = build_value_codes(dtype, nnz_local, d->vals, ctx->stream, &d->vcodes, &d->vdict, &d->n_values);
+            if (!rc && d->vcodes) { d->plan.vcodes = d->vcodes; d->plan.vdict = d->vdict; d->plan.vcodes_for = d->vals; }
+        }
     }
     if (!rc && d->cg1) {
         if (!cg1_supported(d->plan, d->vals, d->cols))
@@ -438,6 +445,7 @@ int cgamd_dist_create(cgamd_ctx *ctx, const void *id128, int rank, int nranks, i
         if (d->tune.slab_cus > 0) d->n_cus = std::min(d->n_cus, d->tune.slab_cus);
         SlabPlan sp;
         if (slab_plan(dtype, n_local, d->n_cus, d->plan, d->codes != nullptr, &sp)) {
+            sp.vcodes = d->vcodes; sp.vdict = d->vdict;
             rc = dalloc(&d->slab_sync, sp.sync_bytes, "slab sync words");
             if (!rc && d->peer.empty() && nranks == 1) {     // nothing to exchange: plain buffers, usable at once
                 for (int b = 0; b < 2 && !rc; ++b) rc = dalloc(&d->ds_own[b], (size_t)n_local * vs, "published d");
@@ -495,6 +503,8 @@ int cgamd_dist_destroy(cgamd_dist *d) {
     if (d->boundary_list) (void)hipFree(d->boundary_list);
     if (d->halo_flag) (void)hipFree(d->halo_flag);
     if (d->codes) (void)hipFree(d->codes);
+    if (d->vcodes) (void)hipFree(d->vcodes);
+    if (d->vdict) (void)hipFree(d->vdict);
     if (d->dict) (void)hipFree(d->dict);
     void *bufs[] = {d->x, d->r, d->q, d->b, d->d_ext, d->sendbuf, d->part_dq, d->part_rr, d->red, d->sc.alpha,
                     d->sc.beta, d->sc.delta, d->sc.history, d->sc.iter, d->s2, d->cg1_state, d->part_cg1, d->slab_sync, d->slab_map, d->ds_own[0], d->ds_own[1],

@@ -76,17 +76,23 @@ template <typename T> struct SpmvP2pArgs {
     int n_local, rotate, push_chunks;   // rotate: row blocks are visited from this one on, so leading boundary blocks come last
 };
 
-template <typename T, int BLOCK, bool NT, int UNROLL, bool CODED = false>
+// CMODE: 0 = aCols / aValues, 1 = one-byte column codes, 2 = one-byte column AND value codes (index_codes.hip: the same columns and
+// the same value bits either way)
+template <typename T, int BLOCK, bool NT, int UNROLL, int CMODE = 0>
 __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T> g) {
     using A = typename VT<T>::acc;
+    constexpr bool CODED = CMODE >= 1, VCODED = CMODE == 2;
     const SpmvArgs<T> &a = g.s;
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     T *sv = reinterpret_cast<T *>(dyn_smem);
-    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));      // CODED: cap bytes of column codes
+    int *sc = reinterpret_cast<int *>(dyn_smem + (VCODED ? 0 : (size_t)a.cap * sizeof(T)));      // CODED: cap bytes of column codes
+    [[maybe_unused]] const unsigned char *svc = reinterpret_cast<const unsigned char *>(dyn_smem) + a.cap;      // VCODED: cap bytes of value codes
     __shared__ A red[BLOCK / kWave];
     __shared__ int sdict[CODED ? BLOCK : 1];
+    __shared__ T sdictv[VCODED ? BLOCK : 1];
     const int t = threadIdx.x, b = blockIdx.x;
     if constexpr (CODED) sdict[t] = a.dict[t];
+    if constexpr (VCODED) sdictv[t] = a.vdict[t];
     // the epoch is loaded only where it is needed: a load here would sit in front of every work-group's first wait
     if (b < g.x.n_peers * g.push_chunks)
         p2p_push_chunk<T>(g.x, a.x, b / g.push_chunks, b % g.push_chunks, g.push_chunks, *g.x.epoch + 1);
@@ -101,7 +107,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T>
     const int s_raw = a.ptr[rclamp], e_raw = a.ptr[rclamp + 1];
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
-    stage_slice<T, BLOCK, NT, CODED ? -3 : -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc, a.codes);
+    if constexpr (VCODED) stage_codes2<BLOCK, NT>(a.codes, a.vcodes, cfirst, p1, reinterpret_cast<unsigned char *>(dyn_smem), reinterpret_cast<unsigned char *>(dyn_smem) + a.cap);
+    else stage_slice<T, BLOCK, NT, CODED ? -3 : -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc, a.codes);
     const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
     const bool boundary = bflag != 0;
     if (boundary && t == 0) {
@@ -124,7 +131,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T>
                 const int idx = min(k + j, e - 1);
                 if constexpr (CODED) cj[j] = reinterpret_cast<const unsigned char *>(sc)[idx];
                 else cj[j] = sc[idx];
-                av[j] = sv[idx];
+                if constexpr (VCODED) av[j] = sdictv[svc[idx]];
+                else av[j] = sv[idx];
             }
             if constexpr (CODED) {
 #pragma unroll
@@ -151,7 +159,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_p2p_kernel(SpmvP2pArgs<T>
                 const int idx = min(k + j, e - 1);
                 if constexpr (CODED) cj[j] = reinterpret_cast<const unsigned char *>(sc)[idx];
                 else cj[j] = sc[idx];
-                av[j] = sv[idx];
+                if constexpr (VCODED) av[j] = sdictv[svc[idx]];
+                else av[j] = sv[idx];
             }
             if constexpr (CODED) {
 #pragma unroll
@@ -338,9 +347,13 @@ static int spmv_p2p_impl(const SpmvPlan &plan, int n, long long nnz, const void 
     g.halo = static_cast<const T *>(e.my_halo);
     g.n_local = e.n_local; g.rotate = rotate; g.push_chunks = p2p_push_chunks(e);
     const bool coded = plan.codes && !plan.codes16 && plan.codes_for == cols && tune().index_codes != 0;
+    const bool vcoded = coded && sizeof(T) <= 8 && plan.vcodes && plan.vcodes_for == vals && tune().value_codes != 0;
     a.codes = coded ? plan.codes : nullptr;
     a.dict = coded ? plan.dict : nullptr;
-    const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
+    a.vcodes = vcoded ? plan.vcodes : nullptr;
+    a.vdict = vcoded ? static_cast<const T *>(plan.vdict) : nullptr;
+    const size_t lds = vcoded ? (((size_t)a.cap * 2 + 15) & ~(size_t)15)
+                              : coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
     const int grid = rowblock_grid(plan.row_blocks, a.cycle);
     if (grid < e.n_peers * g.push_chunks) return fail(CGAMD_ERR_STATE, "spmv_p2p: fewer work-groups than push chunks");
     const dim3 gd(grid), block(kBlock);
@@ -350,9 +363,12 @@ static int spmv_p2p_impl(const SpmvPlan &plan, int n, long long nnz, const void 
     const int fit = (sizeof(T) > 8 || tune().spmv_unroll) ? U : plan.max_row == 5 ? 5 : (plan.max_row == 6 || plan.max_row == 7) ? 7 : U;
 #define CG_P2P(UU)                                                                                                      \
     do {                                                                                                                \
-        if (coded) {                                                                                                    \
-            if (nt) hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, true, UU, true>), gd, block, lds, st, g);   \
-            else hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, false, UU, true>), gd, block, lds, st, g);     \
+        if (vcoded) {                                                                                                   \
+            if (nt) hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, true, UU, 2>), gd, block, lds, st, g);      \
+            else hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, false, UU, 2>), gd, block, lds, st, g);        \
+        } else if (coded) {                                                                                             \
+            if (nt) hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, true, UU, 1>), gd, block, lds, st, g);      \
+            else hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, false, UU, 1>), gd, block, lds, st, g);        \
         } else if (nt) hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, true, UU>), gd, block, lds, st, g);      \
         else hipLaunchKernelGGL((spmv_rowblock_p2p_kernel<T, kBlock, false, UU>), gd, block, lds, st, g);               \
     } while (0)

@@ -56,6 +56,8 @@ template <typename T> struct SlabArgs {
     const int *ptr;
     const unsigned char *codes;     // one byte per non-zero: aCols[j] = row + dict[codes[j]] (index_codes.hip); padded by 64 bytes
     const int *dict;
+    const unsigned char *vcodes;    // one byte per non-zero: aValues[j] == vdict[vcodes[j]] (build_value_codes), or null = the values are streamed
+    const T *vdict;
     T *x, *r;
     T *din;                         // the caller's d (already beta d + r: state of the three / four-launch loops); rewritten at the end
     T *ds0, *ds1;                   // [n + n_halo] each: where iteration k's d is published (k & 1); with peers: uncached, IPC-shared, the peers
@@ -186,6 +188,31 @@ CG_DEV T slab_row(const T *vs, const unsigned char *scode, const int *sdict, int
     return sum;
 }
 
+// the same with the values from the LDS-resident value codes and their dictionary (nothing of the matrix is streamed)
+template <typename T, int UNROLL>
+CG_DEV T slab_row_vc(const unsigned char *svcode, const T *sdictv, const unsigned char *scode, const int *sdict, int s, int e, int row, int R0,
+                     int rows_m, const T *dl, const FarRegs<T, UNROLL> &f) {
+    T sum = vzero<T>();
+    T av[UNROLL], xv[UNROLL];
+    bool far[UNROLL];
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) {
+        const int idx = max(s + min(j, e - s - 1), 0);
+        const int c = row + sdict[scode[idx]];
+        const unsigned off = (unsigned)(c - R0);
+        far[j] = off >= (unsigned)rows_m;
+        av[j] = sdictv[svcode[idx]];
+        xv[j] = dl[far[j] ? 0u : off];
+    }
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) {
+        const T xx = vsel(far[j], f.v[j], xv[j]);
+        const T nxt = vfma(av[j], xx, sum);
+        sum = vsel(s + j < e, nxt, sum);
+    }
+    return sum;
+}
+
 // The sum of `local` over all ranks in rank order (bitwise identical everywhere), for a whole wave: lane s publishes this rank's
 // value in rank s's mailbox and waits for rank s's value in its own (p2p_device.h: scalar slots of the single-reduction region,
 // parity = tag & 1, the epoch word carries the launch sequence and the tag).  Every polling work-group of a rank publishes the
@@ -228,14 +255,18 @@ template <typename T, typename A> CG_DEV A slab_rank_sum(const SlabArgs<T> &a, u
     return from_acc2<A>(tot);
 }
 
-template <typename T, int RPT, int UNROLL>
+// VC: the matrix values are one-byte codes into a dictionary of at most 256 entries (build_value_codes), held in LDS like the column
+// codes: the member streams NOTHING of the matrix, the value slices, their staging registers and the barrier per step are gone.
+template <typename T, int RPT, int UNROLL, bool VC>
 __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     using A = typename VT<T>::acc;
     constexpr int W = sizeof(A) / 4;
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     T *dl = reinterpret_cast<T *>(dyn_smem);                    // d of my rows [rows_m]
-    T *sval = dl + a.rows_m;                                    // two value slices [2][vcap]
-    unsigned char *scode = reinterpret_cast<unsigned char *>(sval + 2 * (size_t)a.vcap);     // the column codes of all my rows [ccap]
+    T *sval = dl + a.rows_m;                                    // two value slices [2][vcap]; VC: the value codes of all my rows [ccap]
+    unsigned char *svcode = reinterpret_cast<unsigned char *>(sval);
+    unsigned char *scode = VC ? svcode + a.ccap : reinterpret_cast<unsigned char *>(sval + 2 * (size_t)a.vcap);     // the column codes of all my rows [ccap]
+    __shared__ T sdictv[VC ? 256 : 1];
     __shared__ ResShared sh;
     __shared__ int sdict[256];
     __shared__ unsigned depmask[8];
@@ -277,8 +308,13 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     const int R0 = a.mstart ? a.mstart[m] : m * a.rows_m, R1 = min(a.mstart ? a.mstart[m + 1] : R0 + a.rows_m, a.n);
     const int nsteps = a.mstart ? (a.mstart[m + 1] - a.mstart[m]) / kSlabStep : a.nsteps;      // even (members start at multiples of 1024)
     const int c0 = a.ptr[R0] & ~3, cend = a.ptr[R1];            // my entries are [c0, cend)
-    for (int o = 4 * t; o < cend - c0; o += 4 * kResThreads)
+    for (int o = 4 * t; o < cend - c0; o += 4 * kResThreads) {
         *reinterpret_cast<unsigned *>(scode + o) = *reinterpret_cast<const unsigned *>(a.codes + c0 + o);
+        if constexpr (VC) *reinterpret_cast<unsigned *>(svcode + o) = *reinterpret_cast<const unsigned *>(a.vcodes + c0 + o);
+    }
+    if constexpr (VC) {
+        if (t < 256) sdictv[t] = a.vdict[t];
+    }
     if (t <= RPT) {
         const int ra = min(R0 + t * kSlabStep, R1);
         sbound[2 * t] = a.ptr[ra] & ~3;
@@ -366,13 +402,15 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     // issues the loads of step G + 3 into the freed set.  Two slices (~56 KB per CU) in flight are what the memory latency under
     // load (~2.3 us measured) needs for the chip's streaming rate; one (the first version) ran the product at 3 TB/s.
     SliceRegs<T> slA, slB;          // slA: slices of odd global steps, slB: of even ones (nsteps is even: the parity of a step is that of h)
-    const __amdgpu_buffer_rsrc_t rv = slab_rsrc(a.vals, (unsigned)((a.nnz * (long long)sizeof(T) + 15) & ~15LL));
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rv = slab_rsrc(a.vals, (unsigned)((a.nnz * (long long)sizeof(T) + 15) & ~15LL));
     const unsigned dbytes = (unsigned)(a.n + a.n_halo) * (unsigned)sizeof(T);
     const __amdgpu_buffer_rsrc_t rd0 = slab_rsrc(a.ds0, dbytes), rd1 = slab_rsrc(a.ds1, dbytes);
-    slab_stage_load<T>(rv, sbound[0], sbound[1], slB);
-    slab_stage_store<T>(slB, sval);
-    slab_stage_load<T>(rv, sbound[2], sbound[3], slA);                                     // step 1
-    slab_stage_load<T>(rv, sbound[2 * (2 % nsteps)], sbound[2 * (2 % nsteps) + 1], slB);   // step 2
+    if constexpr (!VC) {
+        slab_stage_load<T>(rv, sbound[0], sbound[1], slB);
+        slab_stage_store<T>(slB, sval);
+        slab_stage_load<T>(rv, sbound[2], sbound[3], slA);                                     // step 1
+        slab_stage_load<T>(rv, sbound[2 * (2 % nsteps)], sbound[2 * (2 % nsteps) + 1], slB);   // step 2
+    }
     __syncthreads();
 
     long long stamp = clock64();
@@ -482,14 +520,19 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
             const int s = (int)(info >> 5), e = s + (int)(info & 31u);
             const int s2 = (int)(info2 >> 5), e2 = s2 + (int)(info2 & 31u);
             slab_far_issue<T, UNROLL>(scode, sdict, s2, e2, R0 + (h + 1) * kSlabStep + t, R0, R1 - R0, rd, h + 1 < nsteps, fnext);
-            slab_stage_store<T>(sl, sval + (size_t)(bcur ^ 1) * a.vcap);
-            const int j3 = (h + 3) % nsteps;           // (past the last iteration: a redundant load, never stored)
-            slab_stage_load<T>(rv, sbound[2 * j3], sbound[2 * j3 + 1], sl);
-            const T qv = slab_row<T, UNROLL>(sval + (size_t)bcur * a.vcap + (e > s ? (c0 + s) - sbound[2 * h] : 0), scode, sdict, s, e,
-                                             R0 + h * kSlabStep + t, R0, R1 - R0, dl, fcur);
+            T qv;
+            if constexpr (VC) {
+                qv = slab_row_vc<T, UNROLL>(svcode, sdictv, scode, sdict, s, e, R0 + h * kSlabStep + t, R0, R1 - R0, dl, fcur);
+            } else {
+                slab_stage_store<T>(sl, sval + (size_t)(bcur ^ 1) * a.vcap);
+                const int j3 = (h + 3) % nsteps;           // (past the last iteration: a redundant load, never stored)
+                slab_stage_load<T>(rv, sbound[2 * j3], sbound[2 * j3 + 1], sl);
+                qv = slab_row<T, UNROLL>(sval + (size_t)bcur * a.vcap + (e > s ? (c0 + s) - sbound[2 * h] : 0), scode, sdict, s, e,
+                                         R0 + h * kSlabStep + t, R0, R1 - R0, dl, fcur);
+            }
 #pragma unroll
             for (int i = 0; i < RPT; ++i) pq[i] = vsel(h == i, qv, pq[i]);
-            __syncthreads();                         // slice h is done with; slice h + 1 is complete in the other buffer
+            if constexpr (!VC) __syncthreads();      // slice h is done with; slice h + 1 is complete in the other buffer
         };
 #pragma unroll 1
         for (int h = 0; h < nsteps; h += 2) {
@@ -557,9 +600,9 @@ __global__ __launch_bounds__(kResThreads) void cg_slab_kernel(SlabArgs<T> a) {
     }
 }
 
-template <typename T, int RPT, int UNROLL>
-int slab_launch(const SlabArgs<T> &a, size_t lds, hipStream_t st) {
-    auto kern = cg_slab_kernel<T, RPT, UNROLL>;
+template <typename T, int RPT, int UNROLL, bool VC>
+int slab_launch_vc(const SlabArgs<T> &a, size_t lds, hipStream_t st) {
+    auto kern = cg_slab_kernel<T, RPT, UNROLL, VC>;
     if (lds > 64 * 1024) {
         const size_t want = std::min<size_t>((lds + 8191) & ~(size_t)8191, 152 * 1024);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
@@ -567,6 +610,10 @@ int slab_launch(const SlabArgs<T> &a, size_t lds, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(a.G), dim3(kResThreads), lds, st, a);
     return check_launch("cg_slab");
+}
+template <typename T, int RPT, int UNROLL>
+int slab_launch(const SlabArgs<T> &a, size_t lds, hipStream_t st) {
+    return a.vcodes ? slab_launch_vc<T, RPT, UNROLL, true>(a, lds, st) : slab_launch_vc<T, RPT, UNROLL, false>(a, lds, st);
 }
 
 }  // namespace
@@ -588,7 +635,8 @@ bool slab_plan(int dtype, int n, int n_cus, const SpmvPlan &plan, bool coded, Sl
     if (((long long)plan.max_span * 2 + 8) > 8LL * kResThreads) return false;
     const long long vcap = 8LL * kResThreads;       // the whole staging round is stored
     const long long ccap = (((long long)plan.max_span * (rows_m / 256) + 8 + 15) & ~15LL) + 16;
-    const size_t lds = (size_t)rows_m * vs + 2 * (size_t)vcap * vs + (size_t)ccap + 64;
+    // (streamed values: two slices + the column codes; value codes: both code arrays -- the launch takes whichever form the matrix has)
+    const size_t lds = (size_t)rows_m * vs + std::max(2 * (size_t)vcap * vs + (size_t)ccap, 2 * (size_t)ccap) + 64;
     if (lds > 150 * 1024) return false;
     out->ok = true; out->rows_m = (int)rows_m; out->G = G; out->cap = (int)vcap; out->ccap = (int)ccap; out->lds_bytes = (lds + 15) & ~(size_t)15;
     out->nsteps = (int)(rows_m / kSlabStep);
@@ -644,6 +692,7 @@ static int slab_impl(const SlabPlan &sp, int n, long long nnz, const void *vals,
     a.nnz = nnz;
     a.claim_ticks = (long long)std::max(1, tune().resident_claim_ms) * 100000;
     a.vals = static_cast<const T *>(vals); a.ptr = ptr; a.codes = codes; a.dict = dict;
+    a.vcodes = (sp.vcodes && sp.vdict && tune().value_codes != 0) ? sp.vcodes : nullptr; a.vdict = static_cast<const T *>(sp.vdict);
     a.x = static_cast<T *>(x); a.r = static_cast<T *>(r); a.din = static_cast<T *>(din); a.ds0 = static_cast<T *>(ds0); a.ds1 = static_cast<T *>(ds1);
     a.alpha = (T *)sc.alpha; a.beta = (T *)sc.beta; a.delta = (T *)sc.delta; a.history = (T *)sc.history; a.iter = sc.iter;
     a.n_halo = 0; a.nranks = 1; a.rank = 0; a.n_peers = 0;

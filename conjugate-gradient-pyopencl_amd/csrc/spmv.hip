@@ -269,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_vc_kernel(SpmvArgs<T> a) 
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
     sdict[t] = a.dict[t] * (int)sizeof(T);     // byte offsets into x; visible after the first staging barrier
     sdictv[t] = a.vdict[t];
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(a.x), 0, (int)((unsigned)a.n * (unsigned)sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(a.x), 0, 0x7ffffffc, 0x00020000);      // (no bound of its own: the columns were validated, and a rank's x carries halo entries behind its n rows)
     const int supers = (a.row_blocks + kVcBlocks - 1) / kVcBlocks;
     const int srb = rowblock_of(blockIdx.x, supers, a.cycle);
     if (srb < 0) return;
@@ -811,7 +811,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         const bool coded = coded_any && !plan.codes16, coded16 = coded_any && plan.codes16;
         // ... and one-byte value codes on top (matrices of at most 256 distinct entries; complex128 has none)
         // (its staging covers slices of at most 8 x 256 entries: rows of 8 entries on average)
-        const bool vcoded = coded && !rb_list && plan.vcodes && plan.vcodes_for == vals && tune().value_codes != 0 && a.cap <= 8 * kBlock && (unsigned long long)n * sizeof(T) < (1ULL << 31);
+        const bool vcoded = coded && !rb_list && plan.vcodes && plan.vcodes_for == vals && tune().value_codes != 0 && a.cap <= 8 * kBlock && (unsigned long long)n * sizeof(T) < (1ULL << 30);
         a.codes = coded_any ? plan.codes : nullptr;
         a.dict = coded_any ? plan.dict : nullptr;      // (16-bit form: the first column of every row block)
         const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15)
@@ -870,7 +870,7 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         const bool coded = coded_any && !plan.codes16, coded16 = coded_any && plan.codes16;
         // ... and one-byte value codes on top (matrices of at most 256 distinct entries; complex128 has none)
         // (its staging covers slices of at most 8 x 256 entries: rows of 8 entries on average)
-        const bool vcoded = coded && !rb_list && plan.vcodes && plan.vcodes_for == vals && tune().value_codes != 0 && a.cap <= 8 * kBlock && (unsigned long long)n * sizeof(T) < (1ULL << 31);
+        const bool vcoded = coded && !rb_list && plan.vcodes && plan.vcodes_for == vals && tune().value_codes != 0 && a.cap <= 8 * kBlock && (unsigned long long)n * sizeof(T) < (1ULL << 30);
         a.codes = coded_any ? plan.codes : nullptr;
         a.dict = coded_any ? plan.dict : nullptr;
         const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15)

@@ -35,8 +35,12 @@ def _tuned(pkg, **kv):
         pkg._lib.check(lib.cgamd_tune(k.encode(), int(v)))
 
 
-@pytest.mark.parametrize("dtype,coded", [(np.float64, True), (np.float32, True), (np.complex64, True)])
-def test_slab_loop_matches_oracle(pkg, gpu, dtype, coded):
+@pytest.mark.parametrize("dtype,coded,vcoded", [(np.float64, True, True), (np.float32, True, True), (np.complex64, True, True),
+                                                 (np.float64, True, False), (np.float32, True, False)])
+def test_slab_loop_matches_oracle(pkg, gpu, dtype, coded, vcoded):
+    """vcoded: the members keep one-byte VALUE codes of their rows in LDS and stream nothing of the matrix (matrices of at most 256
+    distinct entries, build_value_codes); False: the value slices are streamed (`dev.value_codes = 0`: what a variable-coefficient
+    matrix gets)."""
     import torch
     ctx, queue, kernels = gpu
     lib = pkg._lib.load()
@@ -53,9 +57,10 @@ def test_slab_loop_matches_oracle(pkg, gpu, dtype, coded):
     try:
         if not coded:
             _tuned(pkg, index_codes=0)
+        _tuned(pkg, **{"dev.value_codes": int(vcoded)})
         s = _handle(pkg, ctx, ip, ix, da, dtype, RESIDENT)
     finally:
-        _tuned(pkg, index_codes=1)
+        _tuned(pkg, index_codes=1, **{"dev.value_codes": 1})
     assert (s.index_codes() > 0) == coded
     assert lib.cgamd_dist_loop_launches(s.handle) == 0
     bl = torch.from_numpy(b.astype(dtype)).to(dev)
