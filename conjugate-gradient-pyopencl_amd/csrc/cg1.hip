@@ -40,17 +40,22 @@ template <typename T> struct Cg1SpmvArgs {
 
 // spmv_rowblock_p2p_kernel's structure (p2p.hip) with two fused dots; P2P = false: a rank without the peer-to-peer backend
 // (halo already in the extended vector) or a single rank
-template <typename T, int BLOCK, bool NT, int UNROLL, bool CODED, bool P2P>
+// CMODE: 0 = aCols / aValues, 1 = one-byte column codes, 2 = one-byte column and value codes (index_codes.hip)
+template <typename T, int BLOCK, bool NT, int UNROLL, int CMODE, bool P2P>
 __global__ __launch_bounds__(BLOCK) void spmv_cg1_kernel(Cg1SpmvArgs<T> g) {
     using A = typename VT<T>::acc;
+    constexpr bool CODED = CMODE >= 1, VCODED = CMODE == 2;
     const SpmvArgs<T> &a = g.s;
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     T *sv = reinterpret_cast<T *>(dyn_smem);
-    int *sc = reinterpret_cast<int *>(dyn_smem + (size_t)a.cap * sizeof(T));      // CODED: cap bytes of column codes
+    int *sc = reinterpret_cast<int *>(dyn_smem + (VCODED ? 0 : (size_t)a.cap * sizeof(T)));      // CODED: cap bytes of column codes
+    [[maybe_unused]] const unsigned char *svc = reinterpret_cast<const unsigned char *>(dyn_smem) + a.cap;      // VCODED: cap bytes of value codes
     __shared__ A red[BLOCK / kWave];
     __shared__ int sdict[CODED ? BLOCK : 1];
+    __shared__ T sdictv[VCODED ? BLOCK : 1];
     const int t = threadIdx.x, b = blockIdx.x;
     if constexpr (CODED) sdict[t] = a.dict[t];
+    if constexpr (VCODED) sdictv[t] = a.vdict[t];
     if constexpr (P2P) {
         if (b < g.x.n_peers * g.push_chunks)
             p2p_push_chunk<T>(g.x, a.x, b / g.push_chunks, b % g.push_chunks, g.push_chunks, *g.x.epoch + 1);
@@ -72,7 +77,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_cg1_kernel(Cg1SpmvArgs<T> g) {
     const int p0 = a.ptr[r0], p1 = a.ptr[min(r0 + BLOCK, a.n)];
     const int cfirst = p0 & ~3;
     const T r_own = a.x[rclamp];
-    stage_slice<T, BLOCK, NT, CODED ? -3 : -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc, a.codes);
+    if constexpr (VCODED) stage_codes2<BLOCK, NT>(a.codes, a.vcodes, cfirst, p1, reinterpret_cast<unsigned char *>(dyn_smem), reinterpret_cast<unsigned char *>(dyn_smem) + a.cap);
+    else stage_slice<T, BLOCK, NT, CODED ? -3 : -2>(a.vals, a.cols, a.nnz, cfirst, p1, sv, sc, a.codes);
     const int s = s_raw - cfirst, e = (row < a.n) ? e_raw - cfirst : s_raw - cfirst;
     const bool boundary = bflag != 0;
     if constexpr (P2P) {
@@ -96,7 +102,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_cg1_kernel(Cg1SpmvArgs<T> g) {
             const int idx = min(k + j, e - 1);
             if constexpr (CODED) cj[j] = reinterpret_cast<const unsigned char *>(sc)[idx];
             else cj[j] = sc[idx];
-            av[j] = sv[idx];
+            if constexpr (VCODED) av[j] = sdictv[svc[idx]];
+            else av[j] = sv[idx];
         }
         if constexpr (CODED) {
 #pragma unroll
@@ -368,9 +375,13 @@ static int spmv_cg1_impl(const SpmvPlan &plan, int n, long long nnz, const void 
         g.n_local = e->n_local; g.rotate = rotate; g.push_chunks = p2p_push_chunks(*e);
     }
     const bool coded = plan.codes && !plan.codes16 && plan.codes_for == cols && tune().index_codes != 0;
+    const bool vcoded = coded && sizeof(T) <= 8 && plan.vcodes && plan.vcodes_for == vals && tune().value_codes != 0;
     a.codes = coded ? plan.codes : nullptr;
     a.dict = coded ? plan.dict : nullptr;
-    const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
+    a.vcodes = vcoded ? plan.vcodes : nullptr;
+    a.vdict = vcoded ? static_cast<const T *>(plan.vdict) : nullptr;
+    const size_t lds = vcoded ? (((size_t)a.cap * 2 + 15) & ~(size_t)15)
+                              : coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15) : (size_t)a.cap * (sizeof(T) + 4);
     const int grid = rowblock_grid(plan.row_blocks, a.cycle);
     if (p2p && grid < e->n_peers * g.push_chunks) return fail(CGAMD_ERR_STATE, "spmv_cg1: fewer work-groups than push chunks");
     const dim3 gd(grid), block(kBlock);
@@ -384,8 +395,9 @@ static int spmv_cg1_impl(const SpmvPlan &plan, int n, long long nnz, const void 
     } while (0)
 #define CG1_U(UU)                                                                                                      \
     do {                                                                                                                \
-        if (coded) { if (p2p) CG1_L(UU, true, true); else CG1_L(UU, true, false); }                                    \
-        else { if (p2p) CG1_L(UU, false, true); else CG1_L(UU, false, false); }                                        \
+        if (vcoded) { if (p2p) CG1_L(UU, 2, true); else CG1_L(UU, 2, false); }                                         \
+        else if (coded) { if (p2p) CG1_L(UU, 1, true); else CG1_L(UU, 1, false); }                                     \
+        else { if (p2p) CG1_L(UU, 0, true); else CG1_L(UU, 0, false); }                                                \
     } while (0)
     if (fit == 5) CG1_U(5);
     else if (fit == 7) CG1_U(7);
