@@ -253,7 +253,7 @@ def rate_fields(spmv_moved, spmv_csr, spmv_ms, spmv_alone_ms, iter_moved, iter_c
                           "spmv_bytes": spmv_csr, "spmv_gbs": spmv_csr / (spmv_ms * 1e-3) / 1e9,
                           "cg_iter_bytes": iter_csr, "cg_iter_gbs": iter_csr * it_s / 1e9},
         "roofline": {"bound": "hbm",
-                     "kernel": ("spmv_rowblock_vc_kernel" if n_values > 0 else "spmv_rowblock_kernel") + " (CSR SpMV fused with d.q partials"
+                     "kernel": ("spmv_rowblock_vcp_kernel" if n_values > 0 else "spmv_rowblock_kernel") + " (CSR SpMV fused with d.q partials"
                                + (", column indices read as one-byte codes" if n_offsets > 0 else "")
                                + (", values as one-byte codes into the matrix's %d distinct entries: no longer bound by bytes, see DESIGN.md" % n_values if n_values > 0 else "")
                                + "), in-loop average over the instrumented pass (HIP events on each dispatch)",
@@ -315,7 +315,7 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
     spmv_alone_ms = e0.elapsed_time(e1) / args.spmv_reps
     if spmv_ms is None:
         spmv_ms = spmv_alone_ms
-    traffic, traffic_source = pmc_traffic("spmv_rowblock_vc_kernel" if solver.value_codes > 0 else "spmv_rowblock_kernel")
+    traffic, traffic_source = pmc_traffic("spmv_rowblock_vcp_kernel" if solver.value_codes > 0 else "spmv_rowblock_kernel")
     delta0, deltak = abs(hist[0, 0]), abs(hist[-1, 0])
     res = {
         "metric": "CG iterations/sec + SpMV effective HBM GB/s (% of 8 TB/s peak), N=10M CSR",

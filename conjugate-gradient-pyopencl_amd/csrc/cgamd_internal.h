@@ -107,6 +107,7 @@ struct Tuning {
     // ---- development hooks ("dev." keys): tests, rehearsals, profiling
     int dev_no_fold_alpha = 0;      // 1: small systems keep the separate cg_alpha launch (the four-launch family at sizes that would fold it)
     int value_codes = 1;            // one-byte value codes on top of the one-byte column codes where the matrix has at most 256 distinct entries (0 = off: A/B, tests)
+    int dev_vc_pipe = 1;            // value-coded SpMV: gathers pipelined across the row blocks of a work-group (0 = one block at a time: A/B)
     int dev_generic_spmv = 0;       // 1: the generic chunked CSR stream for every matrix (the row-block kernels' fallback, tested against them)
     int resident_lock = 1;          // 0: no per-GPU serialisation of resident launches (ranks of ONE job sharing a GPU in a rehearsal)
     int slab_trim = -1;             // slab loop: 1024-row granules a member that pushes to a peer owns fewer than the others (-1 = 2, 0 = equal members)

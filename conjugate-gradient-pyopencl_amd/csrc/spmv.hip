@@ -354,6 +354,36 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_vc_kernel(SpmvArgs<T> a) 
             kmax = max(kmax, len[h]);
             row8[h] = (unsigned)min(row[h], a.n - 1) * (unsigned)sizeof(T);
         }
+        // waves whose rows all have exactly UNROLL entries (the interior of a stencil: about half the waves of the 7-point Laplacian on
+        // a 250-wide grid) take the walk without a single mask: no compare, no select -- the same multiply-adds in the same order
+        bool full = true;
+#pragma unroll
+        for (int h = 0; h < PR; ++h) full = full && len[h] == UNROLL;
+        if (__builtin_amdgcn_ballot_w64(!full) == 0) {
+            T xv[PR][UNROLL], av[PR][UNROLL];
+            unsigned off[PR][UNROLL];
+#pragma unroll
+            for (int h = 0; h < PR; ++h) {
+                const unsigned char *pc = buf + (size_t)h * 2 * a.cap + s[h], *pv = pc + a.cap;
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j) {
+                    off[h][j] = pc[j];
+                    av[h][j] = sdictv[pv[j]];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < PR; ++h)
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j) off[h][j] = row8[h] + (unsigned)sdict[off[h][j]];
+#pragma unroll
+            for (int h = 0; h < PR; ++h)
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j) xv[h][j] = buf_gather<T>(xrs, off[h][j]);
+#pragma unroll
+            for (int h = 0; h < PR; ++h)
+#pragma unroll
+                for (int j = 0; j < UNROLL; ++j) sum[h] = vfma(av[h][j], xv[h][j], sum[h]);
+        } else
         for (int k = 0; k < kmax; k += UNROLL) {
             T xv[PR][UNROLL], av[PR][UNROLL];
             unsigned off[PR][UNROLL];
@@ -407,6 +437,140 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_vc_kernel(SpmvArgs<T> a) 
                 a.partials[rb0 + i + t] = v;
             }
         }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// The same with the gathers PIPELINED across the row blocks of a work-group (matrices whose longest row fits one batch: max_row <=
+// UNROLL).  PMC of the form above (gpurun pmc_bench_vc): waves spend 71 % of their cycles in s_waitcnt, the VALU is 36 % busy -- the
+// kernel waits for one gather round trip per row block.  Here the gathers of block i + 1 are issued (codes out of LDS, offsets, 7
+// buffer loads) BEFORE block i is multiplied and stored, so two blocks' gathers are in flight per wave and a block's round trip
+// hides behind its predecessor's arithmetic, store and block sum.  vmcnt retires in order: waiting for block i's gathers does not
+// wait for block i + 1's.  The code dwords of block i + 2 travel in registers meanwhile.  LDS buffers alternate; a buffer is only
+// read by issue() and every issue() lies between two barriers that separate it from the writes of the same buffer.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void spmv_rowblock_vcp_kernel(SpmvArgs<T> a) {
+    using A = typename VT<T>::acc;
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];       // [2 buffers][column codes cap | value codes cap]
+    __shared__ A red[BLOCK / kWave];
+    __shared__ int sdict[BLOCK];
+    __shared__ T sdictv[BLOCK];
+    static_assert(BLOCK == 256, "one dictionary entry per thread");
+    const int t = threadIdx.x;
+    sdict[t] = a.dict[t] * (int)sizeof(T);
+    sdictv[t] = a.vdict[t];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(a.x), 0, 0x7ffffffc, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t xrs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(FUSE_DOT ? a.dvec : a.x), 0, 0x7ffffffc, 0x00020000);
+    const int supers = (a.row_blocks + kVcBlocks - 1) / kVcBlocks;
+    const int srb = rowblock_of(blockIdx.x, supers, a.cycle);
+    if (srb < 0) return;
+    const int rb0 = srb * kVcBlocks, nb = min(kVcBlocks, a.row_blocks - rb0);
+
+    struct Bounds { int s_raw, e_raw, p0, p1; };
+    auto bounds_of = [&](int rb) -> Bounds {          // branch-free: clamped rows (a block past the matrix: empty)
+        const int r0 = min(rb, a.row_blocks) * BLOCK, rclamp = min(r0 + t, a.n - 1);
+        Bounds b;
+        b.s_raw = a.ptr[rclamp]; b.e_raw = a.ptr[rclamp + 1];
+        b.p0 = a.ptr[min(r0, a.n)]; b.p1 = a.ptr[min(r0 + BLOCK, a.n)];
+        return b;
+    };
+    struct Codes { unsigned cw[2], vw[2]; };
+    auto load_codes = [&](const Bounds &b) -> Codes {
+        Codes c;
+        const int cfirst = b.p0 & ~3;
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            const long long q = (long long)cfirst + rg * 4 * BLOCK + 4 * t;
+            const long long qq = q < b.p1 ? q : cfirst;
+            const unsigned *cp = reinterpret_cast<const unsigned *>(a.codes + qq), *vp = reinterpret_cast<const unsigned *>(a.vcodes + qq);
+            c.cw[rg] = NT ? __builtin_nontemporal_load(cp) : *cp;
+            c.vw[rg] = NT ? __builtin_nontemporal_load(vp) : *vp;
+        }
+        return c;
+    };
+    auto stage = [&](int i, const Bounds &b, const Codes &c) {
+        unsigned char *scc = reinterpret_cast<unsigned char *>(dyn_smem) + (size_t)(i & 1) * 2 * a.cap, *svc = scc + a.cap;
+        const int cfirst = b.p0 & ~3;
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            const int o = rg * 4 * BLOCK + 4 * t;
+            if (cfirst + o < b.p1) {
+                *reinterpret_cast<unsigned *>(scc + o) = c.cw[rg];
+                *reinterpret_cast<unsigned *>(svc + o) = c.vw[rg];
+            }
+        }
+    };
+    // one block's gathers in flight: the values of x, the matrix values (out of the dictionary) and what the epilogue needs
+    struct Gath { T xv[UNROLL]; unsigned vc[UNROLL]; T dv; int len, row; };      // (vc: the value codes; the dictionary is read when the block is multiplied)
+    auto issue = [&](int i, const Bounds &b) -> Gath {
+        Gath g;
+        const unsigned char *scc = reinterpret_cast<const unsigned char *>(dyn_smem) + (size_t)(i & 1) * 2 * a.cap, *svc = scc + a.cap;
+        const int cfirst = b.p0 & ~3;
+        g.row = (rb0 + i) * BLOCK + t;
+        const bool live = g.row < a.n && i < nb;
+        const int s = b.s_raw - cfirst;
+        g.len = live ? b.e_raw - b.s_raw : 0;
+        const unsigned row8 = (unsigned)min(g.row, a.n - 1) * (unsigned)sizeof(T);
+        unsigned off[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            off[j] = scc[s + j];                     // unclamped: slots past the row's end read the next row's codes (valid LDS) and are masked
+            g.vc[j] = svc[s + j];
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) off[j] = j < g.len ? row8 + (unsigned)sdict[off[j]] : row8;
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) g.xv[j] = buf_gather<T>(xrs, off[j]);
+        if (FUSE_DOT) g.dv = buf_gather<T>(xrs_d, row8);
+        return g;
+    };
+    auto consume = [&](int i, const Gath &g) {
+        T sum = vzero<T>();
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const T nxt = vfma(sdictv[g.vc[j]], g.xv[j], sum);
+            sum = vsel(j < g.len, nxt, sum);
+        }
+        A dot1 = vzero<A>();
+        if (g.row < a.n && i < nb) {
+            a.y[g.row] = sum;
+            if (FUSE_DOT) dot1 = to_acc(vmul(g.dv, sum));
+        }
+        if (FUSE_DOT) {
+            const A tot = block_sum<BLOCK>(dot1, red);
+            if (t == 0 && i < nb) a.partials[rb0 + i] = tot;
+        }
+    };
+    static_assert(kVcBlocks == 4, "the pipeline below is written out for four row blocks");
+    // two blocks' gathers in flight (three were measured slower: 88.8 against 80.9 us)
+    Bounds b0 = bounds_of(rb0), b1 = bounds_of(rb0 + 1);
+    Codes c0 = load_codes(b0);
+    Bounds b2 = bounds_of(rb0 + 2);
+    Codes c1 = load_codes(b1);
+    stage(0, b0, c0);
+    __syncthreads();
+    Gath gA = issue(0, b0);
+    // block 1 staged and gathered, block 0 multiplied
+    Bounds b3 = bounds_of(rb0 + 3);
+    Codes c2 = load_codes(b2);
+    stage(1, b1, c1);
+    __syncthreads();
+    Gath gB = issue(1, b1);
+    consume(0, gA);
+    if (nb > 2) {                                  // (uniform; the last super block of the matrix may hold fewer row blocks)
+        Codes c3 = load_codes(b3);
+        stage(2, b2, c2);
+        __syncthreads();
+        gA = issue(2, b2);
+        consume(1, gB);
+        stage(3, b3, c3);
+        __syncthreads();
+        gB = issue(3, b3);
+        consume(2, gA);
+        consume(3, gB);
+    } else {
+        consume(1, gB);
     }
 }
 
@@ -842,9 +1006,14 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
                 const int supers = (plan.row_blocks + kVcBlocks - 1) / kVcBlocks, cyc = std::max(1, a.cycle / kVcBlocks);
                 a.cycle = cyc;
                 const dim3 gvc(rowblock_grid(supers, cyc));
+                // rows that fit one batch (max_row <= unroll): the form with the gathers pipelined across the row blocks
+                const bool pipe = plan.max_row > 0 && plan.max_row <= unroll && tune().dev_vc_pipe != 0;
 #define CG_VC(NT, UNR)                                                                                                  \
     do {                                                                                                                \
-        if (fuse) CG_LAUNCH_EV((spmv_rowblock_vc_kernel<T, kBlock, NT, true, UNR>), gvc, block, lds2, st, a);            \
+        if (pipe) {                                                                                                     \
+            if (fuse) CG_LAUNCH_EV((spmv_rowblock_vcp_kernel<T, kBlock, NT, true, UNR>), gvc, block, lds2, st, a);       \
+            else CG_LAUNCH_EV((spmv_rowblock_vcp_kernel<T, kBlock, NT, false, UNR>), gvc, block, lds2, st, a);           \
+        } else if (fuse) CG_LAUNCH_EV((spmv_rowblock_vc_kernel<T, kBlock, NT, true, UNR>), gvc, block, lds2, st, a);     \
         else CG_LAUNCH_EV((spmv_rowblock_vc_kernel<T, kBlock, NT, false, UNR>), gvc, block, lds2, st, a);                \
     } while (0)
                 if (unroll == 4) { if (nt) CG_VC(true, 4); else CG_VC(false, 4); }

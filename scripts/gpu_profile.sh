@@ -11,5 +11,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$TAG/$c -- python bench.py --no-cpu-baseline --steps 20 --warmup 5 --spmv-reps 10 > gpurun_out/pmcb_$TAG/$c.log 2>&1
   rc=$?; echo "pmc $c exit $rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
 done
-python scripts/pmc_traffic.py gpurun_out/pmcb_$TAG ${PMC_KERNEL:-spmv_rowblock_vc_kernel} gpurun_out/${TAG}_pmc_traffic.json
+python scripts/pmc_traffic.py gpurun_out/pmcb_$TAG ${PMC_KERNEL:-spmv_rowblock_vcp_kernel} gpurun_out/${TAG}_pmc_traffic.json
 cat gpurun_out/prof_$TAG/*/*_kernel_stats.csv | cut -c1-200
