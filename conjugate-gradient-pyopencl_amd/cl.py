@@ -413,17 +413,16 @@ class Solver:
         iteration that met the tolerance by re-running exactly that many iterations when the check overshot it."""
         if self.n_rhs != 1:
             raise ValueError("pcg handles one right-hand side")
-        if M is None and int(maxit) > 0 and self._lib.cgamd_solver_loop_launches(self.handle) < 2:
-            self.set_preconditioner(None)
-            self.set_rhs(b, x0)             # resident loop: the stop happens on the device (Solver.solve_tol)
-            run_ = ctypes.c_int(0)
-            st = self._lib.cgamd_solver_iterate_tol(self.handle, int(maxit), float(tol), ctypes.byref(run_))
-            if st == 0:
-                return self.x(), int(run_.value) - 1
-            if st != _lib.ERR_STATE:
-                check(st)
         self.set_preconditioner(M)
         try:
+            if int(maxit) > 0 and self._lib.cgamd_solver_loop_launches(self.handle) < 2:
+                self.set_rhs(b, x0)             # resident loop (with a diagonal M: the chip-wide groups): the stop happens on the device
+                run_ = ctypes.c_int(0)
+                st = self._lib.cgamd_solver_iterate_tol(self.handle, int(maxit), float(tol), ctypes.byref(run_))
+                if st == 0:
+                    return self.x(), int(run_.value) - 1
+                if st != _lib.ERR_STATE:
+                    check(st)
             its = self._run_to_tol(b, x0, tol, int(maxit), int(check_every))
             return self.x(), its - 1
         finally:

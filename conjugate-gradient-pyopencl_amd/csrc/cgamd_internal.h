@@ -185,6 +185,9 @@ struct CgScalars {
     // order of the prologue sums over the d.q / r.r partials: 0 = thread-strided; K > 0 = member-blocked (reduce_device.h
     // thread_partials): handles the chip-wide resident loop can take over, K = 256-row (256-pack) blocks of one resident member
     int kdq = 0, krr = 0;
+    // chip-wide resident loop only: the diagonal preconditioner and the rho parity buffer of a handle that runs the PCG recurrence
+    const void *pcg_m = nullptr;
+    void *pcg_rho2 = nullptr;
 };
 // ten-vector-pass iteration (x update deferred into the aypx launch): see kernels.hip
 int launch_axpy_dot(int dtype, int n, const void *q, void *r, long long ld, const void *alpha, int nrhs, void *partials, int grid,
@@ -341,6 +344,7 @@ int launch_pcg_axpy2_dot2(int dtype, bool init, int n, const void *d, void *x, c
                           long long ld, const void *alpha, int nrhs, void *part_rz, void *part_rr, int grid, hipStream_t st);
 int launch_pcg_aypx_beta(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *part_rz,
                          const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, void *xs, hipStream_t st);
+int launch_pcg_p_update(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *beta, int nrhs, hipStream_t st);
 int launch_pcg_delta0(int dtype, const void *part_rz, const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st);
 // four-launch peer-to-peer iteration (see kernels.hip): SpMV with the push and the wait inside, aypx with the beta all-reduce.
 // halo_flag: device int per row block (1 = references a halo column); rotate: first row block of the visiting order

@@ -510,6 +510,8 @@ template <typename T> struct ResWideArgs {
     unsigned *xcnt;                 // [NG][8] arrivals of a group's members per XCD
     unsigned *marks;                // [NG] members whose column marks are in
     unsigned *need;                 // bitmap over the rows: somebody's row references this column from another member's slice
+    const T *mdiag;                 // PCG: the diagonal preconditioner (z = m .* r), helmFE_var.py:546-586
+    T *rho2;                        // PCG: [2][nrhs] rho of the last two iterations (the launched loop's parity buffer)
     long long *prof;                // diagnostics (CGAMD_RESIDENT_PROF=1)
 };
 
@@ -549,7 +551,10 @@ template <typename A, int N> CG_DEV A member_sum(A (&v)[N], A (*wsn)[kResThreads
     return tot;
 }
 
-template <typename T, int RPT, int U>
+// PCG: the Jacobi-preconditioned recurrence of the launched four-launch loop (vector.hip pcg_*): z = m r, rho = r.z instead of
+// delta = r.r in alpha and beta, p = beta p + z; r.r is still summed (history, stopping test).  The caller's d is always "already
+// beta p + z" (the launched loop's convention), so the first iteration of a launch takes it as is.
+template <typename T, int RPT, int U, bool PCG>
 __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideArgs<T> a) {
     using A = typename VT<T>::acc;
     constexpr int E = Pack<T>::N;
@@ -584,7 +589,8 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
     // small groups: every member polls for itself (the extra hop costs more than the pollers: 90k rows, G = 22: 5.9 against 7.1 us)
     const bool xlead = a.G <= 32 || __builtin_amdgcn_readfirstlane(sh.ctl[2]) == 0;
     const bool xpublish = a.G > 32;
-    u64 *xs_rr = a.xres + ((size_t)grp * 16 + (size_t)(__builtin_amdgcn_readfirstlane(sh.ctl[0]) & 7)) * 16, *xs_dq = xs_rr + 8;   // same & 7 as the counter
+    u64 *xs_rr = a.xres + ((size_t)grp * 16 + (size_t)(__builtin_amdgcn_readfirstlane(sh.ctl[0]) & 7)) * 24, *xs_dq = xs_rr + 8;   // same & 7 as the counter
+    [[maybe_unused]] u64 *xs_r2 = xs_rr + 16;        // PCG: the r.r reduction (xs_rr carries rho there)
     // ---- my rows: entries into registers (rows have at most U entries: the host checked)
     const int R0 = m * ROWS;
     constexpr int UP = (U + 1) / 2;
@@ -650,7 +656,8 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         for (int j = 0; j < UP; ++j) mo2[h][j] = (unsigned)mo[h][2 * j] | ((2 * j + 1 < U ? (unsigned)mo[h][2 * j + 1] : 0u) << 16);
     }
     if (t == 0) win[a.wcap - 1] = vzero<T>();
-    u64 *g_dq = a.gran + (size_t)grp * 2 * a.G * W, *g_rr = g_dq + (size_t)a.G * W;
+    u64 *g_dq = a.gran + (size_t)grp * 3 * a.G * W, *g_rr = g_dq + (size_t)a.G * W;      // g_rr: r.r partials; PCG: r.z partials
+    [[maybe_unused]] u64 *g_r2 = g_rr + (size_t)a.G * W;                                    // PCG: r.r partials
     u64 *slot = a.slot_word + grp;
     char *wb = reinterpret_cast<char *>(win);
     const int ht = kResThreads - 1 - t;              // the last waves load the halo (wave 0 does the divisions)
@@ -686,6 +693,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
     T *xr = a.x + voff, *rr = a.r + voff, *d0r = a.d0 + voff, *d1r = a.d1 + voff;
 
     Pack<T> px[PPT], pr[PPT], pd[PPT];
+    [[maybe_unused]] Pack<T> pm[PPT];
     bool pk[PPT], pub[PPT];
     unsigned poff[PPT];
 #pragma unroll
@@ -700,9 +708,11 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             px[j] = ld_pack(at_off(xr, poff[j]));
             pr[j] = ld_pack(at_off(rr, poff[j]));
             pd[j] = ld_pack(at_off((a.it0 & 1) ? d1r : d0r, poff[j]));
+            if constexpr (PCG) pm[j] = ld_pack(at_off(a.mdiag, poff[j]));
         }
     }
-    T dlt = a.delta[rhs];
+    T dlt = a.delta[rhs];                            // PCG: rho = r.z of the state the launch starts from
+    [[maybe_unused]] T rrT = PCG ? a.history[(long long)min(a.it0, a.history_cap - 1) * a.nrhs + rhs] : vzero<T>();      // PCG: r.r of that state
     const unsigned tag0 = seq << 20;
 
     long long stamp = clock64();
@@ -714,6 +724,7 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         const T *dold_p = (it & 1) ? d1r : d0r;
         T *dnew_p = (it & 1) ? d0r : d1r;
         Pack<T> h_da, h_ra, h_db, h_rb;
+        [[maybe_unused]] Pack<T> h_ma, h_mb;
         int h_pa = 0, h_pb = 0;
         bool h_two = false;
         auto halo_prefetch = [&]() {
@@ -724,11 +735,14 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                 h_pb = h_two ? (hq < nlow ? hq : hi0 + (hq - nlow)) : h_pa;
                 h_da = ld_pack_coh(dold_p + w0 + h_pa * E); h_ra = ld_pack_coh(rr + w0 + h_pa * E);
                 h_db = ld_pack_coh(dold_p + w0 + h_pb * E); h_rb = ld_pack_coh(rr + w0 + h_pb * E);
+                if constexpr (PCG) { h_ma = ld_pack(a.mdiag + w0 + h_pa * E); h_mb = ld_pack(a.mdiag + w0 + h_pb * E); }
             }
         };
         T bt = vzero<T>();
-        const bool as_is = k == 0 && a.d_ready;      // uniform
-        if (it > 0 && k == 0) {                      // beta of a continued run from the stored scalars
+        const bool as_is = k == 0 && (PCG || a.d_ready);      // uniform
+        if (PCG && k == 0) {                         // the caller's d is the direction: no beta
+            halo_prefetch();
+        } else if (it > 0 && k == 0) {               // beta of a continued run from the stored scalars
             bt = from_acc<T>(acc_div(to_acc(dlt), to_acc(a.history[(long long)(it - 1) * a.nrhs + rhs])));
             halo_prefetch();
         } else if (it > 0) {
@@ -739,15 +753,23 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                                        b = from_acc<T>(acc_div(to_acc(dn), to_acc(dlt)));
                                    }, xlead, xpublish, xs_rr, tag0 + 2 * k, true, halo_prefetch)) return;
             dlt = dnT;
+            if constexpr (PCG) {                     // ... and r.r of the same update: what the history records and the stopping test reads
+                T r2, r2_unused;
+                __syncthreads();                     // (the shared words of the reduction above are read by everybody first)
+                if (!xcd_scalars<A, T>(a.G, sh, a.hdr, r2, r2_unused, [&](int i, A &v) { return get_granule(g_r2 + (size_t)i * W, tag0 + 2 * k, v); },
+                                       [&](A tot, T &o, T &u) { o = from_acc<T>(tot); u = o; }, xlead, xpublish, xs_r2, tag0 + 2 * k)) return;
+                rrT = r2;
+            }
             if (leader && t == 0) {
                 a.beta[rhs] = bt;
                 a.delta[rhs] = dnT;
-                if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = dnT;
+                if constexpr (PCG) a.rho2[(long long)(it & 1) * a.nrhs + rhs] = dnT;
+                if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = PCG ? rrT : dnT;
             }
         } else {
             halo_prefetch();
         }
-        if (a.tol > 0. && it > 0 && !(res_norm(dlt) >= a.tol)) {     // (the reference tests after an iteration: never before the first)      // uniform: every member holds the same delta
+        if (a.tol > 0. && it > 0 && !(res_norm(PCG ? rrT : dlt) >= a.tol)) {     // (the reference tests after an iteration: never before the first)      // uniform: every member holds the same delta
             it_end = it;
             stopped = true;
             break;
@@ -758,7 +780,10 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         for (int j = 0; j < PPT; ++j)
             if (pk[j]) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) pd[j].v[e] = as_is ? pd[j].v[e] : vaypx(bt, pd[j].v[e], pr[j].v[e]);
+                for (int e = 0; e < E; ++e) {
+                    if constexpr (PCG) pd[j].v[e] = as_is ? pd[j].v[e] : vadd(vmul(bt, pd[j].v[e]), vmul(pm[j].v[e], pr[j].v[e]));      // p = beta p + m r (pcg_aypx_beta_kernel)
+                    else pd[j].v[e] = as_is ? pd[j].v[e] : vaypx(bt, pd[j].v[e], pr[j].v[e]);
+                }
                 if (pub[j]) st_pack_coh<false>(at_off(dnew_p, poff[j]), pd[j]);
                 *reinterpret_cast<Pack<T> *>(wb + (size_t)(R0 - w0) * sizeof(T) + (size_t)(t + j * kResThreads) * 16) = pd[j];
             }
@@ -766,8 +791,13 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             Pack<T> oa, ob;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                oa.v[e] = as_is ? h_da.v[e] : vaypx(bt, h_da.v[e], h_ra.v[e]);
-                ob.v[e] = as_is ? h_db.v[e] : vaypx(bt, h_db.v[e], h_rb.v[e]);
+                if constexpr (PCG) {
+                    oa.v[e] = as_is ? h_da.v[e] : vadd(vmul(bt, h_da.v[e]), vmul(h_ma.v[e], h_ra.v[e]));
+                    ob.v[e] = as_is ? h_db.v[e] : vadd(vmul(bt, h_db.v[e]), vmul(h_mb.v[e], h_rb.v[e]));
+                } else {
+                    oa.v[e] = as_is ? h_da.v[e] : vaypx(bt, h_da.v[e], h_ra.v[e]);
+                    ob.v[e] = as_is ? h_db.v[e] : vaypx(bt, h_db.v[e], h_rb.v[e]);
+                }
             }
             *reinterpret_cast<Pack<T> *>(wb + (size_t)h_pa * 16) = oa;
             if (h_two) *reinterpret_cast<Pack<T> *>(wb + (size_t)h_pb * 16) = ob;
@@ -778,11 +808,18 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
             const int pa = hp < nlow ? hp : hi0 + (hp - nlow), pb = two ? (hq < nlow ? hq : hi0 + (hq - nlow)) : pa;
             const Pack<T> da_ = ld_pack_coh(dold_p + w0 + pa * E), ra_ = ld_pack_coh(rr + w0 + pa * E);
             const Pack<T> db_ = ld_pack_coh(dold_p + w0 + pb * E), rb_ = ld_pack_coh(rr + w0 + pb * E);
+            [[maybe_unused]] Pack<T> ma_, mb_;
+            if constexpr (PCG) { ma_ = ld_pack(a.mdiag + w0 + pa * E); mb_ = ld_pack(a.mdiag + w0 + pb * E); }
             Pack<T> oa, ob;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                oa.v[e] = as_is ? da_.v[e] : vaypx(bt, da_.v[e], ra_.v[e]);
-                ob.v[e] = as_is ? db_.v[e] : vaypx(bt, db_.v[e], rb_.v[e]);
+                if constexpr (PCG) {
+                    oa.v[e] = as_is ? da_.v[e] : vadd(vmul(bt, da_.v[e]), vmul(ma_.v[e], ra_.v[e]));
+                    ob.v[e] = as_is ? db_.v[e] : vadd(vmul(bt, db_.v[e]), vmul(mb_.v[e], rb_.v[e]));
+                } else {
+                    oa.v[e] = as_is ? da_.v[e] : vaypx(bt, da_.v[e], ra_.v[e]);
+                    ob.v[e] = as_is ? db_.v[e] : vaypx(bt, db_.v[e], rb_.v[e]);
+                }
             }
             *reinterpret_cast<Pack<T> *>(wb + (size_t)pa * 16) = oa;
             if (two) *reinterpret_cast<Pack<T> *>(wb + (size_t)pb * 16) = ob;
@@ -816,23 +853,37 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
         RES_STAMP(5)
         if (leader && t == 0) a.alpha[rhs] = al;
         A accv[PPT];                                 // r.r per pack = per thread of the launched vector kernel (one pack per thread)
+        [[maybe_unused]] A accz[PPT];                // PCG: r.z per pack (pcg_axpy2_dot2_kernel: z = m r, r.z and r.r element by element)
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             accv[j] = vzero<A>();
+            if constexpr (PCG) accz[j] = vzero<A>();
             if (pk[j]) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const T qv = qs[(t + j * kResThreads) * E + e];
                     px[j].v[e] = vadd(px[j].v[e], vmul(al, pd[j].v[e]));
                     pr[j].v[e] = vsub(pr[j].v[e], vmul(al, qv));
+                    if constexpr (PCG) {
+                        const T z = vmul(pm[j].v[e], pr[j].v[e]);
+                        accz[j] = vadd(accz[j], to_acc(vmul(pr[j].v[e], z)));
+                    }
                     accv[j] = vadd(accv[j], to_acc(vmul(pr[j].v[e], pr[j].v[e])));
                 }
                 if (pub[j]) st_pack_coh<false>(at_off(rr, poff[j]), pr[j]);
             }
         }
         RES_STAMP(6)
-        tot = member_sum<A, PPT>(accv, wsn);
-        if (t == 0) put_granule<false>(g_rr + (size_t)m * W, tag0 + 2 * k + 2, tot);
+        if constexpr (PCG) {
+            tot = member_sum<A, PPT>(accz, wsn);
+            if (t == 0) put_granule<false>(g_rr + (size_t)m * W, tag0 + 2 * k + 2, tot);
+            __syncthreads();                         // wsn is rewritten
+            tot = member_sum<A, PPT>(accv, wsn);
+            if (t == 0) put_granule<false>(g_r2 + (size_t)m * W, tag0 + 2 * k + 2, tot);
+        } else {
+            tot = member_sum<A, PPT>(accv, wsn);
+            if (t == 0) put_granule<false>(g_rr + (size_t)m * W, tag0 + 2 * k + 2, tot);
+        }
         RES_STAMP(7)
     }
 #pragma unroll
@@ -857,11 +908,18 @@ __global__ __launch_bounds__(kResThreads) void cg_resident_wide_kernel(ResWideAr
                                      dn = from_acc<T>(tot);
                                      b = from_acc<T>(acc_div(to_acc(dn), to_acc(dlt)));
                                  })) return;
+        [[maybe_unused]] T r2fin = vzero<T>(), r2_unused;
+        if constexpr (PCG) {
+            __syncthreads();
+            if (!group_scalars<A, T>(a.G, sh, a.hdr, r2fin, r2_unused, [&](int i, A &v) { return get_granule(g_r2 + (size_t)i * W, tag0 + 2 * a.K, v); },
+                                     [&](A tot, T &o, T &u) { o = from_acc<T>(tot); u = o; })) return;
+        }
         if (t == 0) {
             const int it = a.it0 + a.K;
             a.beta[rhs] = bfin;
             a.delta[rhs] = dnT;
-            if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = dnT;
+            if constexpr (PCG) a.rho2[(long long)(it & 1) * a.nrhs + rhs] = dnT;
+            if (it < a.history_cap) a.history[(long long)it * a.nrhs + rhs] = PCG ? r2fin : dnT;
             if (rhs == 0) *a.iter = it;
             atomicAdd(a.hdr + kHdrSolved, 1u);
         }
@@ -1110,9 +1168,9 @@ int run_cg_resident(int dtype, const ResidentPlan &rp, int n, int nrhs, const vo
 
 
 // ---- wide resident loop: host side ---------------------------------------------------------------------------------------
-template <typename T, int RPT, int U>
-static int resident_wide_launch(const ResWideArgs<T> &a, size_t lds, int grid, hipStream_t st) {
-    auto kern = cg_resident_wide_kernel<T, RPT, U>;
+template <typename T, int RPT, int U, bool PCG>
+static int resident_wide_launch_p(const ResWideArgs<T> &a, size_t lds, int grid, hipStream_t st) {
+    auto kern = cg_resident_wide_kernel<T, RPT, U, PCG>;
     if (lds > 64 * 1024) {
         const size_t want = std::min<size_t>((lds + 8191) & ~(size_t)8191, 152 * 1024);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
@@ -1122,6 +1180,10 @@ static int resident_wide_launch(const ResWideArgs<T> &a, size_t lds, int grid, h
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CGAMD_ERR_HIP, std::string("wide resident loop launch: ") + hipGetErrorString(e));
     return CGAMD_OK;
+}
+template <typename T, int RPT, int U>
+static int resident_wide_launch(const ResWideArgs<T> &a, size_t lds, int grid, hipStream_t st) {
+    return a.mdiag ? resident_wide_launch_p<T, RPT, U, true>(a, lds, grid, st) : resident_wide_launch_p<T, RPT, U, false>(a, lds, grid, st);
 }
 
 // Does the wide loop apply?  Rows of at most 8 entries, a right-hand side on G <= n_cus work-groups of 2048 / 4096 rows (1024:
@@ -1140,7 +1202,10 @@ int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, con
     ResidentWidePlan best;
     int best_rounds = 1 << 30;
     for (int rpt : {2, 4, 8}) {
-        if (rpt % E || (rpt == 2) != (dtype == 3)) continue;       // complex128 (16-byte values): two rows per thread, the others 4 or 8
+        // complex128 (16-byte values): two rows per thread, the others 4 or 8; complex64 also 2 for systems of up to 65536 rows (its
+        // 4-row instances spill: 34 registers in the 7-entry one, 151 with the preconditioner)
+        if (rpt % E) continue;
+        if (dtype == 3 ? rpt != 2 : (rpt == 2 && !(dtype == 2 && n <= 65536))) continue;
         if (forced > 0 && dtype != 3 && rpt != forced) continue;
         const int rows = kResThreads * rpt, G = (n + rows - 1) / rows;
         if (G > std::min(n_cus, 256)) continue;
@@ -1169,9 +1234,9 @@ int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, con
         best.wcap = (h[0] + 3 + 4) & ~3;
         best.lds_bytes = ((size_t)rows + best.wcap) * dtype_size(dtype);
         const size_t W = acc_size(dtype) / 4;
-        // header | slot words [NG] | granules [NG][2][G W] | XCD results [NG][16][2][8] | XCD arrival counters [NG][8]
+        // header | slot words [NG] | granules [NG][3][G W] | XCD results [NG][16][3][8] | XCD arrival counters [NG][8]
         //   | marks [NG] | bitmap of published rows [n / 32]
-        best.sync_bytes = (((size_t)kHdrWords * 4 + (size_t)NG * (8 + 2 * (size_t)G * W * 8 + 16 * 16 * 8 + 8 * 4) + (size_t)((NG + 3) & ~3) * 4 +
+        best.sync_bytes = (((size_t)kHdrWords * 4 + (size_t)NG * (8 + 3 * (size_t)G * W * 8 + 16 * 24 * 8 + 8 * 4) + (size_t)((NG + 3) & ~3) * 4 +
                             ((size_t)n / 32 + 2) * 4) + 15) & ~(size_t)15;
         best.ok = true;
         best_rounds = rounds;
@@ -1185,6 +1250,7 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, int nrhs, const
                               void *d0, void *d1, bool d_ready, const CgScalars &sc, int it0, int K, void *sync, int grid, hipStream_t st, double tol) {
     using A = typename VT<T>::acc;
     ResWideArgs<T> a;
+    a.mdiag = static_cast<const T *>(sc.pcg_m); a.rho2 = static_cast<T *>(sc.pcg_rho2);      // set: the Jacobi-preconditioned recurrence
     a.n = n; a.nrhs = nrhs; a.G = wp.G; a.NG = wp.NG; a.npack = n / Pack<T>::N; a.it0 = it0; a.K = K; a.history_cap = sc.history_cap;
     a.wcap = wp.wcap;
     a.d_ready = d_ready ? 1 : 0;
@@ -1196,8 +1262,8 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, int nrhs, const
     a.hdr = static_cast<unsigned *>(sync);
     a.slot_word = reinterpret_cast<u64 *>(static_cast<char *>(sync) + kHdrWords * 4);
     a.gran = a.slot_word + wp.NG;
-    a.xres = a.gran + (size_t)wp.NG * 2 * (size_t)wp.G * (sizeof(A) / 4);
-    a.xcnt = reinterpret_cast<unsigned *>(a.xres + (size_t)wp.NG * 16 * 16);
+    a.xres = a.gran + (size_t)wp.NG * 3 * (size_t)wp.G * (sizeof(A) / 4);
+    a.xcnt = reinterpret_cast<unsigned *>(a.xres + (size_t)wp.NG * 16 * 24);
     a.marks = a.xcnt + (size_t)wp.NG * 8;
     a.need = a.marks + ((wp.NG + 3) & ~3);
     if (getenv("CGAMD_RESIDENT_PROF") && !g_prof_dev) CG_HIP(hipMalloc(&g_prof_dev, 64));
@@ -1211,6 +1277,14 @@ static int resident_wide_impl(const ResidentWidePlan &wp, int n, int nrhs, const
         return resident_wide_launch<T, 2, 10>(a, wp.lds_bytes, grid, st);
     } else if (wp.rpt == 8) {
         return resident_wide_launch<T, 8, 5>(a, wp.lds_bytes, grid, st);
+    } else if (wp.rpt == 2) {
+        if constexpr (sizeof(T) == 8 && Pack<T>::N == 2 && !std::is_same<T, double>::value) {      // complex64
+            if (wp.unroll == 5) return resident_wide_launch<T, 2, 5>(a, wp.lds_bytes, grid, st);
+            if (wp.unroll == 7) return resident_wide_launch<T, 2, 7>(a, wp.lds_bytes, grid, st);
+            if (wp.unroll == 8) return resident_wide_launch<T, 2, 8>(a, wp.lds_bytes, grid, st);
+            return resident_wide_launch<T, 2, 10>(a, wp.lds_bytes, grid, st);
+        }
+        return fail(CGAMD_ERR_INVALID, "wide resident loop: no two-row instance for this type");
     } else {
         if (wp.unroll == 5) return resident_wide_launch<T, 4, 5>(a, wp.lds_bytes, grid, st);
         if (wp.unroll == 7) return resident_wide_launch<T, 4, 7>(a, wp.lds_bytes, grid, st);

@@ -183,7 +183,9 @@ static int enqueue_iteration(cgamd_solver *s, int k, hipStream_t st) {
 // resident one.  Called whenever the wide plan may have changed; captured graphs hold grids and orders, so they go when it did.
 static void apply_wide_order(cgamd_solver *s) {
     const int E = (int)(16 / dtype_size(s->dtype));
-    const bool wide = s->resw.ok && !s->res_ok;      // (where the one-XCD resident loop applies it runs, with the strided order)
+    // (where the one-XCD resident loop applies it runs, with the strided order -- unless a preconditioner is set: that recurrence only
+    // has the chip-wide form)
+    const bool wide = s->resw.ok && (!s->res_ok || s->mdiag != nullptr);
     const int kdq = wide ? kResWideBlocksPerRpt * s->resw.rpt : 0, krr = wide ? kdq / E : 0;
     const int vgrid = wide ? (s->n / E + kBlock - 1) / kBlock : vec_grid(s->n, s->dtype, s->nrhs);
     const int fold_max = 0;      // (alpha folded beyond 2048 partials was tried for these handles: every work-group summing 3907 partials, 1M rows 30 -> 52 us)
@@ -262,7 +264,7 @@ static int setup_resident_local(cgamd_solver *s) {
     s->res_ok = false;
     s->resw.ok = false;
     if (int rc = setup_resident_one_xcd(s)) return rc;
-    if (s->res_ok) return CGAMD_OK;
+    // (also where the one-XCD loop applies: it has no preconditioned form, the chip-wide groups do)
     return setup_resident_wide_plan(s);
 }
 static int setup_resident_one_xcd(cgamd_solver *s) {
@@ -581,6 +583,7 @@ int cgamd_solver_set_preconditioner(cgamd_solver *s, const void *m, int on_devic
     s->rhs_set = false;
     if (!m) {
         if (s->mdiag) { (void)hipFree(s->mdiag); s->mdiag = nullptr; }
+        apply_wide_order(s);
         return CGAMD_OK;
     }
     const size_t vs = dtype_size(s->dtype);
@@ -592,6 +595,7 @@ int cgamd_solver_set_preconditioner(cgamd_solver *s, const void *m, int on_devic
     if (s->n != s->n_user) CG_HIP(hipMemsetAsync(s->mdiag, 0, (size_t)s->n * vs, s->ctx->stream));
     CG_HIP(hipMemcpyAsync(s->mdiag, m, (size_t)s->n_user * vs, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->ctx->stream));
     CG_HIP(hipStreamSynchronize(s->ctx->stream));
+    apply_wide_order(s);
     return CGAMD_OK;
 }
 
@@ -606,7 +610,7 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
     int left = nIterations, k = s->iters;
     const bool use_graph = !(s->flags & CGAMD_NO_GRAPH) && !s->graph_failed;
     const bool two = fused2_now(s);
-    if (s->resw.ok && !(two && s->res_ok) && !s->rm && !s->mdiag && !(s->flags & (CGAMD_NO_GRAPH | CGAMD_UNFUSED)) &&
+    if (s->resw.ok && !(two && s->res_ok) && !s->rm && !(s->flags & (CGAMD_NO_GRAPH | CGAMD_UNFUSED)) &&
         (nIterations >= std::max(1, tune().resident_wide_min) || s->tol_req > 0.)) {
         // one chip-wide resident group (single right-hand side, matrix rows in registers).  d ping-pongs inside the launch; handles
         // of the launched loops that keep d in one buffer get it back there, and the launched loops' r.r partials are rebuilt.
@@ -620,8 +624,10 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
             bool untouched = false;
             int stop = -1;
             s->tol_served = s->tol_req > 0.;
+            CgScalars scw = s->sc;           // the Jacobi-preconditioned recurrence runs in the same loop (rho for delta, z = m r)
+            if (s->mdiag) { scw.pcg_m = s->mdiag; scw.pcg_rho2 = s->rho2; }
             if (int rc = run_cg_resident_wide(s->dtype, s->resw, s->n, s->nrhs, s->vals, s->ptr, s->cols, s->x, s->r, d0, d1,
-                                              keeps_new_d && s->iters > 0, s->sc, s->iters, K, s->resw_sync, s->n_cus, st, &untouched, s->tol_req,
+                                              keeps_new_d && s->iters > 0, scw, s->iters, K, s->resw_sync, s->n_cus, st, &untouched, s->tol_req,
                                               &stop)) {
                 if (!untouched) {            // x / r / d / delta may be partly advanced: the handle demands a fresh set_rhs
                     s->rhs_set = false;
@@ -641,7 +647,9 @@ int cgamd_solver_iterate(cgamd_solver *s, int nIterations) {
             if (done > 0) {                  // (a stop before the first iteration leaves d as the caller had it)
                 if (fin != dbuf(s, s->iters))
                     CG_HIP(hipMemcpyAsync(dbuf(s, s->iters), fin, (size_t)s->n * s->nrhs * dtype_size(s->dtype), hipMemcpyDeviceToDevice, st));
-                if (keeps_new_d)             // d = beta d + r with the beta the launch recorded last (clcg.c:415)
+                if (s->mdiag) {              // p = beta p + m r (helmFE_var.py:583-585)
+                    if (int rc = launch_pcg_p_update(s->dtype, s->n, s->r, dbuf(s, s->iters), s->mdiag, s->n, s->sc.beta, s->nrhs, st)) return rc;
+                } else if (keeps_new_d)      // d = beta d + r with the beta the launch recorded last (clcg.c:415)
                     if (int rc = launch_aypx(s->dtype, s->n, s->r, dbuf(s, s->iters), s->n, s->sc.beta, s->nrhs, st)) return rc;
             }
         }
@@ -714,7 +722,7 @@ int cgamd_solver_iterate_tol(cgamd_solver *s, int maxIterations, double tol, int
     if (s->nrhs != 1) return fail(CGAMD_ERR_STATE, "iterate_tol: one right-hand side");
     {
         TuneScope ts(&s->tune);
-        const bool local = fused2_now(s) && s->res_ok, wide = s->resw.ok && !s->rm && !s->mdiag;
+        const bool local = fused2_now(s) && s->res_ok, wide = s->resw.ok && !s->rm && !(s->res_ok && !s->mdiag);
         if ((!local && !wide) || (s->flags & (CGAMD_NO_GRAPH | CGAMD_UNFUSED)))
             return fail(CGAMD_ERR_STATE, "iterate_tol: this handle runs a launched loop (check the history from the host)");
     }
@@ -852,7 +860,7 @@ int cgamd_solver_loop_launches(cgamd_solver *s) {
     TuneScope ts(&s->tune);
     if (s->flags & CGAMD_UNFUSED) return 8;
     if (s->rm) return 5;
-    if (s->mdiag) return 4;
+    if (s->mdiag) return (s->resw.ok && !s->rm && !(s->flags & (CGAMD_NO_GRAPH | CGAMD_UNFUSED))) ? 1 : 4;
     if (fused2_now(s) && s->res_ok && !(s->flags & CGAMD_NO_GRAPH)) return 0;
     if (s->resw.ok && !(s->flags & CGAMD_NO_GRAPH)) return 1;       // chip-wide resident group (not bit-identical to the launched loops)
     if (fused2_now(s)) return 2;

@@ -414,7 +414,7 @@ template <typename T, int BLOCK, bool VEC>
 __global__ __launch_bounds__(BLOCK) void pcg_aypx_beta_kernel(int n, const T *__restrict__ rv, T *__restrict__ pv,
                                                               const T *__restrict__ m, long long ld,
                                                               const typename VT<T>::acc *__restrict__ part_rz,
-                                                              const typename VT<T>::acc *__restrict__ part_rr, int P, int nrhs,
+                                                              const typename VT<T>::acc *__restrict__ part_rr, int P, int K, int nrhs,
                                                               T *delta, T *beta, T *history, int history_cap, T *rho2, const int *iter,
                                                               T *__restrict__ xs, const T *__restrict__ alpha) {
     using A = typename VT<T>::acc;
@@ -422,14 +422,11 @@ __global__ __launch_bounds__(BLOCK) void pcg_aypx_beta_kernel(int n, const T *__
     __shared__ T beta_s;
     const int r = blockIdx.y;
     {
-        A acc = vzero<A>();
-        const A *pz = part_rz + (long long)r * P;
-        for (int i = threadIdx.x; i < P; i += BLOCK) acc = vadd(acc, pz[i]);
+        const A acc = thread_partials<BLOCK>(part_rz + (long long)r * P, P, K);
         const A rho = block_sum<BLOCK>(acc, red);
         A acc2 = vzero<A>();
         if (blockIdx.x == 0) {
-            const A *pr = part_rr + (long long)r * P;
-            for (int i = threadIdx.x; i < P; i += BLOCK) acc2 = vadd(acc2, pr[i]);
+            acc2 = thread_partials<BLOCK>(part_rr + (long long)r * P, P, K);
             acc2 = block_sum<BLOCK>(acc2, red);
         }
         if (threadIdx.x == 0) {
@@ -846,8 +843,8 @@ static int pcg_aypx_impl(int n, const void *r, void *p, const void *m, long long
                          int P, int nrhs, const CgScalars &sc, void *rho2, void *xs, bool vec, hipStream_t st) {
     dim3 g(vec_grid(n, VT<T>::dtype, nrhs), nrhs), blk(kBlock);
     using A = typename VT<T>::acc;
-    if (vec) hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
-    else hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
+    if (vec) hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, true>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, sc.krr, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
+    else hipLaunchKernelGGL((pcg_aypx_beta_kernel<T, kBlock, false>), g, blk, 0, st, n, (const T *)r, (T *)p, (const T *)m, ld, (const A *)part_rz, (const A *)part_rr, P, sc.krr, nrhs, (T *)sc.delta, (T *)sc.beta, (T *)sc.history, sc.history_cap, (T *)rho2, (const int *)sc.iter, (T *)xs, (const T *)sc.alpha);
     return check_launch("pcg_aypx_beta");
 }
 int launch_pcg_aypx_beta(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *part_rz,
@@ -861,6 +858,26 @@ static int pcg_delta0_impl(const void *part_rz, const void *part_rr, int P, int 
     hipLaunchKernelGGL((pcg_delta0_kernel<T>), dim3(nrhs), dim3(kScalarBlock), 0, st, (const A *)part_rz, (const A *)part_rr, P, nrhs,
                        (T *)sc.delta, (T *)sc.history, (T *)rho2, sc.iter);
     return check_launch("pcg_delta0");
+}
+// p = beta p + m r on its own: what the chip-wide resident PCG loop leaves to the host at the end of a call (it returns the direction
+// of the last iteration; the launched loop keeps the NEXT one) -- the very expression of pcg_aypx_beta_kernel
+template <typename T>
+__global__ __launch_bounds__(256) void pcg_p_update_kernel(long long n, const T *__restrict__ rv, T *__restrict__ pv, const T *__restrict__ m,
+                                                           long long ld, const T *__restrict__ beta) {
+    const int r = blockIdx.y;
+    const T bt = beta[r];
+    rv += (long long)r * ld; pv += (long long)r * ld;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        pv[i] = vadd(vmul(bt, pv[i]), vmul(m[i], rv[i]));
+}
+template <typename T> static int pcg_p_update_impl(int n, const void *r, void *p, const void *m, long long ld, const void *beta, int nrhs, hipStream_t st) {
+    const int g = (int)std::min<long long>(((long long)n + 255) / 256, 2048);
+    hipLaunchKernelGGL((pcg_p_update_kernel<T>), dim3(g, nrhs), dim3(256), 0, st, (long long)n, (const T *)r, (T *)p, (const T *)m, ld, (const T *)beta);
+    return check_launch("pcg_p_update");
+}
+int launch_pcg_p_update(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *beta, int nrhs, hipStream_t st) {
+    if (n <= 0) return CGAMD_OK;
+    CG_DISPATCH(dtype, pcg_p_update_impl, n, r, p, m, ld, beta, nrhs, st);
 }
 int launch_pcg_delta0(int dtype, const void *part_rz, const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st) {
     CG_DISPATCH(dtype, pcg_delta0_impl, part_rz, part_rr, P, nrhs, sc, rho2, st);

@@ -241,3 +241,66 @@ def test_wide_resident_loop_with_several_right_hand_sides(pkg, gpu, dtype, kind,
         sl = slice(r * n, (r + 1) * n)
         ex = np.linalg.norm(w["x"][sl] - l["x"][sl]) / np.linalg.norm(l["x"][sl])
         assert ex < (1e-10 if f64 else 5e-3), (r, ex)
+
+
+@pytest.mark.parametrize("dtype,kind,nrhs", [
+    (np.complex64, "helm128", 1),                # the reference's sub-domain system with its Jacobi preconditioner (helmFE_var.PCG)
+    (np.complex128, "helm128", 1),
+    (np.float64, "poisson300", 1),
+    (np.float64, "poisson300", 3),               # one group per right-hand side, the same M
+    (np.complex64, "helm500", 1),                # config 3's size
+])
+def test_resident_jacobi_pcg_is_the_launched_pcg_bit_for_bit(pkg, gpu, dtype, kind, nrhs):
+    """Jacobi-preconditioned CG (reference helmFE_var.py:546-586, M = 1 / diag) in the chip-wide resident loop: rho = r.z in alpha and
+    beta, p = beta p + m r, r.r recorded.  Same x and history as the four-launch PCG loop of the same handle, however the solve is
+    cut into calls (30 | 15 + 15 | 16 + 14 | launched only), the oracle restatement (bit-identical to the reference's PCG on CPU) to
+    1e-10 in fp64, and the tolerance stop on the device returns the reference's (x, i)."""
+    ctx, queue, kernels = gpu
+    lib = pkg._lib.load()
+    if kind.startswith("helm"):
+        N = int(kind[4:])
+        ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+    else:
+        ip, ix, da = cg_numpy.poisson2d(int(kind[7:]))
+        da = da.copy()
+        da[ix == np.repeat(np.arange(len(ip) - 1), np.diff(ip))] += np.linspace(0.5, 4.0, len(ip) - 1)      # a diagonal worth preconditioning
+    n = len(ip) - 1
+    import scipy.sparse as sp
+    m = 1.0 / sp.csr_matrix((da, ix, ip), shape=(n, n)).diagonal()
+    wide_t = np.complex128 if np.dtype(dtype).kind == "c" else np.float64
+    rng = np.random.default_rng(n + nrhs)
+    B = np.concatenate([(1.0 + r + rand_vec(rng, n, wide_t)) for r in range(nrhs)])
+
+    def run(calls, wide_min=16):
+        pkg._lib.check(lib.cgamd_tune(b"resident_wide_min", wide_min))
+        try:
+            s = pkg.Solver(ctx, n, len(ix), da.astype(dtype), ip, ix, nrhs)
+            s.set_preconditioner(m.astype(dtype))
+            s.set_rhs(B.astype(dtype), None)
+            kind_ = lib.cgamd_solver_loop_launches(s.handle)
+            for c in calls:
+                s.iterate(c)
+            out = (s.x(), s.history(), kind_)
+            s.close()
+            return out
+        finally:
+            pkg._lib.check(lib.cgamd_tune(b"resident_wide_min", 16))
+
+    whole = run([30])
+    assert whole[2] == 1
+    for calls, wm in (([15, 15], 16), ([16, 14], 16), ([14, 16], 16), ([30], 1 << 20)):
+        other = run(calls, wm)
+        assert np.array_equal(whole[1], other[1]), (calls, wm, "history")
+        assert np.array_equal(whole[0], other[0]), (calls, wm, "x")
+    wide64 = np.dtype(dtype) in (np.dtype(np.float64), np.dtype(np.complex128))
+    for r in range(nrhs):
+        xo, _, ho = cg_numpy.pcg_diag(ip, ix, da, B[r * n:(r + 1) * n], m, tol=0.0, maxit=30, history=True)
+        keep = np.abs(ho) / np.abs(ho[0]) > (1e-8 if wide64 else 1e-3)
+        assert np.max(np.abs(whole[1][keep, r] - ho[keep]) / np.abs(ho[keep])) < (1e-10 if wide64 else 2e-3), r
+    if nrhs == 1 and wide64:
+        # the stopping test on the device: the reference's (x, i)
+        s = pkg.Solver(ctx, n, len(ix), da.astype(dtype), ip, ix, 1)
+        x, i = s.pcg(B.astype(dtype), M=m.astype(dtype), tol=1e-3, maxit=400)
+        s.close()
+        xo, io, _ = cg_numpy.pcg_diag(ip, ix, da, B, m, tol=1e-3, maxit=400, history=True)
+        assert i == io and np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-9
