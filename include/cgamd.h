@@ -157,7 +157,9 @@ int cgamd_solver_ld(cgamd_solver *s);
 /* Diagonal (Jacobi) preconditioning -- the reference's PCG(A, b, M) with a diagonal CSR M, z = M.dot(r)
  * (helmFE_var.py:546-586).  m: `size` values of the solver's type (1/diag(A) for Jacobi), host or
  * device; NULL removes it.  Takes effect at the next cgamd_solver_set_rhs; history keeps holding r.r (the stopping
- * test of the reference, helmFE_var.py:580-584), the recurrence uses rho = r.z. */
+ * test of the reference, helmFE_var.py:580-584), the recurrence uses rho = r.z.  Handles the chip-wide resident loop can take over
+ * (cgamd_solver_loop_launches() == 1 once the preconditioner is set) run the recurrence inside that loop, with the bits of the
+ * four-launch PCG loop of the same handle; cgamd_solver_iterate_tol then stops it on the device. */
 int cgamd_solver_set_preconditioner(cgamd_solver *s, const void *m, int on_device);
 /* convenience: set_rhs + iterate + get_x (+ history if non-NULL, (nIterations+1)*nRHS values), host arrays */
 int cgamd_solver_solve(cgamd_solver *s, const void *b, void *x, int nIterations, void *history);
@@ -173,8 +175,9 @@ int cgamd_solver_spmm_rowmajor(cgamd_solver *s, const void *x, void *y, int nRHS
  * last cgamd_solver_set_rhs) */
 int cgamd_solver_layout(cgamd_solver *s);
 /* launches per iteration of the loop cgamd_solver_iterate runs for this handle: 0 = the resident loop (small systems: every
- * iteration of a call of at least `resident_min` iterations inside ONE launch, csrc/resident.hip), 1 = its chip-wide form for a
- * single right-hand side (one launch per call as well; partial sums per work-group, so not bit-identical to the others), 2 / 3 / 4 / 5 = the
+ * iteration of a call of at least `resident_min` iterations inside ONE launch, csrc/resident.hip), 1 = its chip-wide form
+ * (one launch per call of at least `resident_wide_min` iterations as well; shorter calls take the launched loops of the same handle,
+ * which return the same bits), 2 / 3 / 4 / 5 = the
  * loops of DESIGN.md section 4, 8 = the reference's op structure (CGAMD_UNFUSED); negative: error */
 int cgamd_solver_loop_launches(cgamd_solver *s);
 /* > 0: this handle's single-RHS SpMV reads one-byte column codes instead of aCols (4 -> 1 byte of index traffic per non-zero),
