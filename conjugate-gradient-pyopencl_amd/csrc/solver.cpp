@@ -264,7 +264,9 @@ static int setup_resident_local(cgamd_solver *s) {
     s->res_ok = false;
     s->resw.ok = false;
     if (int rc = setup_resident_one_xcd(s)) return rc;
-    // (also where the one-XCD loop applies: it has no preconditioned form, the chip-wide groups do)
+    // where the one-XCD loop applies the chip-wide plan is only needed once a preconditioner is set (that recurrence has no one-XCD
+    // form): cgamd_solver_set_preconditioner asks for it then -- the stateless cg() entry reloads per call and would pay the scan
+    if (s->res_ok && !s->mdiag) return CGAMD_OK;
     return setup_resident_wide_plan(s);
 }
 static int setup_resident_one_xcd(cgamd_solver *s) {
@@ -595,6 +597,8 @@ int cgamd_solver_set_preconditioner(cgamd_solver *s, const void *m, int on_devic
     if (s->n != s->n_user) CG_HIP(hipMemsetAsync(s->mdiag, 0, (size_t)s->n * vs, s->ctx->stream));
     CG_HIP(hipMemcpyAsync(s->mdiag, m, (size_t)s->n_user * vs, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->ctx->stream));
     CG_HIP(hipStreamSynchronize(s->ctx->stream));
+    if (!s->resw.ok)
+        if (int rc2 = setup_resident_wide_plan(s)) return rc2;      // (skipped at creation where the one-XCD loop runs the plain recurrence)
     apply_wide_order(s);
     return CGAMD_OK;
 }
