@@ -1037,9 +1037,6 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
         a.cycle = tune().spmv_cycle > 0 ? tune().spmv_cycle : 1;
         const bool coded_any = plan.codes && plan.codes_for == cols && tune().index_codes != 0;
         const bool coded = coded_any && !plan.codes16, coded16 = coded_any && plan.codes16;
-        // ... and one-byte value codes on top (matrices of at most 256 distinct entries; complex128 has none)
-        // (its staging covers slices of at most 8 x 256 entries: rows of 8 entries on average)
-        const bool vcoded = coded && !rb_list && plan.vcodes && plan.vcodes_for == vals && tune().value_codes != 0 && a.cap <= 8 * kBlock && (unsigned long long)n * sizeof(T) < (1ULL << 30);
         a.codes = coded_any ? plan.codes : nullptr;
         a.dict = coded_any ? plan.dict : nullptr;
         const size_t lds = coded ? (((size_t)a.cap * (sizeof(T) + 1) + 15) & ~(size_t)15)
