@@ -529,13 +529,46 @@ template <typename A, int C, int N2> struct BlockChain {       // tot = (((0 + b
     static CG_DEV A run(A tot, A b) { return BlockChain<A, C + 1, N2>::run(vadd(tot, lane_of<C>(b)), b); }
 };
 template <typename A, int N2> struct BlockChain<A, N2, N2> { static CG_DEV A run(A tot, A) { return tot; } };
+CG_DEV double acc_component(double v, int) { return v; }
+CG_DEV double acc_component(double2 v, int c) { return c ? v.y : v.x; }
 template <typename A, int N> CG_DEV A member_sum(A (&v)[N], A (*wsn)[kResThreads / kWave]) {
     static_assert(kResThreads == 512 && kResThreads / 256 == kResWideBlocksPerRpt, "two 256-thread blocks per value");
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    // the N (complex: 2 N) wave sums four at a time (device_types.h wave_sum4: the same tree per value, a third of the adds)
+    constexpr int C = (int)(sizeof(A) / sizeof(double)), ND = N * C;
+    double *wd = reinterpret_cast<double *>(&wsn[0][0]);              // value i, wave w, component c at ((i * 8 + w) * C + c)
+    // value i, component c = element i * C + c (no pointer cast: reading a double2 array through a double pointer is what the
+    // compiler may, and did, treat as unrelated storage)
+    double vd[ND];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        v[i] = wave_sum(v[i]);
-        if (lane == 0) wsn[i][wave] = v[i];
+        if constexpr (C == 1) vd[i] = acc_component(v[i], 0);
+        else { vd[2 * i] = acc_component(v[i], 0); vd[2 * i + 1] = acc_component(v[i], 1); }
+    }
+    auto put = [&](int k, double g) {                                  // k: index into vd
+        wd[((k / C) * (kResThreads / kWave) + wave) * C + (k % C)] = g;
+    };
+    // (real accumulators only: with complex ones the complex64 two-row instance returned wrong, run-to-run different sums on the
+    // banded test system -- scripts/dev/wide_c64_diag.py -- although the primitives check out, scripts/microbench/wave_sum4_probe.hip;
+    // not understood, so complex types keep the one-value-at-a-time tree)
+    if constexpr (ND % 4 == 0 && C == 1) {
+#pragma unroll
+        for (int k = 0; k < ND; k += 4) {
+            const double g = wave_sum4(vd[k], vd[k + 1], vd[k + 2], vd[k + 3]);
+            if ((lane & 15) == 0) put(k + (lane == 0 ? 0 : lane == 16 ? 2 : lane == 32 ? 1 : 3), g);
+        }
+    } else if constexpr (ND % 2 == 0 && C == 1) {
+#pragma unroll
+        for (int k = 0; k < ND; k += 2) {
+            const double g = wave_sum2(vd[k], vd[k + 1]);
+            if ((lane & 31) == 0) put(k + (lane >> 5), g);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            v[i] = wave_sum(v[i]);
+            if (lane == 0) wsn[i][wave] = v[i];
+        }
     }
     drain_stores();
     __syncthreads();
