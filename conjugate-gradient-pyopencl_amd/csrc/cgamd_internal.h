@@ -1,4 +1,4 @@
-// Host-side internal interfaces between the kernel launchers (kernels.hip), the solver
+// Host-side internal interfaces between the kernel launchers (spmv.hip, vector.hip, p2p.hip, cg1.hip, index_codes.hip, rowmajor.hip, resident.hip, slab.hip), the solver
 // (solver.cpp), the C ABI (api.cpp) and the multi-GPU loop (dist.cpp).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -143,7 +143,7 @@ namespace cgamd {
 void tune_set(const std::function<void(Tuning &)> &edit);
 // the calling thread's next row-block SpMV launch records pair[0] / pair[1] on the dispatch itself (kernel duration)
 void set_kernel_event_pair(hipEvent_t *pair);
-void thread_hip_setup();      // once per thread: stream-capture interaction mode "relaxed" (see kernels.hip)
+void thread_hip_setup();      // once per thread: stream-capture interaction mode "relaxed" (see vector.hip)
 struct TuneScope {
     const Tuning *prev;
     explicit TuneScope(const Tuning *t);
@@ -189,7 +189,7 @@ struct CgScalars {
     const void *pcg_m = nullptr;
     void *pcg_rho2 = nullptr;
 };
-// ten-vector-pass iteration (x update deferred into the aypx launch): see kernels.hip
+// ten-vector-pass iteration (x update deferred into the aypx launch): see vector.hip
 int launch_axpy_dot(int dtype, int n, const void *q, void *r, long long ld, const void *alpha, int nrhs, void *partials, int grid,
                     hipStream_t st, int vec_nt = 3);
 int launch_axpy_dot_alpha(int dtype, int n, const void *q, void *r, long long ld, const void *part_dq, int P, const CgScalars &sc,
@@ -198,7 +198,7 @@ int launch_aypx_beta_x(int dtype, int n, const void *x, void *y, void *xs, long 
                        const CgScalars &sc, hipStream_t st, int vec_nt = 3);
 // small systems: alpha = delta / sum(part_dq) in the prologue (three-launch iteration); fold_alpha_ok says when
 bool fold_alpha_ok(int n_partials, int fold_max = 0);      // fold_max 0 = the default limit (2048 partials)
-// two-launch iteration (kernels.hip "Two-launch iteration"): the SpMV launch computes beta and d_new = beta d_old + r on the
+// two-launch iteration (spmv.hip "Two-launch iteration"): the SpMV launch computes beta and d_new = beta d_old + r on the
 // fly; d_old / d_new are different buffers.  fused2_ok: the plan's row-block kernels apply and the system is small enough
 bool fused2_ok(const SpmvPlan &plan, int dtype, int nrhs, const void *vals, const int *cols);
 int launch_spmv_fused(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
@@ -325,7 +325,7 @@ int run_cg_slab(int dtype, const SlabPlan &sp, int n, long long nnz, const void 
 // [rows][cols] -> [cols][rows]: RHS-major (the reference ABI) <-> row-major
 int launch_transpose(int dtype, int rows, int cols, const void *in, void *out, hipStream_t st);
 
-// ---- peer-to-peer backend (kernels.hip "Peer-to-peer communication over xGMI") ----------------------------
+// ---- peer-to-peer backend (p2p.hip "Peer-to-peer communication over xGMI") ----------------------------
 constexpr size_t kMailboxHeader = 16384;  // slots + flags + error word + single-reduction slots; halo entries follow
 struct P2pExchange {
     char *const *mailbox = nullptr;   // device array [nranks] of mapped mailbox bases
@@ -339,14 +339,14 @@ struct P2pExchange {
     const void *my_halo = nullptr;    // halo area of MY mailbox (entry h = column n_local + h)
 };
 int p2p_push_chunks(const P2pExchange &e);
-// diagonally preconditioned CG (helmFE_var.py:546-586 with a diagonal M): see kernels.hip
+// diagonally preconditioned CG (helmFE_var.py:546-586 with a diagonal M): see vector.hip
 int launch_pcg_axpy2_dot2(int dtype, bool init, int n, const void *d, void *x, const void *q, void *r, const void *m,
                           long long ld, const void *alpha, int nrhs, void *part_rz, void *part_rr, int grid, hipStream_t st);
 int launch_pcg_aypx_beta(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *part_rz,
                          const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, void *xs, hipStream_t st);
 int launch_pcg_p_update(int dtype, int n, const void *r, void *p, const void *m, long long ld, const void *beta, int nrhs, hipStream_t st);
 int launch_pcg_delta0(int dtype, const void *part_rz, const void *part_rr, int P, int nrhs, const CgScalars &sc, void *rho2, hipStream_t st);
-// four-launch peer-to-peer iteration (see kernels.hip): SpMV with the push and the wait inside, aypx with the beta all-reduce.
+// four-launch peer-to-peer iteration (see p2p.hip): SpMV with the push and the wait inside, aypx with the beta all-reduce.
 // halo_flag: device int per row block (1 = references a halo column); rotate: first row block of the visiting order
 int launch_spmv_p2p(int dtype, const SpmvPlan &plan, int n, long long nnz, const void *vals, const int *ptr, const int *cols,
                     const void *d_ext, void *q, void *partials, const int *halo_flag, int rotate, const P2pExchange &e,

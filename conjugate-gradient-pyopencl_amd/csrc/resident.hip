@@ -6,7 +6,7 @@
 // right-hand side for the whole solve:
 //   * member m (512 threads, two rows each) keeps rows [1024 m, 1024 m + 1024) of the matrix in LDS for the whole launch
 //     and its 16-byte packs of x, r and d in registers;
-//   * the recurrence is the two-launch loop's (kernels.hip, spmv_fused_kernel / axpy2_dot_alpha_kernel): beta and
+//   * the recurrence is the two-launch loop's (spmv.hip spmv_fused_kernel / vector.hip axpy2_dot_alpha_kernel): beta and
 //     d = beta d + r are recomputed for every gathered column, d ping-pongs between two buffers; only r and d are
 //     exchanged through memory (write + gather), q stays in LDS;
 //   * the two scalar reductions of an iteration are "granule" all-gathers: every partial sum is published as 8-byte

@@ -866,7 +866,7 @@ int cgamd_solver_loop_launches(cgamd_solver *s) {
     if (s->rm) return 5;
     if (s->mdiag) return (s->resw.ok && !s->rm && !(s->flags & (CGAMD_NO_GRAPH | CGAMD_UNFUSED))) ? 1 : 4;
     if (fused2_now(s) && s->res_ok && !(s->flags & CGAMD_NO_GRAPH)) return 0;
-    if (s->resw.ok && !(s->flags & CGAMD_NO_GRAPH)) return 1;       // chip-wide resident group (not bit-identical to the launched loops)
+    if (s->resw.ok && !(s->flags & CGAMD_NO_GRAPH)) return 1;       // chip-wide resident group (same bits as the launched loops of this handle)
     if (fused2_now(s)) return 2;
     return fold_alpha_ok(s->plan.n_partials, s->plan.fold_max) ? 3 : 4;
 }

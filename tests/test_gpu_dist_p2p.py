@@ -1,6 +1,6 @@
 """GPU tests of the row-partitioned C loop with MORE THAN ONE RANK on the one-GPU test box.  RCCL refuses two
 ranks on one device, the peer-to-peer backend does not care: the ranks are separate processes that share
-cuda:0, exchange halos and reduce scalars through each other's IPC mailboxes (csrc/kernels.hip "Peer-to-peer
+cuda:0, exchange halos and reduce scalars through each other's IPC mailboxes (csrc/p2p.hip "Peer-to-peer
 communication").  Same plan, same loop, same kernels as the RCCL path; results against the serial oracle."""
 import importlib
 import os

@@ -1,4 +1,4 @@
-"""GPU tests of the two-launch iteration for small systems (kernels.hip "Two-launch iteration"): the SpMV launch computes
+"""GPU tests of the two-launch iteration for small systems (spmv.hip "Two-launch iteration"): the SpMV launch computes
 beta and d = beta d + r on the fly (reference aypx, clcg.c:415, moved to the head of the next iteration), the second launch
 alpha, x += alpha d, r -= alpha q and the r.r partials (clcg.c:317-374).  It must reproduce the three- and four-launch loops
 BIT FOR BIT (same operations per element in the same order; the only change is where they run), for every value type,
