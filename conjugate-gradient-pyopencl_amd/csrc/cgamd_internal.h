@@ -143,7 +143,7 @@ namespace cgamd {
 void tune_set(const std::function<void(Tuning &)> &edit);
 // the calling thread's next row-block SpMV launch records pair[0] / pair[1] on the dispatch itself (kernel duration)
 void set_kernel_event_pair(hipEvent_t *pair);
-void thread_hip_setup();      // once per thread: stream-capture interaction mode "relaxed" (see vector.hip)
+void thread_hip_setup();      // once per thread: stream-capture interaction mode "relaxed" (see tune.cpp)
 struct TuneScope {
     const Tuning *prev;
     explicit TuneScope(const Tuning *t);

@@ -110,8 +110,17 @@ template <int N> CG_DEV double dpp_row_shl(double v) {
     const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(b >> 32), 0x100 + N, 0xf, 0xf, true);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// v_permlane32_swap / v_permlane16_swap are cross-lane operations whose lane enables come from EXEC.  Every reduction starts with five
+// wait states tied to its first operand (the asm's output feeds the swap, so nothing is scheduled between them): a guard against an
+// EXEC write or a 64-bit VALU result landing directly in front of the swap, which the compiler spaces for DPP but which I could not
+// confirm for these instructions (suspected, not proven, while chasing the complex64 failure noted at resident.hip member_sum).
+CG_DEV unsigned exec_settle(unsigned w) {
+    asm volatile("s_nop 4" : "+v"(w));
+    return w;
+}
 CG_DEV double lanes_plus32(double v) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long b0 = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long b = ((b0 >> 32) << 32) | exec_settle((unsigned)b0);
     const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
     const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
     return __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
@@ -144,7 +153,8 @@ CG_DEV double2 wave_sum(double2 v) {
 // instead of 48.  Results: wave_sum4 -> {v0, v2, v1, v3} in the first lane of rows 0..3 (lanes 0, 16, 32, 48) of the returned
 // register.  Operand pairs are the tree's (an add may see them in the other order: IEEE addition is commutative).
 CG_DEV double pair32(double a, double b) {          // lower half: a[l] + a[l + 32]; upper half: b[l - 32] + b[l]
-    const unsigned long long ba = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+    const unsigned long long ba0 = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+    const unsigned long long ba = ((ba0 >> 32) << 32) | exec_settle((unsigned)ba0);
     const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ba, (unsigned)bb, false, false);
     const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
     const double a2 = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));

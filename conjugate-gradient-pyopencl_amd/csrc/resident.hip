@@ -1235,10 +1235,13 @@ int resident_wide_plan(int dtype, int n, long long nnz, int nrhs, int n_cus, con
     ResidentWidePlan best;
     int best_rounds = 1 << 30;
     for (int rpt : {2, 4, 8}) {
-        // complex128 (16-byte values): two rows per thread, the others 4 or 8; complex64 also 2 for systems of up to 65536 rows (its
-        // 4-row instances spill: 34 registers in the 7-entry one, 151 with the preconditioner)
+        // complex128 (16-byte values): two rows per thread, the others 4 or 8; complex64 also 2 for systems of up to 32768 rows (its
+        // 4-row instances spill: 34 registers in the 7-entry one, 151 with the preconditioner).  NOT beyond: with more than 32 members
+        // the complex64 two-row instance returned wrong, run-to-run different results in some builds (any matrix; scripts/dev/
+        // wide_c64_diag.py) -- a race I could not find; every other instance, and this one up to 32 members, is bit-stable across
+        // builds and runs (tests/test_gpu_resident_wide.py)
         if (rpt % E) continue;
-        if (dtype == 3 ? rpt != 2 : (rpt == 2 && !(dtype == 2 && n <= 65536))) continue;
+        if (dtype == 3 ? rpt != 2 : (rpt == 2 && !(dtype == 2 && n <= 32768))) continue;
         if (forced > 0 && dtype != 3 && rpt != forced) continue;
         const int rows = kResThreads * rpt, G = (n + rows - 1) / rows;
         if (G > std::min(n_cus, 256)) continue;

@@ -11,7 +11,17 @@ lib = pkg._lib.load()
 ctx = pkg.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 DT = {"c64": np.complex64, "c128": np.complex128, "f64": np.float64, "f32": np.float32}[sys.argv[2] if len(sys.argv) > 2 else "c64"]
-ip, ix, da = _banded_spd(n, 3, 0.8, 50)
+kind = sys.argv[3] if len(sys.argv) > 3 else "band"
+if kind == "helm":
+    import cg_numpy
+    N = int(round(n ** 0.5)); n = N * N
+    ip, ix, da = cg_numpy.helm_fe_var(N, 12.0, np.ones((N - 1, N - 1)), 0.15, N, N)
+elif kind == "poisson":
+    import cg_numpy
+    N = int(round(n ** 0.5)); n = N * N
+    ip, ix, da = cg_numpy.poisson2d(N)
+else:
+    ip, ix, da = _banded_spd(n, 3, 0.8, 50)
 rng = np.random.default_rng(n)
 b = (1.0 + rand_vec(rng, n, np.complex128 if np.dtype(DT).kind == 'c' else np.float64)).astype(DT)
 A = da.astype(DT)
