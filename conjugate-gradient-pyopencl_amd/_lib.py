@@ -93,6 +93,7 @@ def load():
         "cgamd_solver_loop_launches": (ci, [vp]),
         "cgamd_solver_index_codes": (ci, [vp]),
         "cgamd_solver_value_codes": (ci, [vp]),
+        "cgamd_solver_joint_codes": (ci, [vp]),
         "cgamd_solver_iterate_tol": (ci, [vp, ci, ctypes.c_double, ctypes.POINTER(ci)]),
         "cgamd_transpose": (ci, [vp, ci, ci, ci, vp, vp]),
         "cgamd_solver_spmv_bytes": (ll, [vp]),

@@ -330,6 +330,11 @@ class Solver:
         """distinct matrix entries behind the one-byte value codes of the SpMV (0 = the kernel reads aValues)"""
         return self._lib.cgamd_solver_value_codes(self.handle)
 
+    @property
+    def joint_codes(self):
+        """distinct (offset, value) pairs when the SpMV reads one joint code byte per non-zero, else 0"""
+        return self._lib.cgamd_solver_joint_codes(self.handle)
+
     def iter_bytes(self, fused=False):
         return self._lib.cgamd_solver_iter_bytes(self.handle, int(fused))
 

@@ -59,6 +59,7 @@ int cgamd_tune(const char *key, int value) {
     else if (k == "dev.generic_spmv") g_tune.dev_generic_spmv = value;
     else if (k == "dev.value_codes") g_tune.value_codes = value;
     else if (k == "dev.vc_pipe") g_tune.dev_vc_pipe = value;
+    else if (k == "dev.joint_codes") g_tune.dev_joint_codes = value;
     else if (k == "dev.resident_lock") g_tune.resident_lock = value;
     else if (k == "dev.slab_cus") g_tune.slab_cus = value;
     else if (k == "dev.slab_trim") g_tune.slab_trim = value;

@@ -55,6 +55,10 @@ struct SpmvPlan {
     const unsigned char *vcodes = nullptr;  // [nnz + pad]
     const void *vdict = nullptr;            // [256] values
     const void *vcodes_for = nullptr;       // the aValues array the codes were made from
+    // one-byte JOINT codes (build_joint_codes): (aCols[j] - row, aValues[j]) == (jdict_off[jcodes[j]], jdict_val[jcodes[j]])
+    const unsigned char *jcodes = nullptr;  // [nnz + pad]
+    const int *jdict_off = nullptr;         // [256] offsets
+    const void *jdict_val = nullptr;        // [256] values
 };
 SpmvPlan make_spmv_plan(int n);
 // fills plan->max_span / chunk_span from the matrix structure; synchronises `st`; scratch_dev: >= 32 bytes
@@ -72,6 +76,8 @@ int build_index_codes(int n, long long nnz, const int *ptr_dev, const int *cols_
                       int **dict_out, int *distinct_out);
 // 16-bit columns relative to the first column of every 256-row block, for matrices with more offsets than the dictionary holds
 // whose row blocks span fewer than 65 536 columns: *codes_out 2 nnz + 64 bytes, *base_out one int per row block; null when not codable
+int build_joint_codes(int dtype, long long nnz, const unsigned char *codes, const unsigned char *vcodes, const int *dict, const void *vdict,
+                      hipStream_t st, unsigned char **jcodes_out, int **joff_out, void **jval_out, int *n_pairs);
 int build_value_codes(int dtype, long long nnz, const void *vals_dev, hipStream_t st, unsigned char **vcodes_out, void **vdict_out, int *n_values);
 int build_index_codes16(int n, long long nnz, const int *ptr_dev, const int *cols_dev, hipStream_t st, unsigned char **codes_out, int **base_out);
 void finalize_spmv_plan(SpmvPlan *plan, int dtype, int nrhs, int n, long long nnz, const void *vals, const int *cols);
@@ -107,6 +113,7 @@ struct Tuning {
     // ---- development hooks ("dev." keys): tests, rehearsals, profiling
     int dev_no_fold_alpha = 0;      // 1: small systems keep the separate cg_alpha launch (the four-launch family at sizes that would fold it)
     int value_codes = 1;            // one-byte value codes on top of the one-byte column codes where the matrix has at most 256 distinct entries (0 = off: A/B, tests)
+    int dev_joint_codes = 1;        // value-coded SpMV: one byte per non-zero naming the (offset, value) pair where at most 256 pairs occur (0 = two bytes: A/B)
     int dev_vc_pipe = 1;            // value-coded SpMV: gathers pipelined across the row blocks of a work-group (0 = one block at a time: A/B)
     int dev_generic_spmv = 0;       // 1: the generic chunked CSR stream for every matrix (the row-block kernels' fallback, tested against them)
     int resident_lock = 1;          // 0: no per-GPU serialisation of resident launches (ranks of ONE job sharing a GPU in a rehearsal)

@@ -317,4 +317,101 @@ int build_value_codes(int dtype, long long nnz, const void *vals_dev, hipStream_
     return build_value_codes_impl<float2>(nnz, vals_dev, st, vcodes_out, vdict_out, n_values);
 }
 
+// -------------------------------------------------------------------------------------------------
+// JOINT codes: where a matrix has both one-byte column codes and one-byte value codes and at most 256 distinct (offset, value)
+// PAIRS (a constant-coefficient stencil has as many pairs as offsets: 7), one byte per non-zero names the pair: jdict_off[code] /
+// jdict_val[code].  The SpMV then streams 1 byte per non-zero and does one look-up per entry instead of two.  Built from the two
+// code arrays: mark the pairs that occur (65 536 possible), number them in order, encode.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_mark_kernel(long long nnz, const unsigned char *__restrict__ codes, const unsigned char *__restrict__ vcodes,
+                                                        unsigned char *present) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < nnz; j += stride) {
+        const unsigned k = ((unsigned)codes[j] << 8) | vcodes[j];
+        if (!present[k]) present[k] = 1;            // (racing writers store the same byte)
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void pair_number_kernel(const unsigned char *present, const int *__restrict__ dict, const T *__restrict__ vdict,
+                                                           unsigned short *pair_code, int *joff, T *jval, int *count) {
+    __shared__ int wsum[16];
+    const int t = threadIdx.x;
+    int mine = 0;
+    for (int k = 0; k < 64; ++k) mine += present[t * 64 + k] != 0;
+    int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if ((t & 63) >= off) incl += o; }
+    if ((t & 63) == 63) wsum[t >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += wsum[w];
+    int code = base + incl - mine;
+    for (int k = 0; k < 64; ++k) {
+        const int p = t * 64 + k;
+        if (present[p]) {
+            pair_code[p] = (unsigned short)code;
+            if (code < 256) { joff[code] = dict[p >> 8]; jval[code] = vdict[p & 255]; }
+            ++code;
+        }
+    }
+    if (t == 1023) *count = code;
+}
+__global__ __launch_bounds__(256) void pair_encode_kernel(long long nnz, const unsigned char *__restrict__ codes, const unsigned char *__restrict__ vcodes,
+                                                          const unsigned short *__restrict__ pair_code, unsigned char *__restrict__ jcodes) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < nnz; j += stride)
+        jcodes[j] = (unsigned char)pair_code[((unsigned)codes[j] << 8) | vcodes[j]];
+}
+template <typename T>
+static int build_joint_codes_impl(long long nnz, const unsigned char *codes, const unsigned char *vcodes, const int *dict, const void *vdict,
+                                  hipStream_t st, unsigned char **jcodes_out, int **joff_out, void **jval_out, int *n_pairs) {
+    char *scratch = nullptr;
+    CG_HIP(hipMalloc((void **)&scratch, 65536 + 65536 * 2 + 16));
+    unsigned char *present = reinterpret_cast<unsigned char *>(scratch);
+    unsigned short *pair_code = reinterpret_cast<unsigned short *>(scratch + 65536);
+    int *count = reinterpret_cast<int *>(scratch + 65536 * 3);
+    unsigned char *jcodes = nullptr;
+    int *joff = nullptr;
+    void *jval = nullptr;
+    int h = 0;
+    hipError_t e = hipMemsetAsync(scratch, 0, 65536 * 3 + 16, st);
+    if (e == hipSuccess) e = hipMalloc((void **)&joff, 256 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&jval, 256 * sizeof(T));
+    if (e == hipSuccess) e = hipMemsetAsync(joff, 0, 256 * sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(jval, 0, 256 * sizeof(T), st);
+    const int grid = (int)std::min<long long>((nnz + 255) / 256, 4096);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pair_mark_kernel, dim3(grid), dim3(256), 0, st, nnz, codes, vcodes, present);
+        hipLaunchKernelGGL((pair_number_kernel<T>), dim3(1), dim3(1024), 0, st, present, dict, static_cast<const T *>(vdict), pair_code, joff, static_cast<T *>(jval), count);
+        e = hipMemcpyAsync(&h, count, sizeof(int), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && h >= 1 && h <= 256) {
+        e = hipMalloc((void **)&jcodes, (size_t)nnz + 64);
+        if (e == hipSuccess) e = hipMemsetAsync(jcodes + (size_t)nnz, 0, 64, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(pair_encode_kernel, dim3(grid), dim3(256), 0, st, nnz, codes, vcodes, pair_code, jcodes);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(scratch);
+    if (e != hipSuccess || !jcodes) {
+        if (jcodes) (void)hipFree(jcodes);
+        if (joff) (void)hipFree(joff);
+        if (jval) (void)hipFree(jval);
+        return e == hipSuccess ? CGAMD_OK : fail(CGAMD_ERR_HIP, std::string("build_joint_codes: ") + hipGetErrorString(e));
+    }
+    *jcodes_out = jcodes; *joff_out = joff; *jval_out = jval; *n_pairs = h;
+    return CGAMD_OK;
+}
+// all three outputs null when the matrix has more than 256 distinct (offset, value) pairs.  Synchronises `st`.
+int build_joint_codes(int dtype, long long nnz, const unsigned char *codes, const unsigned char *vcodes, const int *dict, const void *vdict,
+                      hipStream_t st, unsigned char **jcodes_out, int **joff_out, void **jval_out, int *n_pairs) {
+    *jcodes_out = nullptr; *joff_out = nullptr; *jval_out = nullptr; *n_pairs = 0;
+    if (nnz <= 0 || !codes || !vcodes || dtype == CGAMD_C128) return CGAMD_OK;
+    if (dtype == CGAMD_F32) return build_joint_codes_impl<float>(nnz, codes, vcodes, dict, vdict, st, jcodes_out, joff_out, jval_out, n_pairs);
+    if (dtype == CGAMD_F64) return build_joint_codes_impl<double>(nnz, codes, vcodes, dict, vdict, st, jcodes_out, joff_out, jval_out, n_pairs);
+    return build_joint_codes_impl<float2>(nnz, codes, vcodes, dict, vdict, st, jcodes_out, joff_out, jval_out, n_pairs);
+}
+
 }  // namespace cgamd

@@ -74,6 +74,10 @@ struct cgamd_solver {
     unsigned char *vcodes = nullptr;  // one-byte value codes on top of the one-byte column codes (build_value_codes), with their dictionary
     void *vdict = nullptr;
     int n_values = 0;                 // distinct matrix entries behind the value codes; 0 = the SpMV reads aValues
+    unsigned char *jcodes = nullptr;  // one-byte joint (offset, value) codes where at most 256 pairs occur (build_joint_codes)
+    int *jdict_off = nullptr;
+    void *jdict_val = nullptr;
+    int n_pairs = 0;
     // cgamd_solver_iterate_tol: tolerance of the device-side stop for the call in progress (0 = none), and what it reported
     double tol_req = 0.;
     bool tol_served = false, tol_stopped = false;
@@ -228,6 +232,11 @@ static int setup_index_codes(cgamd_solver *s) {
     if (s->vdict) { (void)hipFree(s->vdict); s->vdict = nullptr; }
     s->plan.vcodes = nullptr; s->plan.vdict = nullptr; s->plan.vcodes_for = nullptr;
     s->n_values = 0;
+    if (s->jcodes) { (void)hipFree(s->jcodes); s->jcodes = nullptr; }
+    if (s->jdict_off) { (void)hipFree(s->jdict_off); s->jdict_off = nullptr; }
+    if (s->jdict_val) { (void)hipFree(s->jdict_val); s->jdict_val = nullptr; }
+    s->plan.jcodes = nullptr; s->plan.jdict_off = nullptr; s->plan.jdict_val = nullptr;
+    s->n_pairs = 0;
     const size_t matrix_bytes = (size_t)s->nnz * (dtype_size(s->dtype) + 4);
     // a handle whose iterations run in the chip-wide resident loop (matrix in registers) would pay the two coding passes at every
     // create / reload (the stateless cg() reloads per call) for the few launched SpMVs around it
@@ -242,6 +251,11 @@ static int setup_index_codes(cgamd_solver *s) {
         if (s->tune.value_codes && s->plan.kind == 5) {
             if (int rc = build_value_codes(s->dtype, s->nnz, s->vals, s->ctx->stream, &s->vcodes, &s->vdict, &s->n_values)) return rc;
             if (s->vcodes) { s->plan.vcodes = s->vcodes; s->plan.vdict = s->vdict; s->plan.vcodes_for = s->vals; }
+            if (s->vcodes && s->tune.dev_joint_codes) {
+                if (int rc = build_joint_codes(s->dtype, s->nnz, s->codes, s->vcodes, s->dict, s->vdict, s->ctx->stream, &s->jcodes, &s->jdict_off,
+                                               &s->jdict_val, &s->n_pairs)) return rc;
+                if (s->jcodes) { s->plan.jcodes = s->jcodes; s->plan.jdict_off = s->jdict_off; s->plan.jdict_val = s->jdict_val; }
+            }
         }
         return CGAMD_OK;
     }
@@ -505,7 +519,7 @@ int cgamd_solver_destroy(cgamd_solver *s) {
         if (s->cols) (void)hipFree(s->cols);
     }
     void *bufs[] = {s->slab, s->part_dq, s->part_rr, s->sc.alpha, s->sc.beta, s->sc.delta,
-                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync, s->resw_sync, s->codes, s->dict, s->rm_pace, s->vcodes, s->vdict};
+                    s->sc.history, s->sc.iter, s->mdiag, s->part_rz, s->rho2, s->sc.stage, s->sc.ticket, s->res_sync, s->resw_sync, s->codes, s->dict, s->rm_pace, s->vcodes, s->vdict, s->jcodes, s->jdict_off, s->jdict_val};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;
@@ -889,18 +903,24 @@ long long cgamd_solver_iter_bytes(cgamd_solver *s, int fused) {
 // passes of the launched loop the handle runs (10 with the deferred x update, 11 without, 12 preconditioned, 14 for the
 // reference's op structure).  Handles whose iterate() runs a resident loop report the launched loop they fall back to.
 static long long index_bytes_per_nnz(const cgamd_solver *s) { return s->plan.codes ? (s->plan.codes16 ? 2 : 1) : 4; }
+// the single-RHS SpMV of this handle runs on joint codes (launch condition of spmv_impl: rows that fit one batch of the walk)
+static bool joint_form(const cgamd_solver *s) {
+    const int fit = s->plan.max_row <= 0 ? 8 : s->plan.max_row <= 4 ? 4 : s->plan.max_row == 5 ? 5 : s->plan.max_row <= 7 ? 7 : 8;
+    return s->plan.jcodes && s->nrhs == 1 && s->plan.max_row > 0 && s->plan.max_row <= fit && dtype_size(s->dtype) <= 8;
+}
 long long cgamd_solver_spmv_moved_bytes(cgamd_solver *s) {
     if (!s) return 0;
     const long long V = (long long)dtype_size(s->dtype);
-    const long long value_bytes = s->plan.vcodes ? 1 : V;      // value codes: one byte per entry instead of the value
+    const long long value_bytes = joint_form(s) ? 0 : s->plan.vcodes ? 1 : V;      // value codes: one byte per entry instead of the value; joint codes: one byte for both
     return s->nnz * (value_bytes + index_bytes_per_nnz(s)) + ((long long)s->n_user + 1) * 4 + 2LL * s->n_user * V * s->nrhs;
 }
 int cgamd_solver_value_codes(cgamd_solver *s) { return s ? s->n_values : -CGAMD_ERR_INVALID; }
+int cgamd_solver_joint_codes(cgamd_solver *s) { return s ? (joint_form(s) ? s->n_pairs : 0) : -CGAMD_ERR_INVALID; }
 long long cgamd_solver_iter_moved_bytes(cgamd_solver *s) {
     if (!s) return 0;
     const long long V = (long long)dtype_size(s->dtype);
     const long long passes = (s->flags & CGAMD_UNFUSED) ? 14 : s->mdiag ? 12 : 10;
-    const long long value_bytes = s->plan.vcodes ? 1 : V;
+    const long long value_bytes = joint_form(s) ? 0 : s->plan.vcodes ? 1 : V;
     return s->nnz * (value_bytes + index_bytes_per_nnz(s)) + ((long long)s->n_user + 1) * 4 + passes * s->n_user * V * s->nrhs;
 }
 

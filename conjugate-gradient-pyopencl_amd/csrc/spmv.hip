@@ -449,7 +449,9 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_vc_kernel(SpmvArgs<T> a) 
 // wait for block i + 1's.  The code dwords of block i + 2 travel in registers meanwhile.  LDS buffers alternate; a buffer is only
 // read by issue() and every issue() lies between two barriers that separate it from the writes of the same buffer.
 // -------------------------------------------------------------------------------------------------
-template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL>
+// JOINT: a.codes holds one byte per non-zero naming the (offset, value) PAIR (build_joint_codes; a.dict / a.vdict are the pair
+// dictionaries): one code stream, 1 byte per non-zero; a.vcodes is not read
+template <typename T, int BLOCK, bool NT, bool FUSE_DOT, int UNROLL, bool JOINT>
 __global__ __launch_bounds__(BLOCK) void spmv_rowblock_vcp_kernel(SpmvArgs<T> a) {
     using A = typename VT<T>::acc;
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];       // [2 buffers][column codes cap | value codes cap]
@@ -483,9 +485,12 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_vcp_kernel(SpmvArgs<T> a)
         for (int rg = 0; rg < 2; ++rg) {
             const long long q = (long long)cfirst + rg * 4 * BLOCK + 4 * t;
             const long long qq = q < b.p1 ? q : cfirst;
-            const unsigned *cp = reinterpret_cast<const unsigned *>(a.codes + qq), *vp = reinterpret_cast<const unsigned *>(a.vcodes + qq);
+            const unsigned *cp = reinterpret_cast<const unsigned *>(a.codes + qq);
             c.cw[rg] = NT ? __builtin_nontemporal_load(cp) : *cp;
-            c.vw[rg] = NT ? __builtin_nontemporal_load(vp) : *vp;
+            if constexpr (!JOINT) {
+                const unsigned *vp = reinterpret_cast<const unsigned *>(a.vcodes + qq);
+                c.vw[rg] = NT ? __builtin_nontemporal_load(vp) : *vp;
+            }
         }
         return c;
     };
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_vcp_kernel(SpmvArgs<T> a)
             const int o = rg * 4 * BLOCK + 4 * t;
             if (cfirst + o < b.p1) {
                 *reinterpret_cast<unsigned *>(scc + o) = c.cw[rg];
-                *reinterpret_cast<unsigned *>(svc + o) = c.vw[rg];
+                if constexpr (!JOINT) *reinterpret_cast<unsigned *>(svc + o) = c.vw[rg];
             }
         }
     };
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowblock_vcp_kernel(SpmvArgs<T> a)
     struct Gath { T xv[UNROLL]; unsigned vc[UNROLL]; T dv; int len, row; };      // (vc: the value codes; the dictionary is read when the block is multiplied)
     auto issue = [&](int i, const Bounds &b) -> Gath {
         Gath g;
-        const unsigned char *scc = reinterpret_cast<const unsigned char *>(dyn_smem) + (size_t)(i & 1) * 2 * a.cap, *svc = scc + a.cap;
+        const unsigned char *scc = reinterpret_cast<const unsigned char *>(dyn_smem) + (size_t)(i & 1) * 2 * a.cap, *svc = JOINT ? scc : scc + a.cap;
         const int cfirst = b.p0 & ~3;
         g.row = (rb0 + i) * BLOCK + t;
         const bool live = g.row < a.n && i < nb;
@@ -1008,11 +1013,17 @@ static int spmv_impl(const SpmvPlan &plan, int n, long long nnz, const void *val
                 const dim3 gvc(rowblock_grid(supers, cyc));
                 // rows that fit one batch (max_row <= unroll): the form with the gathers pipelined across the row blocks
                 const bool pipe = plan.max_row > 0 && plan.max_row <= unroll && tune().dev_vc_pipe != 0;
+                // ... and where at most 256 (offset, value) pairs occur: one joint code byte per non-zero
+                const bool joint = pipe && plan.jcodes && tune().dev_joint_codes != 0;
+                if (joint) { a.codes = plan.jcodes; a.dict = plan.jdict_off; a.vdict = static_cast<const T *>(plan.jdict_val); a.vcodes = nullptr; }
 #define CG_VC(NT, UNR)                                                                                                  \
     do {                                                                                                                \
-        if (pipe) {                                                                                                     \
-            if (fuse) CG_LAUNCH_EV((spmv_rowblock_vcp_kernel<T, kBlock, NT, true, UNR>), gvc, block, lds2, st, a);       \
-            else CG_LAUNCH_EV((spmv_rowblock_vcp_kernel<T, kBlock, NT, false, UNR>), gvc, block, lds2, st, a);           \
+        if (joint) {                                                                                                    \
+            if (fuse) CG_LAUNCH_EV((spmv_rowblock_vcp_kernel<T, kBlock, NT, true, UNR, true>), gvc, block, lds2, st, a); \
+            else CG_LAUNCH_EV((spmv_rowblock_vcp_kernel<T, kBlock, NT, false, UNR, true>), gvc, block, lds2, st, a);     \
+        } else if (pipe) {                                                                                              \
+            if (fuse) CG_LAUNCH_EV((spmv_rowblock_vcp_kernel<T, kBlock, NT, true, UNR, false>), gvc, block, lds2, st, a); \
+            else CG_LAUNCH_EV((spmv_rowblock_vcp_kernel<T, kBlock, NT, false, UNR, false>), gvc, block, lds2, st, a);    \
         } else if (fuse) CG_LAUNCH_EV((spmv_rowblock_vc_kernel<T, kBlock, NT, true, UNR>), gvc, block, lds2, st, a);     \
         else CG_LAUNCH_EV((spmv_rowblock_vc_kernel<T, kBlock, NT, false, UNR>), gvc, block, lds2, st, a);                \
     } while (0)

@@ -193,6 +193,10 @@ int cgamd_solver_index_codes(cgamd_solver *s);
  * that also run on one-byte column codes: 2 bytes per non-zero from memory, same bits); 0 = the SpMV reads aValues.
  * (cgamd_tune("dev.value_codes", 0) turns the form off for A/B runs.) */
 int cgamd_solver_value_codes(cgamd_solver *s);
+/* > 0: the SpMV reads ONE byte per non-zero that names the (column offset, value) pair -- matrices with at most 256 distinct pairs whose
+ * longest row fits one batch of the row walk (constant-coefficient stencils: as many pairs as offsets); the value is the number of
+ * pairs.  0: it reads the column codes and the value codes (2 bytes), or aCols / aValues. */
+int cgamd_solver_joint_codes(cgamd_solver *s);
 int cgamd_transpose(cgamd_ctx *ctx, int dtype, int rows, int cols, const void *in, void *out);
 /* algorithmic HBM bytes of one SpMV / one CG iteration of this solver (SURVEY §8d formulae: 14 vector passes for the
  * reference's op structure, 11 for its "fused minimum"; the default loop here moves 10) */

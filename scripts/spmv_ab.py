@@ -60,7 +60,7 @@ def main():
     ys = torch.empty(n, dtype=tdt, device=dev)
     torch.cuda.synchronize()
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
-    defaults = {"dev.generic_spmv": 0, "spmv_nt": -1, "dev.spmv_grid": 0, "vec_grid": 0, "spmv_cycle": 64, "dev.spmv_chunked": 1, "dev.spmv_chunk_kb": 0, "dev.spmv_slice_kb": 0, "dev.no_fold_alpha": 0, "dev.spmv_unroll": 0, "vec_nt": -1, "index_codes": 1, "index_codes16": 1, "dev.value_codes": 1, "dev.vc_pipe": 1}
+    defaults = {"dev.generic_spmv": 0, "spmv_nt": -1, "dev.spmv_grid": 0, "vec_grid": 0, "spmv_cycle": 64, "dev.spmv_chunked": 1, "dev.spmv_chunk_kb": 0, "dev.spmv_slice_kb": 0, "dev.no_fold_alpha": 0, "dev.spmv_unroll": 0, "vec_nt": -1, "index_codes": 1, "index_codes16": 1, "dev.value_codes": 1, "dev.vc_pipe": 1, "dev.joint_codes": 1}
     solvers = []
     for cfg in args.cfgs:
         kv = dict(defaults)

@@ -19,6 +19,7 @@ def tuned(pkg):
     lib.cgamd_tune(b"index_codes", 1)
     lib.cgamd_tune(b"index_codes16", 1)
     lib.cgamd_tune(b"dev.value_codes", 1)
+    lib.cgamd_tune(b"dev.joint_codes", 1)
     lib.cgamd_tune(b"index_codes_min_mb", 32)
     lib.cgamd_tune(b"resident", 1)
 
@@ -316,7 +317,7 @@ def _run_values(pkg, ctx, ip, ix, da, dtype, b, iters):
     s.set_rhs(bd, None, on_device=True)
     s.iterate(iters)
     ctx.synchronize()
-    out = (s.value_codes, s.index_codes, y.cpu().numpy(), s.history().copy(), s.x().copy(), s.spmv_moved_bytes)
+    out = (s.value_codes, s.index_codes, y.cpu().numpy(), s.history().copy(), s.x().copy(), s.spmv_moved_bytes, s.joint_codes)
     s.close()
     return out
 
@@ -361,16 +362,22 @@ def test_value_codes_change_no_bit(pkg, tuned, dt, kind):
     b = np.linspace(1.0, 2.0, n) * (1 + (0.5j if dt[0] == "c" else 0))
     iters = 25
     tuned(resident=0, resident_wide=0, index_codes=1, index_codes_min_mb=0, **{"dev.value_codes": 1})
-    v1, k1, y1, h1, x1, mb1 = _run_values(pkg, ctx, ip, ix, da, dtype, b, iters)
-    tuned(**{"dev.value_codes": 0})
-    v0, k0, y0, h0, x0, mb0 = _run_values(pkg, ctx, ip, ix, da, dtype, b, iters)
+    v1, k1, y1, h1, x1, mb1, j1 = _run_values(pkg, ctx, ip, ix, da, dtype, b, iters)
+    tuned(**{"dev.joint_codes": 0})
+    v2, k2, y2, h2, x2, mb2, j2 = _run_values(pkg, ctx, ip, ix, da, dtype, b, iters)      # two code bytes per non-zero
+    tuned(**{"dev.value_codes": 0, "dev.joint_codes": 1})
+    v0, k0, y0, h0, x0, mb0, j0 = _run_values(pkg, ctx, ip, ix, da, dtype, b, iters)
     pkg._lib.check(pkg._lib.load().cgamd_tune(b"resident_wide", 1))
     assert v0 == 0 and k0 == k1 and k1 in (5, 7)
     want = {"lap3d": 2, "lap2d": 2, "v256": 256, "v257": 0, "helm": 0}[kind] if dt != "c128" else 0
     assert v1 == want, (v1, want)
     V = np.dtype(dtype).itemsize
-    assert mb0 - mb1 == (len(ix) * (V - 1) if want else 0)       # the moved-byte model follows the form that runs
+    # joint codes: one byte names the (offset, value) pair -- the stencils have as many pairs as offsets, 256 values on 7 offsets too many
+    assert j0 == 0 and j2 == 0 and j1 == ({"lap3d": 7, "lap2d": 5}.get(kind, 0) if want else 0), (j1, kind)
+    assert mb0 - mb2 == (len(ix) * (V - 1) if want else 0)       # the moved-byte model follows the form that runs
+    assert mb0 - mb1 == (len(ix) * V if j1 else len(ix) * (V - 1) if want else 0)
     assert np.array_equal(y1, y0) and np.array_equal(h1, h0) and np.array_equal(x1, x0)
+    assert np.array_equal(y2, y0) and np.array_equal(h2, h0) and np.array_equal(x2, x0)
     if kind != "helm":
         wide = np.complex128 if dt[0] == "c" else np.float64
         xo, ho = cg_oracle.cg(ip, ix, da.astype(wide), b.astype(wide), n_iterations=iters, mode=cg_oracle.MODE_SEQUENTIAL)
