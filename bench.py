@@ -234,7 +234,7 @@ def small_system_extra(pkg, ctx, torch, dev):
             "finite_history": bool(np.all(np.isfinite(h[: iters + 65])))}
 
 
-def rate_fields(spmv_moved, spmv_csr, spmv_ms, spmv_alone_ms, iter_moved, iter_csr, it_s, traffic, traffic_source, n_offsets, n_values=0):
+def rate_fields(spmv_moved, spmv_csr, spmv_ms, spmv_alone_ms, iter_moved, iter_csr, it_s, traffic, traffic_source, n_offsets, n_values=0, n_pairs=0):
     """The rate / roofline part of the single-GPU line (pure arithmetic: tests/test_bench_launch.py checks it without a GPU).
 
     `moved`: what the kernels that ran really move -- index bytes per non-zero as the SpMV reads them (1 with the one-byte
@@ -255,14 +255,17 @@ def rate_fields(spmv_moved, spmv_csr, spmv_ms, spmv_alone_ms, iter_moved, iter_c
         "roofline": {"bound": "hbm",
                      "kernel": ("spmv_rowblock_vcp_kernel" if n_values > 0 else "spmv_rowblock_kernel") + " (CSR SpMV fused with d.q partials"
                                + (", column indices read as one-byte codes" if n_offsets > 0 else "")
-                               + (", values as one-byte codes into the matrix's %d distinct entries: no longer bound by bytes, see DESIGN.md" % n_values if n_values > 0 else "")
+                               + (", values as one-byte codes into the matrix's %d distinct entries" % n_values if n_values > 0 and not n_pairs else "")
+                               + (", ONE code byte per non-zero naming one of the matrix's %d (offset, value) pairs" % n_pairs if n_pairs else "")
+                               + (": no longer bound by bytes, see DESIGN.md" if n_values > 0 else "")
                                + "), in-loop average over the instrumented pass (HIP events on each dispatch)",
                      "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_ratio": (traffic / spmv_moved) if traffic else None,
                      "moved_bytes_per_launch": spmv_moved, "avg_launch_ms": spmv_ms,
                      "index_codes": {"distinct_offsets": n_offsets, "index_bytes_per_nonzero": 2 if n_offsets == 65536 else 1 if n_offsets > 0 else 4},
-                     "value_codes": {"distinct_values": n_values, "value_bytes_per_nonzero": 1 if n_values > 0 else None},
+                     "value_codes": {"distinct_values": n_values, "value_bytes_per_nonzero": 1 if n_values > 0 else None,
+                                     "joint_pairs": n_pairs, "code_bytes_per_nonzero": 1 if n_pairs else 2 if n_values > 0 else None},
                      "effective_csr_bytes_per_launch": spmv_csr, "effective_csr_gbs": spmv_csr / (spmv_ms * 1e-3) / 1e9},
     }
 
@@ -329,7 +332,7 @@ def bench_single(args, pkg, ctx, torch, dev, nx, ny, nz, dtype):
     }
     res.update(rate_fields(spmv_moved=solver.spmv_moved_bytes, spmv_csr=spmv_bytes, spmv_ms=spmv_ms, spmv_alone_ms=spmv_alone_ms,
                            iter_moved=solver.iter_moved_bytes, iter_csr=iter_bytes, it_s=it_s, traffic=traffic,
-                           traffic_source=traffic_source, n_offsets=solver.index_codes, n_values=solver.value_codes))
+                           traffic_source=traffic_source, n_offsets=solver.index_codes, n_values=solver.value_codes, n_pairs=solver.joint_codes))
     n_values = solver.value_codes
     solver.close()
     if n_values > 0 and not args.unfused:
